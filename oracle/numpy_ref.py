@@ -1,0 +1,264 @@
+"""ORACLE CROSS-CHECK — TEST INFRASTRUCTURE ONLY.
+
+An independent NumPy/SciPy restatement of the same algorithms as oracle/*.cpp, sharing no code with it
+(scipy.spatial.cKDTree for neighbours, numpy.linalg for SVD / eigen / solve, scipy.linalg.expm for the
+SE(3) exponential).  Because the reference has no golden vectors (PARITY UNPINNED), the C++
+oracle is pinned by requiring agreement with this file on small seeded inputs (tests/test_oracle_*.py) and
+the agreed outputs are committed as fixtures under tests/golden/.
+
+Specs followed: SURVEY.md §8a rows P1, P2, P5, F2-F9, N1-N3 ([UPSTREAM-RECALL]); call sites in
+/root/reference/points_prefiltering/src/points_prefiltering.cpp:102-140 and
+/root/reference/lidar_scan_matcher/src/lidar_scan_matcher.cpp:37-72,149-172.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import expm
+from scipy.spatial import cKDTree
+
+
+# ---------------------------------------------------------------- PCL pieces
+def distance_filter(pts: np.ndarray, min_distance: float) -> np.ndarray:
+    nrm = np.sqrt((pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]) + pts[:, 2] * pts[:, 2]).astype(np.float32)
+    return pts[min_distance < nrm.astype(np.float64)]
+
+
+def voxel_grid(pts: np.ndarray, leaf: float) -> np.ndarray:
+    """pcl::VoxelGrid centroids (all fields), ascending linear voxel index.  fp32 index arithmetic; centroids
+    here in float64 then cast (the C++ oracle accumulates in fp32, so compare with ~1e-5 tolerance)."""
+    pts = np.asarray(pts, dtype=np.float32)
+    inv = np.float32(1.0) / np.float32(leaf)
+    mn = pts[:, :3].min(axis=0)
+    mx = pts[:, :3].max(axis=0)
+    min_b = np.floor(mn * inv).astype(np.int64)
+    max_b = np.floor(mx * inv).astype(np.int64)
+    div_b = max_b - min_b + 1
+    ijk = (np.floor(pts[:, :3] * inv) - min_b.astype(np.float32)).astype(np.int64)
+    idx = ijk[:, 0] + ijk[:, 1] * div_b[0] + ijk[:, 2] * div_b[0] * div_b[1]
+    order = np.argsort(idx, kind="stable")
+    uniq, start, counts = np.unique(idx[order], return_index=True, return_counts=True)
+    sums = np.add.reduceat(pts[order].astype(np.float64), start, axis=0)
+    return (sums / counts[:, None]).astype(np.float32)
+
+
+def sor(pts: np.ndarray, mean_k: int, stddev_mul: float):
+    xyz = pts[:, :3].astype(np.float64)
+    d, _ = cKDTree(xyz).query(xyz, k=mean_k + 1)
+    dist = d[:, 1:].mean(axis=1).astype(np.float32).astype(np.float64)
+    n = len(pts)
+    s, sq = dist.sum(), (dist * dist).sum()
+    mean = s / n
+    std = np.sqrt((sq - s * s / n) / (n - 1))
+    keep = ~(dist > mean + stddev_mul * std)
+    return pts[keep], keep, dist
+
+
+def fitness(src: np.ndarray, tgt: np.ndarray, T: np.ndarray, max_range: float = np.inf) -> float:
+    p = src[:, :3].astype(np.float64) @ T[:3, :3].T.astype(np.float64) + T[:3, 3].astype(np.float64)
+    d, _ = cKDTree(tgt[:, :3].astype(np.float64)).query(p, k=1)
+    d2 = d * d
+    ok = d2 <= max_range
+    return float(d2[ok].mean()) if ok.any() else float(np.finfo(np.float64).max)
+
+
+# ---------------------------------------------------------------- fast_gicp
+def covariances(pts: np.ndarray, k: int = 20, method: str = "PLANE") -> np.ndarray:
+    xyz = pts[:, :3].astype(np.float64)
+    _, nn = cKDTree(xyz).query(xyz, k=k)
+    nb = xyz[nn]  # [n,k,3]
+    c = nb - nb.mean(axis=1, keepdims=True)
+    cov = np.einsum("nki,nkj->nij", c, c) / k
+    if method == "NONE":
+        return cov
+    if method == "FROBENIUS":
+        C = cov + 1e-3 * np.eye(3)
+        Ci = np.linalg.inv(C)
+        return np.linalg.inv(Ci / np.linalg.norm(Ci, axis=(1, 2), keepdims=True))
+    U, s, Vt = np.linalg.svd(cov)
+    if method == "PLANE":
+        vals = np.broadcast_to(np.array([1.0, 1.0, 1e-3]), s.shape)
+    elif method == "MIN_EIG":
+        vals = np.maximum(s, 1e-3)
+    elif method == "NORMALIZED_MIN_EIG":
+        vals = np.maximum(s / s.max(axis=1, keepdims=True), 1e-3)
+    else:
+        raise ValueError(method)
+    return np.einsum("nij,nj,njk->nik", U, vals, Vt)
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], dtype=np.float64)
+
+
+def se3_exp(d: np.ndarray) -> np.ndarray:
+    """exp of the 4x4 twist [[skew(w), v],[0,0]] — equals fast_gicp's se3_exp (so3 quaternion + V matrix)."""
+    A = np.zeros((4, 4))
+    A[:3, :3] = skew(d[:3])
+    A[:3, 3] = d[3:]
+    return expm(A)
+
+
+def gicp_linearize(src, src_cov, tgt, tgt_cov, T, max_corr):
+    """H (6x6), b (6), error, correspondences — F3 + F4 with float64 throughout except the NN query, which uses
+    the fp32 transform of the fp32 point like the C++ oracle."""
+    T = np.asarray(T, dtype=np.float64)
+    Tf = T.astype(np.float32)
+    s32 = src[:, :3].astype(np.float32)
+    q = (Tf[:3, :3] @ s32.T).T + Tf[:3, 3]
+    d, j = cKDTree(tgt[:, :3].astype(np.float64)).query(q.astype(np.float64), k=1)
+    ok = d * d < max_corr * max_corr
+    corr = np.where(ok, j, -1)
+    R = T[:3, :3]
+    a = src[ok, :3].astype(np.float64) @ R.T + T[:3, 3]
+    e = tgt[j[ok], :3].astype(np.float64) - a
+    RCR = tgt_cov[j[ok]] + R @ src_cov[ok] @ R.T
+    M = np.linalg.inv(RCR)
+    J = np.zeros((len(a), 3, 6))
+    J[:, 0, 1], J[:, 0, 2] = -a[:, 2], a[:, 1]
+    J[:, 1, 0], J[:, 1, 2] = a[:, 2], -a[:, 0]
+    J[:, 2, 0], J[:, 2, 1] = -a[:, 1], a[:, 0]
+    J[:, :, 3:] = -np.eye(3)
+    MJ = M @ J
+    H = np.einsum("nki,nkj->ij", J, MJ)
+    Me = np.einsum("nij,nj->ni", M, e)
+    b = np.einsum("nki,nk->i", J, Me)
+    err = float(np.einsum("ni,ni->", e, Me))
+    return H, b, err, corr
+
+
+def _gicp_error(src, tgt, corr, M_all, T):
+    ok = corr >= 0
+    a = src[ok, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    e = tgt[corr[ok], :3].astype(np.float64) - a
+    return float(np.einsum("ni,nij,nj->", e, M_all, e))
+
+
+def gicp_align(src, tgt, *, k=20, max_iterations=64, transformation_epsilon=0.01, rotation_epsilon=2e-3, max_corr=2.0,
+               method="PLANE", lm_max_iterations=10, lm_init_lambda_factor=1e-9, force_iterations=False, guess=None):
+    """LsqRegistration::computeTransformation + step_lm (F6, F7, F9)."""
+    src_cov = covariances(src, k, method)
+    tgt_cov = covariances(tgt, k, method)
+    x0 = np.eye(4) if guess is None else np.asarray(guess, dtype=np.float64).copy()
+    lam = -1.0
+    converged = False
+    iters = 0
+
+    def is_conv(delta):
+        r = np.abs(delta[:3, :3] - np.eye(3)).max() / rotation_epsilon
+        t = np.abs(delta[:3, 3]).max() / transformation_epsilon
+        return max(r, t) < 1
+
+    for i in range(max_iterations):
+        if converged:
+            break
+        iters = i + 1
+        H, b, y0, corr = gicp_linearize(src, src_cov, tgt, tgt_cov, x0, max_corr)
+        ok = corr >= 0
+        M = np.linalg.inv(tgt_cov[corr[ok]] + x0[:3, :3] @ src_cov[ok] @ x0[:3, :3].T)
+        if lam < 0:
+            lam = lm_init_lambda_factor * np.abs(np.diag(H)).max()
+        nu = 2.0
+        accepted = False
+        delta = np.eye(4)
+        for _ in range(lm_max_iterations):
+            d = np.linalg.solve(H + lam * np.eye(6), -b)
+            delta = se3_exp(d)
+            xi = delta @ x0
+            yi = _gicp_error(src, tgt, corr, M, xi)
+            rho = (y0 - yi) / d.dot(lam * d - b)
+            if rho < 0:
+                if not force_iterations and is_conv(delta):
+                    accepted = True
+                    break
+                lam *= nu
+                nu *= 2
+                continue
+            x0 = xi
+            lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+            accepted = True
+            break
+        if not accepted:
+            break
+        converged = (not force_iterations) and is_conv(delta)
+    return x0.astype(np.float32), converged, iters
+
+
+# ---------------------------------------------------------------- NDT
+def ndt_cells(tgt: np.ndarray, resolution: float, min_points: int = 6, eig_mult: float = 0.01):
+    """VoxelGridCovariance leaves (N1): dict linear_idx -> (n, mean, cov, icov) for n >= min_points and valid."""
+    pts = np.asarray(tgt, dtype=np.float32)
+    inv = np.float32(1.0) / np.float32(resolution)
+    min_b = np.floor(pts[:, :3].min(axis=0) * inv).astype(np.int64)
+    max_b = np.floor(pts[:, :3].max(axis=0) * inv).astype(np.int64)
+    div_b = max_b - min_b + 1
+    ijk = (np.floor(pts[:, :3] * inv) - min_b.astype(np.float32)).astype(np.int64)
+    idx = ijk[:, 0] + ijk[:, 1] * div_b[0] + ijk[:, 2] * div_b[0] * div_b[1]
+    out = {}
+    order = np.argsort(idx, kind="stable")
+    uniq, start, counts = np.unique(idx[order], return_index=True, return_counts=True)
+    p64 = pts[order, :3].astype(np.float64)
+    for u, s, c in zip(uniq, start, counts):
+        if c < min_points:
+            continue
+        q = p64[s : s + c]
+        mean = q.mean(axis=0)
+        cov = np.cov(q.T, bias=True) * (c - 1.0) / c  # population covariance times (n-1)/n, as PCL computes it
+        w, V = np.linalg.eigh(cov)
+        if w[0] < 0 or w[1] < 0 or w[2] <= 0:
+            continue
+        lo = eig_mult * w[2]
+        if w[0] < lo:
+            w = w.copy()
+            w[0] = lo
+            if w[1] < lo:
+                w[1] = lo
+            cov = V @ np.diag(w) @ V.T
+        out[int(u)] = (int(c), mean, cov, np.linalg.inv(cov))
+    return out, min_b, div_b
+
+
+def rot_xyz(roll, pitch, yaw):
+    cx, sx, cy, sy, cz, sz = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def ndt_score(src, cells, min_b, div_b, resolution, p6, outlier_ratio=0.55, frozen_cells=None):
+    """NDT score (eq. 6.9/6.10 [Magnusson 2009]) over DIRECT7 neighbourhoods, float64.  With ``frozen_cells`` (a list of
+    per-point cell-key lists) the neighbourhood assignment is held fixed so finite differences are smooth."""
+    c1 = 10 * (1 - outlier_ratio)
+    c2 = outlier_ratio / resolution ** 3
+    d3 = -np.log(c2)
+    d1 = -np.log(c1 + c2) - d3
+    d2 = -2 * np.log((-np.log(c1 * np.exp(-0.5) + c2) - d3) / d1)
+    R = rot_xyz(*p6[3:])
+    x = src[:, :3].astype(np.float64) @ R.T + np.asarray(p6[:3])
+    inv = 1.0 / resolution
+    disp = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+    max_b = min_b + div_b - 1
+    score = 0.0
+    assign = []
+    for i in range(len(x)):
+        if frozen_cells is None:
+            ijk = np.floor(x[i].astype(np.float32) * np.float32(inv)).astype(np.int64)
+            keys = []
+            for dsp in disp:
+                c = ijk + dsp
+                if np.any(c < min_b) or np.any(c > max_b):
+                    continue
+                key = int((c[0] - min_b[0]) + (c[1] - min_b[1]) * div_b[0] + (c[2] - min_b[2]) * div_b[0] * div_b[1])
+                if key in cells:
+                    keys.append(key)
+            assign.append(keys)
+        else:
+            keys = frozen_cells[i]
+        for key in keys:
+            _, mean, _, icov = cells[key]
+            xt = x[i] - mean
+            e = np.exp(-d2 * xt @ icov @ xt / 2)
+            if d2 * e > 1 or d2 * e < 0 or np.isnan(e):
+                continue
+            score += -d1 * e
+    return score, assign

@@ -1,0 +1,112 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product path.
+ *
+ * CPU restatement (C++17 + OpenMP, fp64 where the upstream engines use double) of the algorithms the
+ * reference's hot path runs: PCL filters, FLANN exact k-NN, fast_gicp::FastGICP and
+ * pclomp::NormalDistributionsTransform.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load this library — as the checker / the timed CPU baseline, never as the
+ * thing shipped.
+ *
+ * PARITY UNPINNED.  The engines live in un-vendored submodules (git@github.com:RyuYamamoto/fast_gicp,
+ * git@github.com:RyuYamamoto/ndt_omp — /root/reference/.gitmodules:1-6, pinned SHAs unknown, directories
+ * empty) and in system PCL/Eigen, none of which exist in this image; the reference holds no tests, golden
+ * vectors or fixtures.  Every function below therefore restates the *published*
+ * algorithm of the upstream project ([UPSTREAM-RECALL] rows F1-F10, N1-N5, P1-P5 of SURVEY.md §8a) and is
+ * anchored on the reference's own call sites, cited per function.  It is pinned instead by (1) analytic
+ * known-answer tests, (2) an independent NumPy/SciPy restatement (oracle/numpy_ref.py) and (3) recovery of
+ * the known ground-truth SE(3) on synthetic scenes — see tests/test_oracle_*.py.
+ *
+ * All clouds are packed float4 (x, y, z, intensity), n points.  Matrices are row-major.
+ */
+#ifndef ORACLE_H_
+#define ORACLE_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* fast_gicp::RegularizationMethod */
+enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4 };
+/* fast_gicp::LSQ_OPTIMIZER_TYPE */
+enum { ORC_OPT_LM = 0, ORC_OPT_GN = 1 };
+
+/* Same field order/meaning as mi355_gicp_params (include/mi355_lidar.h). */
+typedef struct orc_gicp_params {
+  int k_correspondences;              /* setCorrespondenceRandomness   (lidar_scan_matcher.cpp:48, yaml:19 -> 20) */
+  int max_iterations;                 /* setMaximumIterations          (lidar_scan_matcher.cpp:49, yaml:9  -> 64) */
+  double transformation_epsilon;      /* setTransformationEpsilon      (lidar_scan_matcher.cpp:50, yaml:11 -> 0.01) */
+  double rotation_epsilon;            /* fast_gicp default 2e-3 (not set by the node) */
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance  (lidar_scan_matcher.cpp:51, yaml:18 -> 2.0) */
+  int regularization_method;          /* fast_gicp default PLANE */
+  int optimizer;                      /* fast_gicp default LevenbergMarquardt */
+  int lm_max_iterations;              /* fast_gicp default 10 */
+  double lm_init_lambda_factor;       /* fast_gicp default 1e-9 */
+  int force_iterations;               /* 0 = reference behaviour; 1 = never early-stop (benchmark config: exactly max_iterations) */
+  int num_threads;                    /* setNumThreads (lidar_scan_matcher.cpp:52, yaml:10 -> 4); 0 = all */
+} orc_gicp_params;
+
+typedef struct orc_result {
+  float T[16];        /* final_transformation_, row-major 4x4 (getFinalTransformation) */
+  int converged;      /* hasConverged() */
+  int iterations;     /* optimiser steps executed */
+  double error;       /* GICP: last accepted sum of Mahalanobis errors; NDT: final score */
+  double H[36];       /* GICP: final_hessian_; NDT: last Hessian */
+  double trans_probability; /* NDT only */
+  double ms_setup, ms_align; /* wall-clock breakdown (kd-trees+covariances / optimisation) */
+} orc_result;
+
+typedef struct orc_ndt_params {
+  double transformation_epsilon; /* lidar_scan_matcher.cpp:65, yaml:11 -> 0.01 */
+  double step_size;              /* lidar_scan_matcher.cpp:66, yaml:14 -> 0.1 */
+  double resolution;             /* lidar_scan_matcher.cpp:67, yaml:15 -> 2.0 (back end / BASELINE: 1.0) */
+  int max_iterations;            /* lidar_scan_matcher.cpp:68, yaml:9  -> 64 */
+  double outlier_ratio;          /* PCL default 0.55 */
+  int min_points_per_voxel;      /* VoxelGridCovariance default 6 */
+  double min_covar_eigvalue_mult;/* VoxelGridCovariance default 0.01 */
+  int legacy_mt_skip;            /* 1 = restate the `interval_converged = (step_max-step_min) > 0` variant found in
+                                    older PCL / some ndt_omp trees (line search never iterates); 0 = More-Thuente as in
+                                    SURVEY.md row N4 */
+  int num_threads;               /* lidar_scan_matcher.cpp:70 */
+} orc_ndt_params;
+
+void orc_gicp_default_params(orc_gicp_params* p);
+void orc_ndt_default_params(orc_ndt_params* p);
+int orc_max_threads(void);
+
+/* ---- PCL pieces ---- */
+int orc_distance_filter(const float* pts, size_t n, double min_distance, float* out, size_t* out_n);
+int orc_voxel_grid(const float* pts, size_t n, float leaf, float* out, size_t* out_n, int* overflow);
+int orc_sor(const float* pts, size_t n, int mean_k, double stddev_mul, float* out, size_t* out_n,
+            uint8_t* keep_mask /*n, may be NULL*/, float* mean_dist /*n, may be NULL*/);
+int orc_transform(const float* pts, size_t n, const float* T16, float* out);
+int orc_knn(const float* pts, size_t n, const float* queries, size_t m, int k, int* idx, float* d2, int brute_force);
+int orc_fitness(const float* src, size_t n, const float* tgt, size_t m, const float* T16, double max_range, double* score);
+
+/* ---- fast_gicp ---- */
+int orc_covariances(const float* pts, size_t n, int k, int method, double* covs9 /* n x 9 */, int num_threads);
+void orc_se3_exp(const double d[6], double T16[16]);
+int orc_gicp_linearize(const float* src, size_t n, const double* src_cov9, const float* tgt, size_t m,
+                       const double* tgt_cov9, const double T16[16], double max_corr, double* H36, double* b6,
+                       double* err, int* corr /*n*/, double* mahal9 /* n x 9, may be NULL */);
+int orc_gicp_error(const float* src, size_t n, const float* tgt, const int* corr, const double* mahal9,
+                   const double T16[16], double* err);
+int orc_gicp_align(const float* src, size_t n, const float* tgt, size_t m, const orc_gicp_params* p,
+                   const float* guess16, orc_result* r);
+
+/* ---- pclomp NDT ---- */
+/* Builds the VoxelGridCovariance leaves.  Outputs (capacity = n leaves): linear voxel index, point count
+ * (-1 = rejected), mean[3], cov[9], icov[9]; grid: min_b[3], div_b[3]. Returns the number of leaves. */
+int orc_ndt_cells(const float* tgt, size_t m, const orc_ndt_params* p, int64_t* leaf_idx, int* leaf_n,
+                  double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3, size_t* n_leaves);
+/* score / gradient / Hessian of pose p6 = (tx,ty,tz,roll,pitch,yaw) exactly as computeDerivatives evaluates it
+ * (per-point fp32 maths of ndt_omp).  hessian_fp64 != 0 evaluates the Hessian with computeHessian's fp64 path. */
+int orc_ndt_derivatives(const float* src, size_t n, const float* tgt, size_t m, const orc_ndt_params* p,
+                        const double p6[6], double* score, double* grad6, double* hess36, int hessian_fp64);
+int orc_ndt_align(const float* src, size_t n, const float* tgt, size_t m, const orc_ndt_params* p,
+                  const float* guess16, orc_result* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

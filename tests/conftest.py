@@ -1,0 +1,45 @@
+"""Test configuration.
+
+Markers: ``gpu`` = needs a real MI355X (run by the driver on the GPU box with ``-m gpu``); everything else
+runs on CPU (``-m "not gpu"``).  The oracle (oracle/) is test infrastructure: tests use it as the checker of
+the HIP path, never the other way round.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
+
+
+@pytest.fixture(scope="session")
+def small_pair():
+    """4 096-ray pair (64 rings x 64 azimuth), prefiltered like the pipeline does: distance filter 1.0 m + voxel 0.2 m."""
+    from lidar_graph_slam_amd import synth
+    from oracle import oracle_py as O
+
+    src, tgt, T_gt = synth.make_pair(n_azimuth=64)
+    s = O.voxel_grid(O.distance_filter(src, 1.0), 0.2)[0]
+    t = O.voxel_grid(O.distance_filter(tgt, 1.0), 0.2)[0]
+    return s, t, T_gt
+
+
+@pytest.fixture(scope="session")
+def medium_pair():
+    """16 384-ray pair (64 x 256), raw (not prefiltered)."""
+    from lidar_graph_slam_amd import synth
+
+    return synth.make_pair(n_azimuth=256)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    path = os.path.join(ROOT, "tests", "golden", "golden_small.npz")
+    return dict(np.load(path))
