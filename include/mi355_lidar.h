@@ -1,0 +1,187 @@
+/* mi355_lidar.h — C-ABI of the MI355X-native LiDAR odometry front-end (libmi355_lidar.so).
+ *
+ * This is the drop-in boundary for the hot path of RyuYamamoto/lidar_graph_slam: the PCL / fast_gicp / ndt_omp
+ * calls made by the `points_prefiltering` and `lidar_scan_matcher` nodes (and the loop-closure registration of
+ * `graph_based_slam`).  Every entry point names the reference interface it replaces (file:line under the
+ * reference tree).  extern "C", plain pointers and sizes, opaque handles, no C++/torch types, no exceptions:
+ * every function returns 0 on success and a negative MI355_E* code otherwise; mi355_last_error() gives the text.
+ *
+ * Clouds are (base pointer, count, byte stride): xyz as 3 floats at offset 0, intensity as a float at
+ * `intensity_offset` bytes — stride 32 / intensity 16 for pcl::PointXYZI, stride 16 / intensity 12 for the packed
+ * float4 device layout.  Host-pointer entry points copy in/out; the *_dev entry points take device pointers
+ * (e.g. torch tensor .data_ptr()) in the packed float4 layout and run on the context's HIP stream.
+ * One handle may be used from one thread at a time; different handles are independent.
+ */
+#ifndef MI355_LIDAR_H_
+#define MI355_LIDAR_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_EINVAL (-1)   /* bad argument */
+#define MI355_EHIP (-2)     /* HIP runtime error (text in mi355_last_error) */
+#define MI355_ECAPACITY (-3)/* output buffer too small */
+#define MI355_ESTATE (-4)   /* call order (e.g. align before set_target) */
+
+typedef struct mi355_ctx mi355_ctx;
+typedef struct mi355_reg mi355_reg;
+typedef struct mi355_batch mi355_batch;
+
+/* Cloud layout descriptor. */
+typedef struct mi355_cloud_view {
+  const void* data;
+  size_t n;
+  size_t stride;            /* bytes between points */
+  size_t intensity_offset;  /* bytes from point start to the intensity float */
+} mi355_cloud_view;
+
+/* registration_method of lidar_scan_matcher.param.yaml:4 / lidar_scan_matcher.cpp:37,55 */
+enum { MI355_METHOD_FAST_GICP = 0, MI355_METHOD_NDT_OMP = 1 };
+/* fast_gicp::RegularizationMethod (default PLANE) */
+enum { MI355_REG_NONE = 0, MI355_REG_MIN_EIG = 1, MI355_REG_NORMALIZED_MIN_EIG = 2, MI355_REG_PLANE = 3, MI355_REG_FROBENIUS = 4 };
+/* fast_gicp::LSQ_OPTIMIZER_TYPE (default LevenbergMarquardt) */
+enum { MI355_OPT_LM = 0, MI355_OPT_GN = 1 };
+
+/* fast_gicp::FastGICP setters — lidar_scan_matcher.cpp:48-52 (values: lidar_scan_matcher.param.yaml:9-11,18-19)
+ * and graph_based_slam.cpp:94-98. */
+typedef struct mi355_gicp_params {
+  int k_correspondences;              /* setCorrespondenceRandomness(20) */
+  int max_iterations;                 /* setMaximumIterations(64) */
+  double transformation_epsilon;      /* setTransformationEpsilon(0.01) */
+  double rotation_epsilon;            /* fast_gicp default 2e-3 */
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance(2.0) */
+  int regularization_method;          /* MI355_REG_PLANE */
+  int optimizer;                      /* MI355_OPT_LM */
+  int lm_max_iterations;              /* 10 */
+  double lm_init_lambda_factor;       /* 1e-9 */
+  int force_iterations;               /* 1 = run exactly max_iterations (benchmark config: "20 GICP iters") */
+  int num_threads;                    /* setNumThreads — accepted for interface parity, unused on the GPU */
+} mi355_gicp_params;
+
+/* pclomp::NormalDistributionsTransform setters — lidar_scan_matcher.cpp:65-70 (yaml:9-11,14-15),
+ * graph_based_slam.cpp:112-117. Neighbourhood search is DIRECT7 (lidar_scan_matcher.cpp:69). */
+typedef struct mi355_ndt_params {
+  double transformation_epsilon; /* 0.01 */
+  double step_size;              /* 0.1 */
+  double resolution;             /* 2.0 front end / 1.0 back end */
+  int max_iterations;            /* 64 */
+  double outlier_ratio;          /* PCL default 0.55 */
+  int min_points_per_voxel;      /* 6 */
+  double min_covar_eigvalue_mult;/* 0.01 */
+  int legacy_mt_skip;            /* see oracle/oracle.h */
+  int num_threads;               /* unused on the GPU */
+} mi355_ndt_params;
+
+/* points_prefiltering parameters — points_prefiltering.launch.xml:2-13. */
+typedef struct mi355_prefilter_params {
+  double min_distance;   /* min_distance_cloud 1.0; <= 0 disables the distance filter (points_prefiltering.cpp:102-112) */
+  double leaf_size;      /* leaf_size 0.1 (BASELINE: 0.2); <= 0 disables VoxelGrid (cpp:114-121) */
+  int mean_k;            /* mean_k 30; <= 0 disables StatisticalOutlierRemoval (cpp:132-140) */
+  double stddev_mul;     /* stddev 1.2 */
+} mi355_prefilter_params;
+
+/* Result of one alignment: what hasConverged()/getFinalTransformation()/getFitnessScore() expose
+ * (lidar_scan_matcher.cpp:167,172; graph_based_slam.cpp:320-322). */
+typedef struct mi355_result {
+  float T[16];              /* final_transformation_, row-major 4x4 */
+  int converged;
+  int iterations;
+  double error;             /* GICP: last accepted sum of Mahalanobis errors; NDT: final score */
+  double H[36];             /* GICP: final_hessian_; NDT: last Hessian */
+  double trans_probability; /* NDT */
+  int n_source;             /* source points actually registered (after any prefilter) */
+  int n_target;
+  int n_inliers;            /* correspondences within max_correspondence_distance at the last linearisation (GICP) */
+  int reserved;
+} mi355_result;
+
+void mi355_gicp_default_params(mi355_gicp_params* p);
+void mi355_ndt_default_params(mi355_ndt_params* p);
+void mi355_prefilter_default_params(mi355_prefilter_params* p);
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+mi355_ctx* mi355_create(int device_id);
+void mi355_destroy(mi355_ctx* ctx);
+const char* mi355_last_error(const mi355_ctx* ctx);
+/* Run on a caller-owned HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int mi355_set_stream(mi355_ctx* ctx, void* hip_stream);
+int mi355_synchronize(mi355_ctx* ctx);
+/* NN-grid cell edge in metres for the voxel-hash searches (default 0.5). */
+int mi355_set_grid_cell(mi355_ctx* ctx, float cell);
+/* device name / CU count, for the benchmark log */
+int mi355_device_info(mi355_ctx* ctx, char* name, size_t name_cap, int* compute_units);
+
+/* ---- filters: replace the PCL filter objects of points_prefiltering.cpp:146-148 ------------------------ */
+/* PointsPreFiltering::distance_filter (points_prefiltering.cpp:102-112). out: packed float4. */
+int mi355_distance_filter(mi355_ctx* ctx, const mi355_cloud_view* in, double min_distance, float* out, size_t out_cap, size_t* out_n);
+/* pcl::VoxelGrid::setLeafSize + filter (points_prefiltering.cpp:118-120; graph_based_slam.cpp:61,311-313). */
+int mi355_voxel_grid(mi355_ctx* ctx, const mi355_cloud_view* in, float leaf, float* out, size_t out_cap, size_t* out_n, int* overflow);
+/* pcl::StatisticalOutlierRemoval::setMeanK/setStddevMulThresh/filter (points_prefiltering.cpp:136-139).
+ * keep_mask (n bytes) and mean_dist (n floats) are optional diagnostics. */
+int mi355_sor(mi355_ctx* ctx, const mi355_cloud_view* in, int mean_k, double stddev_mul, float* out, size_t out_cap, size_t* out_n,
+              uint8_t* keep_mask, float* mean_dist);
+/* PointsPreFiltering::callback_sensor_points pipeline (points_prefiltering.cpp:65-87): distance -> voxel -> SOR, on device. */
+int mi355_prefilter(mi355_ctx* ctx, const mi355_cloud_view* in, const mi355_prefilter_params* p, float* out, size_t out_cap, size_t* out_n);
+/* pcl::transformPointCloud (lidar_scan_matcher.cpp:282,291). */
+int mi355_transform(mi355_ctx* ctx, const mi355_cloud_view* in, const float T16[16], float* out);
+
+/* ---- stage-level entry points (parity tests of the search / covariance kernels) ------------------------ */
+/* Exact k-NN of `queries` in `pts` (pcl::search::KdTree::nearestKSearch semantics: ascending d2; ties -> lower index). */
+int mi355_knn(mi355_ctx* ctx, const mi355_cloud_view* pts, const mi355_cloud_view* queries, int k, int* idx, float* d2);
+/* fast_gicp calculate_covariances: per-point k-NN covariance + regularisation; cov6 = (xx,xy,xz,yy,yz,zz) per point. */
+int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, int k, int method, float* cov6);
+
+/* ---- registration object: replaces pcl::Registration<PointXYZI,PointXYZI>::Ptr registration_ ----------- */
+/* new fast_gicp::FastGICP / new pclomp::NormalDistributionsTransform (lidar_scan_matcher.cpp:38-39,56-57;
+ * graph_based_slam.cpp:84-85,103-104).  params: mi355_gicp_params* or mi355_ndt_params* (NULL = defaults). */
+mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* params);
+void mi355_reg_destroy(mi355_reg* reg);
+int mi355_reg_set_params(mi355_reg* reg, const void* params);
+/* setInputTarget (lidar_scan_matcher.cpp:149,212).  ALWAYS rebuilds: the node mutates the same cloud in place and
+ * re-passes the same pointer (cpp:187,209,212), so pointer identity must not short-circuit. */
+int mi355_reg_set_target(mi355_reg* reg, const mi355_cloud_view* cloud);
+/* setInputSource (lidar_scan_matcher.cpp:162). */
+int mi355_reg_set_source(mi355_reg* reg, const mi355_cloud_view* cloud);
+/* align(output, guess) + hasConverged + getFinalTransformation (lidar_scan_matcher.cpp:165-172; guess NULL = identity as
+ * graph_based_slam.cpp:318).  aligned_out (optional): source transformed by the result, packed float4, n_source points. */
+int mi355_reg_align(mi355_reg* reg, const float guess16[16], mi355_result* result, float* aligned_out);
+/* getFitnessScore(max_range) (graph_based_slam.cpp:321): mean squared 1-NN distance of the aligned source. */
+int mi355_reg_fitness(mi355_reg* reg, double max_range, double* score);
+/* One linearisation at pose T (row-major 4x4 double): the 6x6 normal equations of FastGICP::linearize, for parity tests.
+ * corr (optional, n_source ints): target index per source point in the CALLER's point order, -1 = none. */
+int mi355_reg_gicp_linearize(mi355_reg* reg, const double T16[16], double* H36, double* b6, double* error, int* corr);
+/* NDT computeDerivatives at p6 = (tx,ty,tz,roll,pitch,yaw); hessian_fp64 selects computeHessian's fp64 path. */
+int mi355_reg_ndt_derivatives(mi355_reg* reg, const double p6[6], double* score, double* grad6, double* hess36, int hessian_fp64);
+/* NDT leaves (VoxelGridCovariance) for parity: arrays sized by mi355_reg_ndt_num_cells(); sorted by linear voxel index. */
+int mi355_reg_ndt_num_cells(mi355_reg* reg, size_t* n_cells);
+int mi355_reg_ndt_cells(mi355_reg* reg, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3);
+
+/* ---- batch mode: many independent scan pairs per launch (BASELINE configs 2 and 5) --------------------- */
+/* n_sources source clouds and n_targets target clouds, each up to `capacity` points; pair p aligns source p to
+ * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates). */
+mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity);
+void mi355_batch_destroy(mi355_batch* b);
+/* Device-resident inputs: packed float4 [n_clouds][capacity] + host counts.  prefilter (optional) is applied on device
+ * (distance + voxel; SOR when mean_k > 0).  Enqueues work on the context stream; does not synchronise. */
+int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter);
+int mi355_batch_set_sources_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter);
+/* Host-pointer variants (PCIe copy included). */
+int mi355_batch_set_targets(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* prefilter);
+int mi355_batch_set_sources(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* prefilter);
+/* tgt_of_src: n_sources ints (NULL = identity mapping, requires n_targets == n_sources); guesses: n_sources x 16 floats (NULL = I).
+ * Enqueues every alignment; does not synchronise. */
+int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesses16, int with_fitness);
+/* Synchronises and copies results (n_sources entries) and optional fitness scores. */
+int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
+/* Dominant-kernel timing of the last mi355_batch_align, measured with HIP events on the context stream:
+ * total milliseconds inside the GICP linearise kernel and the number of launches. */
+int mi355_batch_kernel_time(mi355_batch* b, double* linearize_ms, int* linearize_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_LIDAR_H_ */

@@ -1,0 +1,198 @@
+"""ctypes binding of libmi355_lidar.so (include/mi355_lidar.h).
+
+The library is HIP-only: there is no CPU fallback anywhere in this package.  Loading fails loudly when the
+shared object has not been built (run ``python -c "import __graft_entry__ as g; g.build()"``), and
+``Context()`` fails loudly when no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_lidar.so")
+_LIB = None
+
+METHOD_FAST_GICP, METHOD_NDT_OMP = 0, 1
+REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)
+OPT_LM, OPT_GN = 0, 1
+OK, EINVAL, EHIP, ECAPACITY, ESTATE = 0, -1, -2, -3, -4
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"mi355 error {code}: {text}")
+        self.code = code
+
+
+class CloudView(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("stride", C.c_size_t), ("intensity_offset", C.c_size_t)]
+
+
+class GicpParams(C.Structure):
+    _fields_ = [
+        ("k_correspondences", C.c_int),
+        ("max_iterations", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("rotation_epsilon", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("regularization_method", C.c_int),
+        ("optimizer", C.c_int),
+        ("lm_max_iterations", C.c_int),
+        ("lm_init_lambda_factor", C.c_double),
+        ("force_iterations", C.c_int),
+        ("num_threads", C.c_int),
+    ]
+
+
+class NdtParams(C.Structure):
+    _fields_ = [
+        ("transformation_epsilon", C.c_double),
+        ("step_size", C.c_double),
+        ("resolution", C.c_double),
+        ("max_iterations", C.c_int),
+        ("outlier_ratio", C.c_double),
+        ("min_points_per_voxel", C.c_int),
+        ("min_covar_eigvalue_mult", C.c_double),
+        ("legacy_mt_skip", C.c_int),
+        ("num_threads", C.c_int),
+    ]
+
+
+class PrefilterParams(C.Structure):
+    _fields_ = [("min_distance", C.c_double), ("leaf_size", C.c_double), ("mean_k", C.c_int), ("stddev_mul", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("T", C.c_float * 16),
+        ("converged", C.c_int),
+        ("iterations", C.c_int),
+        ("error", C.c_double),
+        ("H", C.c_double * 36),
+        ("trans_probability", C.c_double),
+        ("n_source", C.c_int),
+        ("n_target", C.c_int),
+        ("n_inliers", C.c_int),
+        ("reserved", C.c_int),
+    ]
+
+    def to_dict(self):
+        return {
+            "T": np.array(self.T, dtype=np.float32).reshape(4, 4),
+            "converged": bool(self.converged),
+            "iterations": int(self.iterations),
+            "error": float(self.error),
+            "H": np.array(self.H, dtype=np.float64).reshape(6, 6),
+            "trans_probability": float(self.trans_probability),
+            "n_source": int(self.n_source),
+            "n_target": int(self.n_target),
+            "n_inliers": int(self.n_inliers),
+        }
+
+
+# every symbol include/mi355_lidar.h declares (tests/test_abi.py checks the library exports each one)
+EXPORTS = [
+    "mi355_gicp_default_params", "mi355_ndt_default_params", "mi355_prefilter_default_params",
+    "mi355_create", "mi355_destroy", "mi355_last_error", "mi355_set_stream", "mi355_synchronize", "mi355_set_grid_cell", "mi355_device_info",
+    "mi355_distance_filter", "mi355_voxel_grid", "mi355_sor", "mi355_prefilter", "mi355_transform",
+    "mi355_knn", "mi355_covariances",
+    "mi355_reg_create", "mi355_reg_destroy", "mi355_reg_set_params", "mi355_reg_set_target", "mi355_reg_set_source", "mi355_reg_align",
+    "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
+    "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
+    "mi355_batch_set_sources", "mi355_batch_align", "mi355_batch_results", "mi355_batch_kernel_time",
+]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        L.mi355_create.restype = C.c_void_p
+        L.mi355_create.argtypes = [C.c_int]
+        L.mi355_destroy.argtypes = [C.c_void_p]
+        L.mi355_destroy.restype = None
+        L.mi355_last_error.restype = C.c_char_p
+        L.mi355_last_error.argtypes = [C.c_void_p]
+        L.mi355_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_synchronize.argtypes = [C.c_void_p]
+        L.mi355_set_grid_cell.argtypes = [C.c_void_p, C.c_float]
+        L.mi355_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+        PV = C.POINTER(CloudView)
+        L.mi355_distance_filter.argtypes = [C.c_void_p, PV, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355_voxel_grid.argtypes = [C.c_void_p, PV, C.c_float, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.mi355_sor.argtypes = [C.c_void_p, PV, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
+        L.mi355_prefilter.argtypes = [C.c_void_p, PV, C.POINTER(PrefilterParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355_transform.argtypes = [C.c_void_p, PV, C.c_void_p, C.c_void_p]
+        L.mi355_knn.argtypes = [C.c_void_p, PV, PV, C.c_int, C.c_void_p, C.c_void_p]
+        L.mi355_covariances.argtypes = [C.c_void_p, PV, C.c_int, C.c_int, C.c_void_p]
+        L.mi355_reg_create.restype = C.c_void_p
+        L.mi355_reg_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mi355_reg_destroy.argtypes = [C.c_void_p]
+        L.mi355_reg_destroy.restype = None
+        L.mi355_reg_set_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_reg_set_target.argtypes = [C.c_void_p, PV]
+        L.mi355_reg_set_source.argtypes = [C.c_void_p, PV]
+        L.mi355_reg_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Result), C.c_void_p]
+        L.mi355_reg_fitness.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double)]
+        L.mi355_reg_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        L.mi355_reg_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_reg_ndt_num_cells.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.mi355_reg_ndt_cells.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.mi355_batch_create.restype = C.c_void_p
+        L.mi355_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        L.mi355_batch_destroy.argtypes = [C.c_void_p]
+        L.mi355_batch_destroy.restype = None
+        for name in ("mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets", "mi355_batch_set_sources"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
+        L.mi355_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def gicp_params(**kw) -> GicpParams:
+    p = GicpParams()
+    lib().mi355_gicp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def ndt_params(**kw) -> NdtParams:
+    p = NdtParams()
+    lib().mi355_ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def prefilter_params(**kw) -> PrefilterParams:
+    p = PrefilterParams()
+    lib().mi355_prefilter_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def view(a: np.ndarray):
+    """(CloudView, keep-alive array) for a float32 [n,4] packed cloud or a [n,8] pcl::PointXYZI-shaped one."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] not in (4, 8):
+        raise ValueError(f"cloud must be [n,4] packed or [n,8] PointXYZI-shaped float32, got {a.shape}")
+    v = CloudView(a.ctypes.data if a.size else None, a.shape[0], a.shape[1] * 4, 12 if a.shape[1] == 4 else 16)
+    return v, a

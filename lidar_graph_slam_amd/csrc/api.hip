@@ -1,0 +1,710 @@
+// The C-ABI of libmi355_lidar.so (include/mi355_lidar.h).  Thin: argument checking, host<->device staging and
+// sequencing of the engine calls.  No CPU fallback: without a HIP device mi355_create() fails.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "engine.hpp"
+
+using namespace mi355;
+
+namespace {
+
+template <typename F>
+int guarded(mi355_ctx* ctx, F&& f) {
+  try {
+    f();
+    return MI355_OK;
+  } catch (const ArgError& e) {
+    if (ctx) ctx->err = e.what();
+    return e.code;
+  } catch (const HipError& e) {
+    if (ctx) ctx->err = e.what();
+    return MI355_EHIP;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = e.what();
+    return MI355_EINVAL;
+  }
+}
+
+void check_view(const mi355_cloud_view* v) {
+  if (!v) throw ArgError(MI355_EINVAL, "cloud view is NULL");
+  if (v->n && !v->data) throw ArgError(MI355_EINVAL, "cloud data is NULL");
+  if (v->stride < 16 || v->stride % 4) throw ArgError(MI355_EINVAL, "stride must be >= 16 and a multiple of 4");
+  if (v->intensity_offset < 12 || v->intensity_offset + 4 > v->stride) throw ArgError(MI355_EINVAL, "bad intensity_offset");
+}
+
+// host (strided) -> packed float4 pinned staging -> device
+struct Uploader {
+  PinnedBuf<float4> h;
+  void upload(hipStream_t s, const mi355_cloud_view* v, float4* d_dst) {
+    check_view(v);
+    if (v->n == 0) return;
+    h.ensure(v->n);
+    const char* base = (const char*)v->data;
+    for (size_t i = 0; i < v->n; i++) {
+      const float* p = (const float*)(base + i * v->stride);
+      h.p[i] = make_float4(p[0], p[1], p[2], *(const float*)(base + i * v->stride + v->intensity_offset));
+    }
+    MI_HIP(hipMemcpyAsync(d_dst, h.p, v->n * sizeof(float4), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));  // staging buffer is reused by the next upload
+  }
+};
+
+// scratch for the single-cloud filter entry points
+struct FilterScratch {
+  Workspace ws;
+  Uploader up;
+  DevBuf<float4> a, b;
+  DevBuf<int> na, nb;
+  CloudSet set;
+  DevBuf<int> idx;
+  DevBuf<float> f;
+  DevBuf<uint8_t> mask;
+};
+
+}  // namespace
+
+struct mi355_reg {
+  mi355_ctx* ctx = nullptr;
+  int method = MI355_METHOD_FAST_GICP;
+  mi355_gicp_params gp;
+  mi355_ndt_params np;
+  Workspace ws;
+  Uploader up;
+  DevBuf<float4> stage_src, stage_tgt;
+  DevBuf<int> cnt_src, cnt_tgt;
+  CloudSet src, tgt;
+  GicpBatch gb;
+  NdtTarget* ndt = nullptr;
+  size_t n_src = 0, n_tgt = 0;
+  bool has_src = false, has_tgt = false, aligned = false;
+  float last_T[16];
+  DevBuf<float4> aligned_dev;
+  ~mi355_reg() {
+    if (ndt) ndt_target_destroy(ndt);
+  }
+};
+
+struct mi355_batch {
+  mi355_ctx* ctx = nullptr;
+  int method = MI355_METHOD_FAST_GICP;
+  mi355_gicp_params gp;
+  int n_sources = 0, n_targets = 0;
+  size_t cap = 0;
+  Workspace ws;
+  CloudSet src, tgt, sor_set;
+  GicpBatch gb;
+  DevBuf<int> cnt_in;
+  DevBuf<float4> host_stage;
+  std::vector<int> h_counts;
+  bool has_src = false, has_tgt = false, aligned = false, with_fitness = false;
+};
+
+struct CtxExtras {
+  FilterScratch fs;
+};
+static CtxExtras* extras(mi355_ctx* ctx);
+
+// ---- defaults ------------------------------------------------------------------------------------------------------
+extern "C" void mi355_gicp_default_params(mi355_gicp_params* p) {
+  p->k_correspondences = 20;
+  p->max_iterations = 64;
+  p->transformation_epsilon = 0.01;
+  p->rotation_epsilon = 2e-3;
+  p->max_correspondence_distance = 2.0;
+  p->regularization_method = MI355_REG_PLANE;
+  p->optimizer = MI355_OPT_LM;
+  p->lm_max_iterations = 10;
+  p->lm_init_lambda_factor = 1e-9;
+  p->force_iterations = 0;
+  p->num_threads = 0;
+}
+extern "C" void mi355_ndt_default_params(mi355_ndt_params* p) {
+  p->transformation_epsilon = 0.01;
+  p->step_size = 0.1;
+  p->resolution = 2.0;
+  p->max_iterations = 64;
+  p->outlier_ratio = 0.55;
+  p->min_points_per_voxel = 6;
+  p->min_covar_eigvalue_mult = 0.01;
+  p->legacy_mt_skip = 0;
+  p->num_threads = 0;
+}
+extern "C" void mi355_prefilter_default_params(mi355_prefilter_params* p) {
+  p->min_distance = 1.0;
+  p->leaf_size = 0.1;
+  p->mean_k = 30;
+  p->stddev_mul = 1.2;
+}
+
+// ---- context -------------------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+static std::mutex g_mu;
+static std::map<mi355_ctx*, CtxExtras*> g_extras;
+static CtxExtras* extras(mi355_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_extras.find(ctx);
+  if (it != g_extras.end()) return it->second;
+  auto* e = new CtxExtras();
+  g_extras[ctx] = e;
+  return e;
+}
+
+extern "C" mi355_ctx* mi355_create(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  auto* ctx = new mi355_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return nullptr;
+  }
+  ctx->own_stream = true;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    ctx->compute_units = prop.multiProcessorCount;
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return ctx;
+}
+
+extern "C" void mi355_destroy(mi355_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_extras.find(ctx);
+    if (it != g_extras.end()) {
+      delete it->second;
+      g_extras.erase(it);
+    }
+  }
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* mi355_last_error(const mi355_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context (no HIP device?)"; }
+
+extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
+  if (!ctx) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) MI_HIP(hipStreamDestroy(ctx->stream));
+    if (hip_stream) {
+      ctx->stream = (hipStream_t)hip_stream;
+      ctx->own_stream = false;
+    } else {
+      MI_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+  });
+}
+
+extern "C" int mi355_synchronize(mi355_ctx* ctx) {
+  if (!ctx) return MI355_EINVAL;
+  return guarded(ctx, [&] { MI_HIP(hipStreamSynchronize(ctx->stream)); });
+}
+
+extern "C" int mi355_set_grid_cell(mi355_ctx* ctx, float cell) {
+  if (!ctx || !(cell > 0.f)) return MI355_EINVAL;
+  ctx->grid_cell = cell;
+  return MI355_OK;
+}
+
+extern "C" int mi355_device_info(mi355_ctx* ctx, char* name, size_t name_cap, int* compute_units) {
+  if (!ctx) return MI355_EINVAL;
+  if (name && name_cap) snprintf(name, name_cap, "%s", ctx->name);
+  if (compute_units) *compute_units = ctx->compute_units;
+  return MI355_OK;
+}
+
+// ---- filters -------------------------------------------------------------------------------------------------------
+namespace {
+struct OneCloud {
+  FilterScratch& fs;
+  size_t n;
+  OneCloud(mi355_ctx* ctx, const mi355_cloud_view* in) : fs(extras(ctx)->fs), n(in->n) {
+    MI_HIP(hipSetDevice(ctx->device));
+    check_view(in);
+    const size_t cap = std::max<size_t>(n, 1);
+    fs.a.ensure(cap); fs.b.ensure(cap);
+    fs.na.ensure(1); fs.nb.ensure(1);
+    ws_reserve(fs.ws, 1, cap);
+    fs.up.upload(ctx->stream, in, fs.a.p);
+    const int ni = (int)n;
+    MI_HIP(hipMemcpyAsync(fs.na.p, &ni, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  size_t cap() const { return std::max<size_t>(n, 1); }
+};
+
+size_t download(mi355_ctx* ctx, const float4* d_pts, const int* d_cnt, float* out, size_t out_cap) {
+  int cnt = 0;
+  MI_HIP(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MI_HIP(hipStreamSynchronize(ctx->stream));
+  if ((size_t)cnt > out_cap) throw ArgError(MI355_ECAPACITY, "output capacity too small");
+  if (cnt > 0) {
+    MI_HIP(hipMemcpyAsync(out, d_pts, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return (size_t)cnt;
+}
+}  // namespace
+
+extern "C" int mi355_distance_filter(mi355_ctx* ctx, const mi355_cloud_view* in, double min_distance, float* out, size_t out_cap, size_t* out_n) {
+  if (!ctx || !out_n) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, in);
+    distance_filter(ctx->stream, oc.fs.ws, oc.fs.a.p, oc.fs.na.p, oc.fs.b.p, oc.fs.nb.p, 1, oc.cap(), min_distance);
+    *out_n = download(ctx, oc.fs.b.p, oc.fs.nb.p, out, out_cap);
+  });
+}
+
+extern "C" int mi355_voxel_grid(mi355_ctx* ctx, const mi355_cloud_view* in, float leaf, float* out, size_t out_cap, size_t* out_n, int* overflow) {
+  if (!ctx || !out_n || !(leaf > 0.f)) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, in);
+    voxel_grid(ctx->stream, oc.fs.ws, oc.fs.a.p, oc.fs.na.p, oc.fs.b.p, oc.fs.nb.p, 1, oc.cap(), leaf);
+    *out_n = download(ctx, oc.fs.b.p, oc.fs.nb.p, out, out_cap);
+    if (overflow) {
+      GridMeta m;
+      MI_HIP(hipMemcpy(&m, oc.fs.ws.vmeta.p, sizeof(m), hipMemcpyDeviceToHost));
+      *overflow = (oc.n > 0) ? m.overflow : 0;
+    }
+  });
+}
+
+extern "C" int mi355_sor(mi355_ctx* ctx, const mi355_cloud_view* in, int mean_k, double stddev_mul, float* out, size_t out_cap, size_t* out_n,
+                         uint8_t* keep_mask, float* mean_dist) {
+  if (!ctx || !out_n) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, in);
+    if (oc.n == 0) { *out_n = 0; return; }
+    if ((size_t)mean_k + 1 > oc.n) throw ArgError(MI355_EINVAL, "mean_k + 1 exceeds the number of points");
+    oc.fs.mask.ensure(oc.cap());
+    oc.fs.f.ensure(oc.cap());
+    sor_filter(ctx->stream, oc.fs.ws, oc.fs.set, oc.fs.a.p, oc.fs.na.p, oc.fs.b.p, oc.fs.nb.p, 1, oc.cap(), mean_k, stddev_mul, ctx->grid_cell,
+               oc.fs.mask.p, oc.fs.f.p);
+    *out_n = download(ctx, oc.fs.b.p, oc.fs.nb.p, out, out_cap);
+    if (keep_mask) MI_HIP(hipMemcpy(keep_mask, oc.fs.mask.p, oc.n, hipMemcpyDeviceToHost));
+    if (mean_dist) MI_HIP(hipMemcpy(mean_dist, oc.fs.f.p, oc.n * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+// distance -> voxel -> SOR on device; returns the buffer holding the result (a or b of `fs`-like scratch)
+static void run_prefilter(hipStream_t s, Workspace& ws, CloudSet& sor_set, float grid_cell, const mi355_prefilter_params& p, int B, size_t cap,
+                          const float4* in, const int* cnt_in, DevBuf<float4>& a, DevBuf<float4>& b, DevBuf<int>& na, DevBuf<int>& nb,
+                          const float4** out, const int** cnt_out) {
+  a.ensure((size_t)B * cap); b.ensure((size_t)B * cap);
+  na.ensure(B); nb.ensure(B);
+  const float4* cur = in;
+  const int* ncur = cnt_in;
+  auto next = [&](float4** dst, int** ndst) {
+    if (cur == a.p) { *dst = b.p; *ndst = nb.p; } else { *dst = a.p; *ndst = na.p; }
+  };
+  float4* dst;
+  int* ndst;
+  if (p.min_distance > 0) {
+    next(&dst, &ndst);
+    distance_filter(s, ws, cur, ncur, dst, ndst, B, cap, p.min_distance);
+    cur = dst; ncur = ndst;
+  }
+  if (p.leaf_size > 0) {
+    next(&dst, &ndst);
+    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size);
+    cur = dst; ncur = ndst;
+  }
+  if (p.mean_k > 0) {
+    next(&dst, &ndst);
+    sor_filter(s, ws, sor_set, cur, ncur, dst, ndst, B, cap, p.mean_k, p.stddev_mul, grid_cell, nullptr, nullptr);
+    cur = dst; ncur = ndst;
+  }
+  *out = cur;
+  *cnt_out = ncur;
+}
+
+extern "C" int mi355_prefilter(mi355_ctx* ctx, const mi355_cloud_view* in, const mi355_prefilter_params* p, float* out, size_t out_cap, size_t* out_n) {
+  if (!ctx || !out_n || !p) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, in);
+    if (oc.n == 0) { *out_n = 0; return; }
+    // ping-pong between two extra stages so the input in fs.a stays intact
+    static thread_local int dummy = 0;
+    (void)dummy;
+    FilterScratch& fs = oc.fs;
+    const float4* res;
+    const int* nres;
+    run_prefilter(ctx->stream, fs.ws, fs.set, ctx->grid_cell, *p, 1, oc.cap(), fs.a.p, fs.na.p, fs.ws.stage_a, fs.ws.stage_b, fs.ws.count_a,
+                  fs.ws.count_b, &res, &nres);
+    *out_n = download(ctx, res, nres, out, out_cap);
+  });
+}
+
+extern "C" int mi355_transform(mi355_ctx* ctx, const mi355_cloud_view* in, const float T16[16], float* out) {
+  if (!ctx || !T16 || !out) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, in);
+    transform_points(ctx->stream, oc.fs.a.p, oc.fs.b.p, oc.n, T16);
+    if (oc.n) MI_HIP(hipMemcpyAsync(out, oc.fs.b.p, oc.n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+// ---- stage-level ---------------------------------------------------------------------------------------------------
+extern "C" int mi355_knn(mi355_ctx* ctx, const mi355_cloud_view* pts, const mi355_cloud_view* queries, int k, int* idx, float* d2) {
+  if (!ctx || !idx || !d2) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, pts);
+    check_view(queries);
+    if (k < 1 || (size_t)k > oc.n) throw ArgError(MI355_EINVAL, "k must be in [1, n]");
+    FilterScratch& fs = oc.fs;
+    if (fs.set.B != 1 || fs.set.cap != oc.cap()) fs.set.alloc(1, oc.cap());
+    build_grid(ctx->stream, fs.ws, fs.a.p, fs.na.p, fs.set, ctx->grid_cell);
+    const size_t m = queries->n;
+    if (m == 0) return;
+    fs.b.ensure(m);
+    fs.up.upload(ctx->stream, queries, fs.b.p);
+    fs.idx.ensure(m * k);
+    fs.f.ensure(m * k);
+    knn_query(ctx->stream, fs.set, fs.b.p, (int)m, k, fs.idx.p, fs.f.p);
+    MI_HIP(hipMemcpyAsync(idx, fs.idx.p, m * k * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2, fs.f.p, m * k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+extern "C" int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, int k, int method, float* cov6) {
+  if (!ctx || !cov6) return MI355_EINVAL;
+  return guarded(ctx, [&] {
+    OneCloud oc(ctx, pts);
+    if (k < 1 || (size_t)k > oc.n) throw ArgError(MI355_EINVAL, "k must be in [1, n]");
+    FilterScratch& fs = oc.fs;
+    if (fs.set.B != 1 || fs.set.cap != oc.cap()) fs.set.alloc(1, oc.cap());
+    build_grid(ctx->stream, fs.ws, fs.a.p, fs.na.p, fs.set, ctx->grid_cell);
+    compute_covariances(ctx->stream, fs.set, k, method);
+    std::vector<float4> c(2 * oc.n);
+    std::vector<int> orig(oc.n);
+    MI_HIP(hipMemcpyAsync(c.data(), fs.set.cov.p, c.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(orig.data(), fs.set.orig.p, oc.n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < oc.n; i++) {  // back to the caller's point order
+      float* o = cov6 + 6 * (size_t)orig[i];
+      o[0] = c[2 * i].x; o[1] = c[2 * i].y; o[2] = c[2 * i].z; o[3] = c[2 * i].w; o[4] = c[2 * i + 1].x; o[5] = c[2 * i + 1].y;
+    }
+  });
+}
+
+// ---- registration object -------------------------------------------------------------------------------------------
+extern "C" mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* params) {
+  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP)) return nullptr;
+  auto* r = new mi355_reg();
+  r->ctx = ctx;
+  r->method = method;
+  mi355_gicp_default_params(&r->gp);
+  mi355_ndt_default_params(&r->np);
+  if (params) {
+    if (method == MI355_METHOD_FAST_GICP) r->gp = *(const mi355_gicp_params*)params;
+    else r->np = *(const mi355_ndt_params*)params;
+  }
+  if (method == MI355_METHOD_NDT_OMP) r->ndt = ndt_target_create();
+  for (int i = 0; i < 16; i++) r->last_T[i] = (i % 5 == 0) ? 1.f : 0.f;
+  return r;
+}
+
+extern "C" void mi355_reg_destroy(mi355_reg* reg) {
+  if (!reg) return;
+  (void)hipSetDevice(reg->ctx->device);
+  (void)hipStreamSynchronize(reg->ctx->stream);
+  delete reg;
+}
+
+extern "C" int mi355_reg_set_params(mi355_reg* reg, const void* params) {
+  if (!reg || !params) return MI355_EINVAL;
+  if (reg->method == MI355_METHOD_FAST_GICP) {
+    const int old_k = reg->gp.k_correspondences, old_m = reg->gp.regularization_method;
+    reg->gp = *(const mi355_gicp_params*)params;
+    if (old_k != reg->gp.k_correspondences || old_m != reg->gp.regularization_method) { reg->src.has_cov = false; reg->tgt.has_cov = false; }
+  } else {
+    reg->np = *(const mi355_ndt_params*)params;
+    reg->has_tgt = false;  // resolution may have changed: the voxel grid must be rebuilt by the next set_target
+  }
+  return MI355_OK;
+}
+
+static void reg_upload(mi355_reg* reg, const mi355_cloud_view* cloud, DevBuf<float4>& stage, DevBuf<int>& cnt) {
+  mi355_ctx* ctx = reg->ctx;
+  MI_HIP(hipSetDevice(ctx->device));
+  check_view(cloud);
+  const size_t cap = std::max<size_t>(cloud->n, 1);
+  stage.ensure(cap);
+  cnt.ensure(1);
+  reg->up.upload(ctx->stream, cloud, stage.p);
+  const int ni = (int)cloud->n;
+  MI_HIP(hipMemcpyAsync(cnt.p, &ni, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  MI_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+extern "C" int mi355_reg_set_target(mi355_reg* reg, const mi355_cloud_view* cloud) {
+  if (!reg) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_upload(reg, cloud, reg->stage_tgt, reg->cnt_tgt);
+    reg->n_tgt = cloud->n;
+    reg->has_tgt = false;
+    reg->aligned = false;
+    if (reg->n_tgt == 0) throw ArgError(MI355_EINVAL, "empty target cloud");
+    if (reg->method == MI355_METHOD_FAST_GICP) {
+      if ((size_t)reg->gp.k_correspondences > reg->n_tgt) throw ArgError(MI355_EINVAL, "target has fewer points than k_correspondences");
+      reg->tgt.alloc(1, reg->n_tgt);
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+      compute_covariances(ctx->stream, reg->tgt, reg->gp.k_correspondences, reg->gp.regularization_method);
+    } else {
+      ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
+      // getFitnessScore needs the NN structure of the target as well
+      reg->tgt.alloc(1, reg->n_tgt);
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+    }
+    reg->has_tgt = true;
+  });
+}
+
+extern "C" int mi355_reg_set_source(mi355_reg* reg, const mi355_cloud_view* cloud) {
+  if (!reg) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_upload(reg, cloud, reg->stage_src, reg->cnt_src);
+    reg->n_src = cloud->n;
+    reg->has_src = false;
+    reg->aligned = false;
+    if (reg->n_src == 0) throw ArgError(MI355_EINVAL, "empty source cloud");
+    reg->src.alloc(1, reg->n_src);
+    build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
+    if (reg->method == MI355_METHOD_FAST_GICP) {
+      if ((size_t)reg->gp.k_correspondences > reg->n_src) throw ArgError(MI355_EINVAL, "source has fewer points than k_correspondences");
+      compute_covariances(ctx->stream, reg->src, reg->gp.k_correspondences, reg->gp.regularization_method);
+    }
+    gicp_alloc(reg->gb, 1, reg->n_src, ctx->compute_units);
+    reg->has_src = true;
+  });
+}
+
+static void reg_require(mi355_reg* reg) {
+  if (!reg->has_tgt) throw ArgError(MI355_ESTATE, "setInputTarget has not been called");
+  if (!reg->has_src) throw ArgError(MI355_ESTATE, "setInputSource has not been called");
+  MI_HIP(hipSetDevice(reg->ctx->device));
+  if (reg->method == MI355_METHOD_FAST_GICP) {
+    if (!reg->src.has_cov) compute_covariances(reg->ctx->stream, reg->src, reg->gp.k_correspondences, reg->gp.regularization_method);
+    if (!reg->tgt.has_cov) compute_covariances(reg->ctx->stream, reg->tgt, reg->gp.k_correspondences, reg->gp.regularization_method);
+  }
+}
+
+extern "C" int mi355_reg_align(mi355_reg* reg, const float guess16[16], mi355_result* result, float* aligned_out) {
+  if (!reg || !result) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_require(reg);
+    if (reg->method == MI355_METHOD_FAST_GICP) {
+      gicp_align(ctx->stream, reg->gb, reg->src, reg->tgt, reg->gp, nullptr, guess16);
+      gicp_results(ctx->stream, reg->gb, reg->src, reg->tgt, result, nullptr);
+    } else {
+      float I[16];
+      for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
+      ndt_align(ctx->stream, reg->ws, *reg->ndt, reg->stage_src.p, reg->n_src, reg->np, guess16 ? guess16 : I, result);
+      result->n_source = (int)reg->n_src;
+      result->n_target = (int)reg->n_tgt;
+    }
+    memcpy(reg->last_T, result->T, sizeof(reg->last_T));
+    reg->aligned = true;
+    if (aligned_out) {  // pcl::transformPointCloud(*input_, output, final_transformation_), caller's point order
+      reg->aligned_dev.ensure(reg->n_src);
+      transform_points(ctx->stream, reg->stage_src.p, reg->aligned_dev.p, reg->n_src, result->T);
+      MI_HIP(hipMemcpyAsync(aligned_out, reg->aligned_dev.p, reg->n_src * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+      MI_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  });
+}
+
+extern "C" int mi355_reg_fitness(mi355_reg* reg, double max_range, double* score) {
+  if (!reg || !score) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_require(reg);
+    const int zero = 0;
+    MI_HIP(hipMemcpyAsync(reg->gb.tgt_of_src.p, &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    gicp_fitness(ctx->stream, reg->gb, reg->src, reg->tgt, max_range, false, reg->last_T);
+    double f[2];
+    MI_HIP(hipMemcpyAsync(f, reg->gb.fitness.p, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    *score = f[1] > 0 ? f[0] / f[1] : 1.7976931348623157e308;
+  });
+}
+
+extern "C" int mi355_reg_gicp_linearize(mi355_reg* reg, const double T16[16], double* H36, double* b6, double* error, int* corr) {
+  if (!reg || !T16 || !H36 || !b6 || !error) return MI355_EINVAL;
+  if (reg->method != MI355_METHOD_FAST_GICP) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_require(reg);
+    gicp_linearize_once(ctx->stream, reg->gb, reg->src, reg->tgt, reg->gp, T16, H36, b6, error, corr);
+  });
+}
+
+extern "C" int mi355_reg_ndt_derivatives(mi355_reg* reg, const double p6[6], double* score, double* grad6, double* hess36, int hessian_fp64) {
+  if (!reg || !p6 || !score || !grad6 || !hess36) return MI355_EINVAL;
+  if (reg->method != MI355_METHOD_NDT_OMP) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_require(reg);
+    ndt_derivatives(ctx->stream, reg->ws, *reg->ndt, reg->stage_src.p, reg->n_src, reg->np, p6, score, grad6, hess36, hessian_fp64 != 0);
+  });
+}
+
+extern "C" int mi355_reg_ndt_num_cells(mi355_reg* reg, size_t* n_cells) {
+  if (!reg || !n_cells || reg->method != MI355_METHOD_NDT_OMP) return MI355_EINVAL;
+  return guarded(reg->ctx, [&] {
+    if (!reg->has_tgt) throw ArgError(MI355_ESTATE, "setInputTarget has not been called");
+    *n_cells = ndt_num_cells(*reg->ndt);
+  });
+}
+
+extern "C" int mi355_reg_ndt_cells(mi355_reg* reg, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3,
+                                   int* div_b3) {
+  if (!reg || reg->method != MI355_METHOD_NDT_OMP) return MI355_EINVAL;
+  return guarded(reg->ctx, [&] {
+    if (!reg->has_tgt) throw ArgError(MI355_ESTATE, "setInputTarget has not been called");
+    MI_HIP(hipSetDevice(reg->ctx->device));
+    ndt_cells(reg->ctx->stream, *reg->ndt, leaf_idx, leaf_n, mean3, cov9, icov9, min_b3, div_b3);
+  });
+}
+
+// ---- batch ---------------------------------------------------------------------------------------------------------
+extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity) {
+  if (!ctx || method != MI355_METHOD_FAST_GICP || n_sources <= 0 || n_targets <= 0 || capacity == 0) {
+    if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP)";
+    return nullptr;
+  }
+  auto* b = new mi355_batch();
+  b->ctx = ctx;
+  b->method = method;
+  mi355_gicp_default_params(&b->gp);
+  if (params) b->gp = *(const mi355_gicp_params*)params;
+  b->n_sources = n_sources;
+  b->n_targets = n_targets;
+  b->cap = capacity;
+  const int rc = guarded(ctx, [&] {
+    MI_HIP(hipSetDevice(ctx->device));
+    b->src.alloc(n_sources, capacity);
+    b->tgt.alloc(n_targets, capacity);
+    gicp_alloc(b->gb, n_sources, capacity, ctx->compute_units);
+    b->gb.time_kernels = true;
+    ws_reserve(b->ws, std::max(n_sources, n_targets), capacity);
+    b->cnt_in.ensure(std::max(n_sources, n_targets));
+  });
+  if (rc != MI355_OK) {
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
+
+extern "C" void mi355_batch_destroy(mi355_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  delete b;
+}
+
+static void batch_set(mi355_batch* b, CloudSet& set, int B, const float4* d_points, const int* counts, const mi355_prefilter_params* pf) {
+  mi355_ctx* ctx = b->ctx;
+  MI_HIP(hipSetDevice(ctx->device));
+  if (!d_points || !counts) throw ArgError(MI355_EINVAL, "NULL points / counts");
+  b->h_counts.assign(counts, counts + B);
+  for (int i = 0; i < B; i++)
+    if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
+  MI_HIP(hipMemcpyAsync(b->cnt_in.p, b->h_counts.data(), B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  const float4* pts = d_points;
+  const int* cnt = b->cnt_in.p;
+  if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
+    run_prefilter(ctx->stream, b->ws, b->sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, b->cnt_in.p, b->ws.stage_a, b->ws.stage_b, b->ws.count_a,
+                  b->ws.count_b, &pts, &cnt);
+  build_grid(ctx->stream, b->ws, pts, cnt, set, ctx->grid_cell);
+  compute_covariances(ctx->stream, set, b->gp.k_correspondences, b->gp.regularization_method);
+}
+
+extern "C" int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    batch_set(b, b->tgt, b->n_targets, (const float4*)d_points, counts, prefilter);
+    b->has_tgt = true;
+    b->aligned = false;
+  });
+}
+
+extern "C" int mi355_batch_set_sources_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    batch_set(b, b->src, b->n_sources, (const float4*)d_points, counts, prefilter);
+    b->has_src = true;
+    b->aligned = false;
+  });
+}
+
+static int batch_set_host(mi355_batch* b, bool targets, const float* points, const int* counts, const mi355_prefilter_params* pf) {
+  if (!b || !points) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    MI_HIP(hipSetDevice(b->ctx->device));
+    const int B = targets ? b->n_targets : b->n_sources;
+    b->host_stage.ensure((size_t)B * b->cap);
+    MI_HIP(hipMemcpyAsync(b->host_stage.p, points, (size_t)B * b->cap * sizeof(float4), hipMemcpyHostToDevice, b->ctx->stream));
+    MI_HIP(hipStreamSynchronize(b->ctx->stream));
+    batch_set(b, targets ? b->tgt : b->src, B, b->host_stage.p, counts, pf);
+    MI_HIP(hipStreamSynchronize(b->ctx->stream));  // host_stage is reused by the next call
+    if (targets) b->has_tgt = true; else b->has_src = true;
+    b->aligned = false;
+  });
+}
+extern "C" int mi355_batch_set_targets(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* pf) {
+  return batch_set_host(b, true, points, counts, pf);
+}
+extern "C" int mi355_batch_set_sources(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* pf) {
+  return batch_set_host(b, false, points, counts, pf);
+}
+
+extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesses16, int with_fitness) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    if (!b->has_src || !b->has_tgt) throw ArgError(MI355_ESTATE, "sources / targets not set");
+    if (!tgt_of_src && b->n_sources != b->n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
+    MI_HIP(hipSetDevice(b->ctx->device));
+    gicp_align(b->ctx->stream, b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
+    b->with_fitness = with_fitness != 0;
+    if (b->with_fitness) gicp_fitness(b->ctx->stream, b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
+    b->aligned = true;
+  });
+}
+
+extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness) {
+  if (!b || !results) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    if (!b->aligned) throw ArgError(MI355_ESTATE, "mi355_batch_align has not been called");
+    if (fitness && !b->with_fitness) throw ArgError(MI355_ESTATE, "fitness was not requested in mi355_batch_align");
+    MI_HIP(hipSetDevice(b->ctx->device));
+    gicp_results(b->ctx->stream, b->gb, b->src, b->tgt, results, fitness);
+  });
+}
+
+extern "C" int mi355_batch_kernel_time(mi355_batch* b, double* linearize_ms, int* linearize_launches) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    MI_HIP(hipSetDevice(b->ctx->device));
+    MI_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (b->gb.ev_used) gicp_finish_timing(b->gb);
+    if (linearize_ms) *linearize_ms = b->gb.last_linearize_ms;
+    if (linearize_launches) *linearize_launches = b->gb.last_linearize_launches;
+  });
+}

@@ -1,0 +1,508 @@
+// Cloud-set kernels: the PCL-filter replacements (distance filter, VoxelGrid, StatisticalOutlierRemoval), the NN
+// voxel-hash build, exact k-NN and the fast_gicp covariance estimation.  SURVEY.md §8a rows A1-A4, P1-P4, F1, F2.
+#include "engine.hpp"
+#include "grid.hpp"
+#include "primitives.hpp"
+
+namespace mi355 {
+
+void CloudSet::alloc(int B_, size_t cap_) {
+  B = B_;
+  cap = cap_;
+  size_t s = 16;
+  while (s < 2 * cap) s <<= 1;
+  slots_cap = s;
+  pts.ensure((size_t)B * cap);
+  orig.ensure((size_t)B * cap);
+  count.ensure(B);
+  meta.ensure(B);
+  table.ensure((size_t)B * slots_cap);
+  built = false;
+  has_cov = false;
+}
+
+void ws_reserve(Workspace& ws, int B, size_t cap) {
+  const size_t n = (size_t)B * cap;
+  ws.keys_a.ensure(n); ws.keys_b.ensure(n);
+  ws.vals_a.ensure(n); ws.vals_b.ensure(n);
+  ws.flags.ensure(n);
+  ws.scan_local.ensure(n);
+  ws.scan_block.ensure((size_t)B * div_up((long)cap, kScanTile));
+  ws.totals.ensure(B);
+  ws.bounds.ensure((size_t)B * 6);
+  ws.vmeta.ensure(B);
+}
+
+// ---- bounding boxes ---------------------------------------------------------------------------------------------
+__global__ void k_bounds_init(uint32_t* bounds, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 6) bounds[i] = ((i % 6) < 3) ? 0xFFFFFFFFu : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pts, const int* __restrict__ counts, uint32_t* __restrict__ bounds,
+                                                size_t cap) {
+  const int c = blockIdx.y;
+  const int n = counts[c];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const float4* p = pts + (size_t)c * cap;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) {
+      mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z);
+      mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_down(mn[d], off, kWave));
+      mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off, kWave));
+    }
+  if (lane_id() == 0 && mn[0] <= mx[0]) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      atomicMin(&bounds[c * 6 + d], float_to_ordered(mn[d]));
+      atomicMax(&bounds[c * 6 + 3 + d], float_to_ordered(mx[d]));
+    }
+  }
+}
+
+static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const int* cnt, int B, size_t cap) {
+  hipLaunchKernelGGL(k_bounds_init, dim3(div_up(B * 6, 256)), dim3(256), 0, s, ws.bounds.p, B);
+  const int gx = std::max(1, std::min(64, div_up((long)cap, 1024)));
+  hipLaunchKernelGGL(k_bounds, dim3(gx, B), dim3(256), 0, s, in, cnt, ws.bounds.p, cap);
+}
+
+// ---- NN voxel-hash build ----------------------------------------------------------------------------------------
+__global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __restrict__ counts, GridMeta* __restrict__ meta, int B, float cell,
+                            uint32_t slots_cap) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  GridMeta m;
+  const int n = counts[c];
+  m.n = n;
+  m.overflow = 0;
+  float mn[3], mx[3];
+  for (int d = 0; d < 3; d++) { mn[d] = ordered_to_float(bounds[c * 6 + d]); mx[d] = ordered_to_float(bounds[c * 6 + 3 + d]); }
+  if (n <= 0 || !(mn[0] <= mx[0])) { mn[0] = mn[1] = mn[2] = 0.f; mx[0] = mx[1] = mx[2] = 0.f; }
+  float cs = cell;
+  int dx, dy, dz;
+  for (;;) {
+    const float inv = 1.0f / cs;
+    dx = (int)floorf((mx[0] - mn[0]) * inv) + 1;
+    dy = (int)floorf((mx[1] - mn[1]) * inv) + 1;
+    dz = (int)floorf((mx[2] - mn[2]) * inv) + 1;
+    if ((double)dx * (double)dy * (double)dz < 2.0e9 && dx < (1 << 20) && dy < (1 << 20) && dz < (1 << 20)) break;
+    cs *= 2.0f;  // absurdly large extents: coarsen until the linear index fits 31 bits
+  }
+  m.ox = mn[0]; m.oy = mn[1]; m.oz = mn[2];
+  m.cell = cs;
+  m.inv_cell = 1.0f / cs;
+  m.dx = dx; m.dy = dy; m.dz = dz;
+  uint32_t slots = 16, lg = 4;
+  while (slots < 2u * (uint32_t)max(n, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  m.hshift = 32 - lg;
+  m.hmask = slots - 1;
+  meta[c] = m;
+}
+
+__device__ __forceinline__ uint32_t cell_key(const GridMeta& m, float x, float y, float z) {
+  const int ix = min(max((int)floorf(cell_coord(x, m.ox, m.inv_cell)), 0), m.dx - 1);
+  const int iy = min(max((int)floorf(cell_coord(y, m.oy, m.inv_cell)), 0), m.dy - 1);
+  const int iz = min(max((int)floorf(cell_coord(z, m.oz, m.inv_cell)), 0), m.dz - 1);
+  return (uint32_t)ix + (uint32_t)m.dx * ((uint32_t)iy + (uint32_t)m.dy * (uint32_t)iz);
+}
+
+__global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, uint32_t* __restrict__ keys,
+                                                   int* __restrict__ vals, size_t cap) {
+  const int c = blockIdx.y;
+  const GridMeta m = meta[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const float4 p = pts[(size_t)c * cap + i];
+  keys[(size_t)c * cap + i] = cell_key(m, p.x, p.y, p.z);
+  vals[(size_t)c * cap + i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_table_clear(HashSlot* __restrict__ table, const GridMeta* __restrict__ meta, size_t slots_cap) {
+  const int c = blockIdx.y;
+  const uint32_t slots = meta[c].hmask + 1;
+  int4* t = reinterpret_cast<int4*>(table + (size_t)c * slots_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += gridDim.x * blockDim.x) t[i] = make_int4((int)kEmptyKey, 0, 0, 0);
+}
+
+__device__ __forceinline__ HashSlot* table_insert(HashSlot* t, const GridMeta& m, uint32_t key) {
+  uint32_t h = hash_slot(key, m.hshift);
+  for (;;) {
+    const uint32_t prev = atomicCAS(&t[h].key, kEmptyKey, key);
+    if (prev == kEmptyKey || prev == key) return &t[h];
+    h = (h + 1) & m.hmask;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
+                                                       const GridMeta* __restrict__ meta, float4* __restrict__ pts, int* __restrict__ orig,
+                                                       HashSlot* __restrict__ table, size_t cap, size_t slots_cap) {
+  const int c = blockIdx.y;
+  const GridMeta m = meta[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const size_t o = (size_t)c * cap;
+  const int v = vals[o + i];
+  pts[o + i] = in[o + v];
+  orig[o + i] = v;
+  const uint32_t key = keys[o + i];
+  const bool head = (i == 0) || (keys[o + i - 1] != key);
+  const bool tail = (i == m.n - 1) || (keys[o + i + 1] != key);
+  if (head || tail) {
+    HashSlot* sl = table_insert(table + (size_t)c * slots_cap, m, key);
+    if (head) sl->start = i;
+    if (tail) sl->end = i + 1;
+  }
+}
+
+__global__ void k_copy_counts(const int* in, int* out, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = in[i];
+}
+
+void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell) {
+  const int B = out.B;
+  const size_t cap = out.cap;
+  ws_reserve(ws, B, cap);
+  compute_bounds(s, ws, in, cnt_in, B, cap);
+  hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, out.meta.p, B, cell, (uint32_t)out.slots_cap);
+  hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
+  const dim3 grid(div_up((long)cap, 256), B);
+  hipLaunchKernelGGL(k_cell_keys, grid, dim3(256), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
+  sort_pairs(s, ws, B, cap, cnt_in, 4);
+  hipLaunchKernelGGL(k_table_clear, dim3(std::max(1, std::min(64, (int)(out.slots_cap / 1024))), B), dim3(256), 0, s, out.table.p, out.meta.p,
+                     out.slots_cap);
+  hipLaunchKernelGGL(k_gather_insert, grid, dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p, out.table.p, cap,
+                     out.slots_cap);
+  MI_LAUNCH_CHECK();
+  out.built = true;
+  out.has_cov = false;
+}
+
+// ---- k-NN covariances (F2) --------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_cov(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+                                                 const GridMeta* __restrict__ meta, float4* __restrict__ cov, size_t cap, size_t slots_cap, int k,
+                                                 int method) {
+  const int c = blockIdx.y;
+  const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.m.n) return;
+  const float4 q = g.pts[i];
+  NearestK<K> nk;
+  nk.init(g.orig, k);
+  grid_search(g, q.x, q.y, q.z, INFINITY, nk);
+  // neighbours as fp64, mean-subtracted, cov = D D^T / k  (divide by k, not k-1)
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll
+  for (int j = 0; j < K; j++)
+    if (j < k && nk.idx[j] >= 0) {
+      const float4 p = g.pts[nk.idx[j]];
+      mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
+    }
+  const double invk = 1.0 / (double)k;
+  mx *= invk; my *= invk; mz *= invk;
+  Sym3<double> cv = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < K; j++)
+    if (j < k && nk.idx[j] >= 0) {
+      const float4 p = g.pts[nk.idx[j]];
+      const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
+      cv.xx += x * x; cv.xy += x * y; cv.xz += x * z; cv.yy += y * y; cv.yz += y * z; cv.zz += z * z;
+    }
+  cv.xx *= invk; cv.xy *= invk; cv.xz *= invk; cv.yy *= invk; cv.yz *= invk; cv.zz *= invk;
+  const Sym3<double> r = regularize_covariance(cv, method);
+  float4* o = cov + ((size_t)c * cap + i) * 2;
+  o[0] = make_float4((float)r.xx, (float)r.xy, (float)r.xz, (float)r.yy);
+  o[1] = make_float4((float)r.yz, (float)r.zz, 0.f, 0.f);
+}
+
+template <int K>
+static void launch_knn_cov(hipStream_t s, CloudSet& set, int k, int method) {
+  hipLaunchKernelGGL(k_knn_cov<K>, dim3(div_up((long)set.cap, 256), set.B), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p,
+                     set.cov.p, set.cap, set.slots_cap, k, method);
+}
+
+void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
+  if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k_correspondences must be in [1, 64]");
+  set.cov.ensure((size_t)set.B * set.cap * 2);
+  if (k == 20) launch_knn_cov<20>(s, set, k, method);
+  else if (k <= 8) launch_knn_cov<8>(s, set, k, method);
+  else if (k <= 16) launch_knn_cov<16>(s, set, k, method);
+  else if (k <= 32) launch_knn_cov<32>(s, set, k, method);
+  else launch_knn_cov<64>(s, set, k, method);
+  MI_LAUNCH_CHECK();
+  set.has_cov = true;
+}
+
+// ---- stand-alone k-NN query (parity tests, SOR) -----------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_query(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+                                                   const GridMeta* __restrict__ meta, const float4* __restrict__ queries, int m, int k,
+                                                   int* __restrict__ out_idx, float* __restrict__ out_d2, size_t cap, size_t slots_cap) {
+  const GridView g = grid_view(pts, orig, table, meta, 0, cap, slots_cap);
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= m) return;
+  const float4 q = queries[qi];
+  NearestK<K> nk;
+  nk.init(g.orig, k);
+  grid_search(g, q.x, q.y, q.z, INFINITY, nk);
+#pragma unroll
+  for (int j = 0; j < K; j++)
+    if (j < k) {
+      out_idx[(size_t)qi * k + j] = nk.idx[j] >= 0 ? g.orig[nk.idx[j]] : -1;
+      out_d2[(size_t)qi * k + j] = nk.d2[j];
+    }
+}
+
+void knn_query(hipStream_t s, const CloudSet& set, const float4* d_queries, int m, int k, int* d_idx, float* d_d2) {
+  if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k must be in [1, 64]");
+  const dim3 grid(div_up(m, 256)), blk(256);
+#define MI_KNN(KK)                                                                                                                     \
+  hipLaunchKernelGGL(k_knn_query<KK>, grid, blk, 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, d_queries, m, k, d_idx, d_d2, set.cap, \
+                     set.slots_cap)
+  if (k == 1) MI_KNN(1);
+  else if (k <= 8) MI_KNN(8);
+  else if (k <= 16) MI_KNN(16);
+  else if (k == 20) MI_KNN(20);
+  else if (k <= 32) MI_KNN(32);
+  else MI_KNN(64);
+#undef MI_KNN
+  MI_LAUNCH_CHECK();
+}
+
+// ---- A8/P3: pcl::transformPointCloud ----------------------------------------------------------------------------
+struct Mat4f {
+  float m[16];
+};
+__global__ __launch_bounds__(256) void k_transform(const float4* __restrict__ in, float4* __restrict__ out, size_t n, Mat4f T) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  out[i] = make_float4(transform_row(T.m, p.x, p.y, p.z), transform_row(T.m + 4, p.x, p.y, p.z), transform_row(T.m + 8, p.x, p.y, p.z), p.w);
+}
+void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, const float* T16_host) {
+  Mat4f T;
+  memcpy(T.m, T16_host, sizeof(T.m));
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_transform, dim3(div_up((long)n, 256)), dim3(256), 0, s, in, out, n, T);
+  MI_LAUNCH_CHECK();
+}
+
+// ---- order-preserving compaction --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ in, const int* __restrict__ counts, const int* __restrict__ flags,
+                                                 const int* __restrict__ local, const int* __restrict__ blockoff, const int* __restrict__ totals,
+                                                 float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk) {
+  const int c = blockIdx.y;
+  const int n = counts[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) cnt_out[c] = (n > 0) ? totals[c] : 0;
+  if (i >= n) return;
+  const size_t o = (size_t)c * cap;
+  if (flags[o + i]) out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = in[o + i];
+}
+
+// ---- A1: distance filter ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_distance_flags(const float4* __restrict__ in, const int* __restrict__ counts, int* __restrict__ flags,
+                                                        size_t cap, double min_distance) {
+  const int c = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= counts[c]) return;
+  const float4 p = in[(size_t)c * cap + i];
+  // Eigen Vector3f::norm(): fp32 sqrt of (x*x + y*y) + z*z, promoted to double, strict '<' (NaN compares false)
+  const float nrm = sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
+  flags[(size_t)c * cap + i] = (min_distance < (double)nrm) ? 1 : 0;
+}
+
+void distance_filter(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap,
+                     double min_distance) {
+  ws_reserve(ws, B, cap);
+  const dim3 grid(div_up((long)cap, 256), B);
+  hipLaunchKernelGGL(k_distance_flags, grid, dim3(256), 0, s, in, cnt_in, ws.flags.p, cap, min_distance);
+  scan_flags(s, ws, B, cap, cnt_in);
+  hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, s, in, cnt_in, ws.flags.p, ws.scan_local.p, ws.scan_block.p, ws.totals.p, out, cnt_out, cap,
+                     div_up((long)cap, kScanTile));
+  MI_LAUNCH_CHECK();
+}
+
+// ---- P1: pcl::VoxelGrid -----------------------------------------------------------------------------------------
+__global__ void k_voxel_meta(const uint32_t* __restrict__ bounds, const int* __restrict__ counts, GridMeta* __restrict__ vmeta, int B, float leaf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  GridMeta m;
+  m.n = counts[c];
+  const float inv = 1.0f / leaf;  // inverse_leaf_size_
+  float mn[3], mx[3];
+  for (int d = 0; d < 3; d++) { mn[d] = ordered_to_float(bounds[c * 6 + d]); mx[d] = ordered_to_float(bounds[c * 6 + 3 + d]); }
+  const bool any = m.n > 0 && (mn[0] <= mx[0]);
+  if (!any) { mn[0] = mn[1] = mn[2] = 0.f; mx[0] = mx[1] = mx[2] = 0.f; }
+  const long long ddx = (long long)((mx[0] - mn[0]) * inv) + 1, ddy = (long long)((mx[1] - mn[1]) * inv) + 1, ddz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  m.overflow = (ddx * ddy * ddz > 2147483647LL) ? 1 : 0;
+  // min_b_ / div_b_ travel in (ox,oy,oz as int bits) and (dx,dy,dz)
+  const int mb0 = (int)floorf(mn[0] * inv), mb1 = (int)floorf(mn[1] * inv), mb2 = (int)floorf(mn[2] * inv);
+  m.ox = __int_as_float(mb0); m.oy = __int_as_float(mb1); m.oz = __int_as_float(mb2);
+  m.dx = (int)floorf(mx[0] * inv) - mb0 + 1;
+  m.dy = (int)floorf(mx[1] * inv) - mb1 + 1;
+  m.dz = (int)floorf(mx[2] * inv) - mb2 + 1;
+  m.inv_cell = inv;
+  m.cell = leaf;
+  m.hshift = 0; m.hmask = 0;
+  vmeta[c] = m;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ in, const GridMeta* __restrict__ vmeta, uint32_t* __restrict__ keys,
+                                                    int* __restrict__ vals, size_t cap) {
+  const int c = blockIdx.y;
+  const GridMeta m = vmeta[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const float4 p = in[(size_t)c * cap + i];
+  uint32_t key = kEmptyKey;
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !m.overflow) {
+    const int mb0 = __float_as_int(m.ox), mb1 = __float_as_int(m.oy), mb2 = __float_as_int(m.oz);
+    const int i0 = (int)(floorf(p.x * m.inv_cell) - (float)mb0);
+    const int i1 = (int)(floorf(p.y * m.inv_cell) - (float)mb1);
+    const int i2 = (int)(floorf(p.z * m.inv_cell) - (float)mb2);
+    key = (uint32_t)(i0 + i1 * m.dx + i2 * m.dx * m.dy);
+  }
+  keys[(size_t)c * cap + i] = key;
+  vals[(size_t)c * cap + i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict__ keys, const GridMeta* __restrict__ vmeta, int* __restrict__ flags,
+                                                     size_t cap) {
+  const int c = blockIdx.y;
+  const GridMeta m = vmeta[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const size_t o = (size_t)c * cap;
+  const uint32_t k = keys[o + i];
+  int f;
+  if (m.overflow) f = 1;
+  else f = (k != kEmptyKey) && (i == 0 || keys[o + i - 1] != k);
+  flags[o + i] = f;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
+                                                         const GridMeta* __restrict__ vmeta, const int* __restrict__ flags,
+                                                         const int* __restrict__ local, const int* __restrict__ blockoff,
+                                                         const int* __restrict__ totals, float4* __restrict__ out, int* __restrict__ cnt_out,
+                                                         size_t cap, int nblk) {
+  const int c = blockIdx.y;
+  const GridMeta m = vmeta[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
+  if (i >= m.n) return;
+  const size_t o = (size_t)c * cap;
+  if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input
+    out[o + i] = in[o + i];
+    return;
+  }
+  if (!flags[o + i]) return;
+  const uint32_t k = keys[o + i];
+  float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+  int j = i;
+  for (; j < m.n && keys[o + j] == k; j++) {  // ascending point index inside the voxel (stable sort)
+    const float4 p = in[o + vals[o + j]];
+    ax += p.x; ay += p.y; az += p.z; aw += p.w;
+  }
+  const float cnt = (float)(j - i);
+  out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(ax / cnt, ay / cnt, az / cnt, aw / cnt);
+}
+
+void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf) {
+  ws_reserve(ws, B, cap);
+  compute_bounds(s, ws, in, cnt_in, B, cap);
+  hipLaunchKernelGGL(k_voxel_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, ws.vmeta.p, B, leaf);
+  const dim3 grid(div_up((long)cap, 256), B);
+  hipLaunchKernelGGL(k_voxel_keys, grid, dim3(256), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap);
+  sort_pairs(s, ws, B, cap, cnt_in, 4);
+  hipLaunchKernelGGL(k_voxel_heads, grid, dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap);
+  scan_flags(s, ws, B, cap, cnt_in);
+  hipLaunchKernelGGL(k_voxel_centroids, grid, dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
+                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, div_up((long)cap, kScanTile));
+  MI_LAUNCH_CHECK();
+}
+
+// ---- P2: pcl::StatisticalOutlierRemoval -------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_sor_meandist(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+                                                      const GridMeta* __restrict__ meta, float* __restrict__ mean_dist, size_t cap, size_t slots_cap,
+                                                      int mean_k) {
+  const int c = blockIdx.y;
+  const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.m.n) return;
+  const float4 q = g.pts[i];
+  NearestK<K> nk;
+  nk.init(g.orig, mean_k + 1);
+  grid_search(g, q.x, q.y, q.z, INFINITY, nk);
+  double dist_sum = 0.0;
+#pragma unroll
+  for (int j = 1; j < K; j++)  // j = 0 is the query point itself
+    if (j < mean_k + 1) dist_sum += sqrt((double)nk.d2[j]);
+  mean_dist[(size_t)c * cap + g.orig[i]] = (float)(dist_sum / (double)mean_k);  // caller order
+}
+
+__global__ __launch_bounds__(1024) void k_sor_threshold(const float* __restrict__ mean_dist, const int* __restrict__ counts, double* __restrict__ thr,
+                                                        size_t cap, double stddev_mul) {
+  __shared__ double sm[2 * 16];
+  const int c = blockIdx.x;
+  const int n = counts[c];
+  double acc[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double d = (double)mean_dist[(size_t)c * cap + i];
+    acc[0] += d;
+    acc[1] += d * d;
+  }
+  block_sum<2, 16>(acc, sm);
+  if (threadIdx.x == 0) {
+    const double valid = (double)n;
+    const double mean = acc[0] / valid;
+    const double variance = (acc[1] - acc[0] * acc[0] / valid) / (valid - 1.0);
+    thr[c] = mean + stddev_mul * sqrt(variance);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sor_flags(const float* __restrict__ mean_dist, const int* __restrict__ counts, const double* __restrict__ thr,
+                                                   int* __restrict__ flags, uint8_t* __restrict__ keep, size_t cap) {
+  const int c = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= counts[c]) return;
+  const int f = !((double)mean_dist[(size_t)c * cap + i] > thr[c]);
+  flags[(size_t)c * cap + i] = f;
+  if (keep) keep[(size_t)c * cap + i] = (uint8_t)f;
+}
+
+void sor_filter(hipStream_t s, Workspace& ws, CloudSet& set, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap,
+                int mean_k, double stddev_mul, float cell, uint8_t* d_keep, float* d_mean_dist) {
+  if (mean_k < 1 || mean_k > 63) throw ArgError(MI355_EINVAL, "mean_k must be in [1, 63]");
+  if (set.B != B || set.cap != cap) set.alloc(B, cap);
+  build_grid(s, ws, in, cnt_in, set, cell);
+  ws.fscratch.ensure((size_t)B * cap);
+  ws.dscratch.ensure(B);
+  float* md = d_mean_dist ? d_mean_dist : ws.fscratch.p;
+  const dim3 grid(div_up((long)cap, 256), B);
+  const int kk = mean_k + 1;
+#define MI_SOR(KK) hipLaunchKernelGGL(k_sor_meandist<KK>, grid, dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, md, cap, set.slots_cap, mean_k)
+  if (kk == 31) MI_SOR(31);
+  else if (kk <= 8) MI_SOR(8);
+  else if (kk <= 16) MI_SOR(16);
+  else if (kk <= 32) MI_SOR(32);
+  else MI_SOR(64);
+#undef MI_SOR
+  hipLaunchKernelGGL(k_sor_threshold, dim3(B), dim3(1024), 0, s, md, cnt_in, ws.dscratch.p, cap, stddev_mul);
+  hipLaunchKernelGGL(k_sor_flags, grid, dim3(256), 0, s, md, cnt_in, ws.dscratch.p, ws.flags.p, d_keep, cap);
+  scan_flags(s, ws, B, cap, cnt_in);
+  hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, s, in, cnt_in, ws.flags.p, ws.scan_local.p, ws.scan_block.p, ws.totals.p, out, cnt_out, cap,
+                     div_up((long)cap, kScanTile));
+  MI_LAUNCH_CHECK();
+}
+
+}  // namespace mi355

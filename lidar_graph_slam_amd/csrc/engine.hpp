@@ -1,0 +1,143 @@
+// Internal (C++) interface between the translation units of libmi355_lidar.so.
+//
+// Data layout in HBM.  Everything is *batched*: a CloudSet holds B clouds in fixed-capacity
+// segments [c*cap, c*cap + count[c]) of shared arrays, with the per-cloud point count living in device memory, so
+// that a whole pipeline (filter -> sort -> index -> covariances -> LM iterations) is enqueued without one host
+// synchronisation.  A single registration object is simply a batch of one.
+//   pts   float4 (x,y,z,intensity)  16 B/pt   sorted by NN-grid cell key (x fastest)
+//   orig  int32                      4 B/pt   index of the point in the caller's order
+//   cov   2 x float4 (xx,xy,xz,yy | yz,zz,0,0) 32 B/pt (24 B algorithmic)
+//   table HashSlot{key,start,end,-} 16 B/slot open-addressing voxel hash: cell key -> point range
+#pragma once
+#include <stdint.h>
+
+#include "common.hpp"
+#include "devmath.hpp"
+
+namespace mi355 {
+
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+
+struct HashSlot {
+  uint32_t key;
+  int start;
+  int end;
+  int pad;
+};
+
+struct GridMeta {
+  float ox, oy, oz;   // grid origin (bounding-box minimum)
+  float inv_cell, cell;
+  int dx, dy, dz;     // cells per axis
+  uint32_t hshift;    // slot = (key * 0x9E3779B1) >> hshift
+  uint32_t hmask;     // n_slots - 1
+  int n;              // points in this cloud
+  int overflow;       // VoxelGrid index overflow flag (pass-through)
+};
+
+struct Workspace {
+  DevBuf<uint32_t> keys_a, keys_b;
+  DevBuf<int> vals_a, vals_b;
+  DevBuf<int> hist;
+  DevBuf<uint32_t> bounds;  // [B][6] ordered-uint min xyz, max xyz
+  DevBuf<int> flags, scan_local, scan_block, totals;
+  DevBuf<float4> stage_a, stage_b;  // prefilter stages
+  DevBuf<int> count_a, count_b;
+  DevBuf<float> fscratch;
+  DevBuf<double> dscratch;
+  DevBuf<GridMeta> vmeta;  // voxel-grid meta
+};
+
+struct CloudSet {
+  int B = 0;
+  size_t cap = 0;
+  size_t slots_cap = 0;
+  DevBuf<float4> pts;
+  DevBuf<int> orig;
+  DevBuf<int> count;
+  DevBuf<float4> cov;
+  DevBuf<GridMeta> meta;
+  DevBuf<HashSlot> table;
+  bool built = false, has_cov = false;
+  void alloc(int B_, size_t cap_);
+};
+
+// ---- sort.hip ------------------------------------------------------------------------------------------------
+// Stable LSD radix sort of (key32, val32) pairs per cloud segment, `passes` x 8 bits from bit 0.
+// Result ends up in (keys_a, vals_a) of the workspace.
+void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes);
+// Exclusive scan of ws.flags per cloud: position(i) = ws.scan_local[i] + ws.scan_block[c*nblk + i/1024]; totals[c].
+void scan_flags(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts);
+constexpr int kScanTile = 1024;
+
+// ---- cloud.hip -----------------------------------------------------------------------------------------------
+void ws_reserve(Workspace& ws, int B, size_t cap);
+// Copy a (possibly strided) host/device cloud into packed float4 staging: see api.hip.
+// distance filter (A1): in -> out compacted, order preserved.
+void distance_filter(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap,
+                     double min_distance);
+// VoxelGrid (P1): in -> out centroids in ascending voxel index.
+void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf);
+// SOR (P2): in -> out, order preserved.  Optional diagnostics (device pointers, [B*cap]).
+void sor_filter(hipStream_t s, Workspace& ws, CloudSet& scratch_set, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B,
+                size_t cap, int mean_k, double stddev_mul, float cell, uint8_t* d_keep, float* d_mean_dist);
+// Build the NN voxel-hash over `in` (any order): sorted points, orig map, hash table.
+void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell);
+// k-NN covariances with regularisation (F2) for every point of a built CloudSet.
+void compute_covariances(hipStream_t s, CloudSet& set, int k, int method);
+// Exact k-NN of queries (packed float4 [m]) in cloud 0 of a built set; idx in the caller's point order.
+void knn_query(hipStream_t s, const CloudSet& set, const float4* d_queries, int m, int k, int* d_idx, float* d_d2);
+void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, const float* T16_host);
+
+// ---- gicp.hip ------------------------------------------------------------------------------------------------
+struct GicpPairState;  // device-side LM state, one per source cloud
+struct GicpBatch {
+  int S = 0;           // sources (= pairs)
+  size_t cap = 0;
+  int blocks_per_pair = 0;
+  DevBuf<int> tgt_of_src;
+  DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
+  DevBuf<float4> mahal;      // [S*cap*2] Mahalanobis (6 floats + pad)
+  DevBuf<double> partials;   // [S][blocks][32]
+  DevBuf<GicpPairState> state;
+  DevBuf<int> n_active;
+  PinnedBuf<int> h_active;
+  DevBuf<double> fit_partials;
+  DevBuf<double> fitness;    // [S][2] (sum, count)
+  DevBuf<float> guesses, fit_T;        // device staging that must outlive the enqueued kernels
+  std::vector<int> h_map;
+  std::vector<float> h_guess, h_fit_T;
+  // dominant-kernel timing (HIP events on the context stream)
+  std::vector<hipEvent_t> ev;
+  int ev_used = 0;
+  bool time_kernels = false;
+  double last_linearize_ms = 0;
+  int last_linearize_launches = 0;
+  ~GicpBatch();
+};
+void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units);
+// Enqueue the full LM optimisation of every pair.  guesses_host: S x 16 floats or nullptr.
+void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
+                const float* guesses_host);
+void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
+                  const float* T16_host_all);
+void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, mi355_result* out, double* fitness_out);
+// single linearisation at a given pose (parity tests), pair 0 only
+void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T16,
+                         double* H36, double* b6, double* err, int* corr_caller_order);
+void gicp_finish_timing(GicpBatch& gb);
+
+// ---- ndt.hip -------------------------------------------------------------------------------------------------
+struct NdtTarget;
+struct NdtState;
+NdtTarget* ndt_target_create();
+void ndt_target_destroy(NdtTarget*);
+void ndt_build_target(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_pts, size_t n, const mi355_ndt_params& p);
+void ndt_align(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_src, size_t n, const mi355_ndt_params& p, const float* guess16,
+               mi355_result* out);
+void ndt_derivatives(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_src, size_t n, const mi355_ndt_params& p, const double* p6,
+                     double* score, double* grad6, double* hess36, bool hessian_fp64);
+size_t ndt_num_cells(NdtTarget& t);
+void ndt_cells(hipStream_t s, NdtTarget& t, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3);
+
+}  // namespace mi355

@@ -1,0 +1,585 @@
+// GICP on gfx950: the fast_gicp::FastGICP optimisation loop as a device-resident,
+// batched Levenberg-Marquardt.  One launch covers every scan pair of the batch (blockIdx.y = pair).
+//
+// Per outer iteration (LsqRegistration::step_lm):
+//   k_gicp_linearize  F3+F4 fused: fp32 transform -> exact 1-NN in the target voxel-hash -> RCR = C_B + R C_A R^T ->
+//                     Mahalanobis = RCR^-1 -> residual (fp64 transform) -> 21+6+1 normal-equation terms, accumulated
+//                     in fp64 registers, reduced by wave shuffles + LDS to ONE partial per block (fixed order =>
+//                     bitwise reproducible).  Writes the correspondence and the Mahalanobis matrix (28 B/pt) for F5.
+//   k_gicp_solve      per pair: sums the partials, lambda init, LDL^T solve of (H + lambda I) d = -b, se3_exp, trial pose.
+//   k_gicp_error      F5 compute_error at the trial pose with frozen correspondences / Mahalanobis.
+//   k_gicp_decide     rho test, accept / reject (rejected trials are re-evaluated inside this block: rare path),
+//                     lambda update, convergence test, iteration bookkeeping — no host round trip.
+// Algorithmic HBM bytes of k_gicp_linearize per source point: src pt 16 + src cov 24 + tgt pt 16 + tgt cov 24 = 80 B.
+#include "engine.hpp"
+#include "grid.hpp"
+#include "primitives.hpp"
+
+namespace mi355 {
+
+struct GicpPairState {
+  Pose x0, xi, delta;
+  double H[36], b[6], d[6];
+  double y0, yi, lambda, nu;
+  double final_H[36];
+  double last_error;
+  int iter, trial, active, converged, n_inliers, lm_failed, need_error, pad;
+};
+
+struct GicpDevParams {
+  int max_iterations, optimizer, lm_max_iterations, force_iterations;
+  double transformation_epsilon, rotation_epsilon, lm_init_lambda_factor;
+  float max_corr_d2;
+};
+
+constexpr int kNAcc = 29;      // 6 Hrr + 9 Hrt + 6 Htt + 6 b + 1 cost + 1 inlier count
+constexpr int kPartStride = 32;
+constexpr int kGicpBlock = 256;
+
+GicpBatch::~GicpBatch() {
+  for (auto e : ev) (void)hipEventDestroy(e);
+}
+
+void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
+  gb.S = S;
+  gb.cap = cap;
+  const int cu = compute_units > 0 ? compute_units : 256;
+  int G = (4 * cu + S - 1) / S;
+  G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock)));
+  gb.blocks_per_pair = G;
+  gb.tgt_of_src.ensure(S);
+  gb.corr.ensure((size_t)S * cap);
+  gb.mahal.ensure((size_t)S * cap * 2);
+  gb.partials.ensure((size_t)S * G * kPartStride);
+  gb.state.ensure(S);
+  gb.n_active.ensure(1);
+  gb.h_active.ensure(1);
+  gb.fit_partials.ensure((size_t)S * G * 2);
+  gb.fitness.ensure((size_t)S * 2);
+}
+
+__global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses, int S, int has_guess) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S) return;
+  GicpPairState s;
+  s.x0 = has_guess ? pose_from_rowmajor4x4f(guesses + 16 * p) : pose_identity();  // Isometry3d(guess.cast<double>())
+  s.xi = s.x0;
+  s.delta = pose_identity();
+  for (int i = 0; i < 36; i++) { s.H[i] = 0; s.final_H[i] = 0; }
+  for (int i = 0; i < 6; i++) { s.b[i] = 0; s.d[i] = 0; }
+  s.y0 = s.yi = 0;
+  s.lambda = -1.0;
+  s.nu = 2.0;
+  s.last_error = 0;
+  s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.pad = 0;
+  st[p] = s;
+}
+
+// ---- per-point pieces ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ Sym3<float> load_cov(const float4* cov, size_t i) {
+  const float4 a = cov[2 * i], b = cov[2 * i + 1];
+  return {a.x, a.y, a.z, a.w, b.x, b.y};
+}
+
+__device__ __forceinline__ void residual(const Pose& x, const float4& p, const float4& q, float& ax, float& ay, float& az, float& ex, float& ey,
+                                         float& ez) {
+  // transed_mean_A = trans * mean_A in fp64 (as upstream); the small residual is then handed to fp32
+  const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
+  const double dax = x.R[0] * px + x.R[1] * py + x.R[2] * pz + x.t[0];
+  const double day = x.R[3] * px + x.R[4] * py + x.R[5] * pz + x.t[1];
+  const double daz = x.R[6] * px + x.R[7] * py + x.R[8] * pz + x.t[2];
+  ax = (float)dax; ay = (float)day; az = (float)daz;
+  ex = (float)((double)q.x - dax); ey = (float)((double)q.y - day); ez = (float)((double)q.z - daz);
+}
+
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const float4* __restrict__ scov,
+                                                               const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
+                                                               const int* __restrict__ torig, const float4* __restrict__ tcov,
+                                                               const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
+                                                               size_t tslots, const int* __restrict__ tgt_of_src,
+                                                               const GicpPairState* __restrict__ state, int* __restrict__ corr,
+                                                               float4* __restrict__ mahal, double* __restrict__ partials, float max_corr_d2) {
+  __shared__ double smem[4 * kNAcc];
+  const int pair = blockIdx.y;
+  const GicpPairState* st = state + pair;
+  if (!st->active) return;
+  const int t = tgt_of_src[pair];
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
+  const float4* tc = tcov + (size_t)t * tcap * 2;
+  const int n = scount[pair];
+  const Pose x0 = st->x0;
+  float Tf[12], Rf[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { Tf[4 * r + c] = (float)x0.R[3 * r + c]; Rf[3 * r + c] = Tf[4 * r + c]; }
+    Tf[4 * r + 3] = (float)x0.t[r];
+  }
+  double acc[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
+  const size_t so = (size_t)pair * scap;
+  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
+    const float4 p = spts[so + i];
+    const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+    Nearest1 nn{g.orig, INFINITY, -1};
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, max_corr_d2, nn);
+    const int j = (nn.best_j >= 0 && nn.best_d2 < max_corr_d2) ? nn.best_j : -1;
+    corr[so + i] = j;
+    if (j < 0) continue;
+    const Sym3<float> CA = load_cov(scov, so + i);
+    const Sym3<float> CB = load_cov(tc, (size_t)j);
+    Sym3<float> RCR = sym3_rotate(Rf, CA);
+    RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
+    const Sym3<float> M = sym3_inverse(RCR);
+    mahal[2 * (so + i)] = make_float4(M.xx, M.xy, M.xz, M.yy);
+    mahal[2 * (so + i) + 1] = make_float4(M.yz, M.zz, 0.f, 0.f);
+    float ax, ay, az, ex, ey, ez;
+    residual(x0, p, g.pts[j], ax, ay, az, ex, ey, ez);
+    const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
+    const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
+    const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
+    // MS = M * skew(a)
+    const float m0[3] = {M.xx, M.xy, M.xz}, m1[3] = {M.xy, M.yy, M.yz}, m2[3] = {M.xz, M.yz, M.zz};
+    float MS[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float* mr = (r == 0) ? m0 : ((r == 1) ? m1 : m2);
+      MS[r][0] = mr[1] * az - mr[2] * ay;
+      MS[r][1] = mr[2] * ax - mr[0] * az;
+      MS[r][2] = mr[0] * ay - mr[1] * ax;
+    }
+    // Hrr = skew(a)^T * MS  (symmetric)
+    acc[0] += (double)(az * MS[1][0] - ay * MS[2][0]);
+    acc[1] += (double)(az * MS[1][1] - ay * MS[2][1]);
+    acc[2] += (double)(az * MS[1][2] - ay * MS[2][2]);
+    acc[3] += (double)(ax * MS[2][1] - az * MS[0][1]);
+    acc[4] += (double)(ax * MS[2][2] - az * MS[0][2]);
+    acc[5] += (double)(ay * MS[0][2] - ax * MS[1][2]);
+    // Hrt[i][c] = -(MS)[c][i]
+#pragma unroll
+    for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) acc[6 + 3 * i2 + c] -= (double)MS[c][i2];
+    // Htt = M
+    acc[15] += (double)M.xx; acc[16] += (double)M.xy; acc[17] += (double)M.xz;
+    acc[18] += (double)M.yy; acc[19] += (double)M.yz; acc[20] += (double)M.zz;
+    // b = J^T M e
+    acc[21] += (double)(az * Me1 - ay * Me2);
+    acc[22] += (double)(ax * Me2 - az * Me0);
+    acc[23] += (double)(ay * Me0 - ax * Me1);
+    acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
+    acc[27] += (double)(ex * Me0 + ey * Me1 + ez * Me2);
+    acc[28] += 1.0;
+  }
+  block_sum<kNAcc, 4>(acc, smem);
+  if (threadIdx.x == 0) {
+    double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride;
+#pragma unroll
+    for (int k = 0; k < kNAcc; k++) out[k] = acc[k];
+  }
+}
+
+__device__ __forceinline__ void unpack_normal_equations(const double* a, double* H, double* b) {
+  // rows/cols 0-2 rotation, 3-5 translation
+  H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[7] = a[3]; H[8] = a[4]; H[14] = a[5];
+  H[6] = a[1]; H[12] = a[2]; H[13] = a[4];
+  for (int i = 0; i < 3; i++)
+    for (int c = 0; c < 3; c++) { H[6 * i + 3 + c] = a[6 + 3 * i + c]; H[6 * (3 + c) + i] = a[6 + 3 * i + c]; }
+  H[21] = a[15]; H[22] = a[16]; H[23] = a[17]; H[28] = a[18]; H[29] = a[19]; H[35] = a[20];
+  H[27] = a[16]; H[33] = a[17]; H[34] = a[19];
+  for (int i = 0; i < 6; i++) b[i] = a[21 + i];
+}
+
+__device__ __forceinline__ void lm_trial(GicpPairState& s) {
+  double A[36], nb[6];
+  for (int i = 0; i < 36; i++) A[i] = s.H[i];
+  for (int i = 0; i < 6; i++) { A[7 * i] += s.lambda; nb[i] = -s.b[i]; }
+  ldlt6_solve(A, nb, s.d);
+  s.delta = se3_exp(s.d);
+  s.xi = pose_compose(s.delta, s.x0);
+}
+
+// After a step_optimize completed: iteration bookkeeping + convergence (F6).
+__device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParams& P, bool ok) {
+  s.iter += 1;
+  s.need_error = 0;
+  if (!ok) { s.lm_failed = 1; s.active = 0; return; }  // "lm not converged!!" -> break
+  const bool conv = is_converged(s.delta, P.rotation_epsilon, P.transformation_epsilon);
+  s.converged = conv ? 1 : 0;
+  if ((conv && !P.force_iterations) || s.iter >= P.max_iterations) s.active = 0;
+}
+
+__global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, const double* __restrict__ partials, int G, GicpDevParams P) {
+  __shared__ double sums[kPartStride];
+  const int pair = blockIdx.x;
+  GicpPairState* st = state + pair;
+  if (!st->active) return;
+  const int l = threadIdx.x;
+  if (l < kNAcc) {
+    double s = 0;
+    const double* p = partials + (size_t)pair * G * kPartStride + l;
+    for (int g = 0; g < G; g++) s += p[(size_t)g * kPartStride];
+    sums[l] = s;
+  }
+  __syncthreads();
+  if (l != 0) return;
+  GicpPairState s = *st;
+  unpack_normal_equations(sums, s.H, s.b);
+  s.y0 = sums[27];
+  s.n_inliers = (int)(sums[28] + 0.5);
+  if (P.optimizer == MI355_OPT_GN) {
+    double nb[6];
+    for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
+    ldlt6_solve(s.H, nb, s.d);
+    s.delta = se3_exp(s.d);
+    s.x0 = pose_compose(s.delta, s.x0);
+    for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
+    s.last_error = s.y0;
+    finish_step(s, P, true);
+  } else {
+    if (s.lambda < 0.0) {
+      double mx = 0;
+      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(s.H[7 * i]));
+      s.lambda = P.lm_init_lambda_factor * mx;
+    }
+    s.nu = 2.0;
+    s.trial = 0;
+    lm_trial(s);
+    s.need_error = 1;
+  }
+  *st = s;
+}
+
+__device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const float4& ma, const float4& mb) {
+  float ax, ay, az, ex, ey, ez;
+  residual(x, p, q, ax, ay, az, ex, ey, ez);
+  const float Me0 = ma.x * ex + ma.y * ey + ma.z * ez;
+  const float Me1 = ma.y * ex + ma.w * ey + mb.x * ez;
+  const float Me2 = ma.z * ex + mb.x * ey + mb.y * ez;
+  return (double)(ex * Me0 + ey * Me1 + ez * Me2);
+}
+
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
+                                                           const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
+                                                           const GicpPairState* __restrict__ state, const int* __restrict__ corr,
+                                                           const float4* __restrict__ mahal, double* __restrict__ partials) {
+  __shared__ double smem[4];
+  const int pair = blockIdx.y;
+  const GicpPairState* st = state + pair;
+  if (!st->active || !st->need_error) return;
+  const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
+  const int n = scount[pair];
+  const Pose xi = st->xi;
+  const size_t so = (size_t)pair * scap;
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
+    const int j = corr[so + i];
+    if (j < 0) continue;
+    acc[0] += point_error(xi, spts[so + i], tp[j], mahal[2 * (so + i)], mahal[2 * (so + i) + 1]);
+  }
+  block_sum<1, 4>(acc, smem);
+  if (threadIdx.x == 0) partials[((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + 30] = acc[0];
+}
+
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_decide(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
+                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
+                                                            GicpPairState* __restrict__ state, const int* __restrict__ corr,
+                                                            const float4* __restrict__ mahal, const double* __restrict__ partials, int G,
+                                                            GicpDevParams P) {
+  __shared__ double smem[4];
+  __shared__ GicpPairState s;
+  __shared__ int again;
+  const int pair = blockIdx.x;
+  if (!state[pair].active || !state[pair].need_error) return;
+  if (threadIdx.x == 0) {
+    s = state[pair];
+    double yi = 0;
+    for (int g = 0; g < G; g++) yi += partials[((size_t)pair * G + g) * kPartStride + 30];
+    s.yi = yi;
+  }
+  __syncthreads();
+  const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
+  const int n = scount[pair];
+  const size_t so = (size_t)pair * scap;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      again = 0;
+      double denom = 0;
+      for (int i = 0; i < 6; i++) denom += s.d[i] * (s.lambda * s.d[i] - s.b[i]);
+      const double rho = (s.y0 - s.yi) / denom;
+      if (rho < 0) {
+        if (!P.force_iterations && is_converged(s.delta, P.rotation_epsilon, P.transformation_epsilon)) {
+          finish_step(s, P, true);  // step_lm returns true without moving x0
+        } else {
+          s.lambda = s.nu * s.lambda;
+          s.nu = 2 * s.nu;
+          s.trial += 1;
+          if (s.trial >= P.lm_max_iterations) {
+            finish_step(s, P, false);
+          } else {
+            lm_trial(s);
+            again = 1;
+          }
+        }
+      } else {
+        s.x0 = s.xi;
+        const double t = 2 * rho - 1;
+        s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
+        for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
+        s.last_error = s.yi;
+        finish_step(s, P, true);
+      }
+    }
+    __syncthreads();
+    if (!again) break;
+    // rejected trial: evaluate compute_error at the new trial pose inside this block (rare path)
+    const Pose xi = s.xi;
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += kGicpBlock) {
+      const int j = corr[so + i];
+      if (j < 0) continue;
+      acc[0] += point_error(xi, spts[so + i], tp[j], mahal[2 * (so + i)], mahal[2 * (so + i) + 1]);
+    }
+    block_sum<1, 4>(acc, smem);
+    if (threadIdx.x == 0) s.yi = acc[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) state[pair] = s;
+}
+
+__global__ void k_count_active(const GicpPairState* __restrict__ st, int S, int* __restrict__ n_active) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int p = threadIdx.x; p < S; p += blockDim.x) c += st[p].active ? 1 : 0;
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) *n_active = cnt;
+}
+
+static GicpDevParams dev_params(const mi355_gicp_params& p) {
+  GicpDevParams P;
+  P.max_iterations = p.max_iterations;
+  P.optimizer = p.optimizer;
+  P.lm_max_iterations = p.lm_max_iterations;
+  P.force_iterations = p.force_iterations;
+  P.transformation_epsilon = p.transformation_epsilon;
+  P.rotation_epsilon = p.rotation_epsilon;
+  P.lm_init_lambda_factor = p.lm_init_lambda_factor;
+  const double m2 = p.max_correspondence_distance * p.max_correspondence_distance;
+  P.max_corr_d2 = m2 > 3.0e38 ? INFINITY : (float)m2;
+  return P;
+}
+
+static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (gb.time_kernels) {
+    while ((int)gb.ev.size() < gb.ev_used + 2) {
+      hipEvent_t e;
+      MI_HIP(hipEventCreate(&e));
+      gb.ev.push_back(e);
+    }
+    e0 = gb.ev[gb.ev_used];
+    e1 = gb.ev[gb.ev_used + 1];
+    gb.ev_used += 2;
+    MI_HIP(hipEventRecord(e0, s));
+  }
+  hipLaunchKernelGGL(k_gicp_linearize, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap, tgt.pts.p,
+                     tgt.orig.p, tgt.cov.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p,
+                     gb.partials.p, P.max_corr_d2);
+  if (gb.time_kernels) MI_HIP(hipEventRecord(e1, s));
+}
+
+void gicp_finish_timing(GicpBatch& gb) {
+  double ms = 0;
+  for (int i = 0; i + 1 < gb.ev_used; i += 2) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, gb.ev[i], gb.ev[i + 1]) == hipSuccess) ms += t;
+  }
+  gb.last_linearize_ms = ms;
+  gb.last_linearize_launches = gb.ev_used / 2;
+  gb.ev_used = 0;
+}
+
+void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
+                const float* guesses_host) {
+  if (!src.has_cov || !tgt.has_cov) throw ArgError(MI355_ESTATE, "covariances missing");
+  const int S = gb.S;
+  gb.h_map.resize(S);
+  for (int i = 0; i < S; i++) {
+    gb.h_map[i] = tgt_of_src_host ? tgt_of_src_host[i] : i;
+    if (gb.h_map[i] < 0 || gb.h_map[i] >= tgt.B) throw ArgError(MI355_EINVAL, "tgt_of_src out of range");
+  }
+  MI_HIP(hipMemcpyAsync(gb.tgt_of_src.p, gb.h_map.data(), S * sizeof(int), hipMemcpyHostToDevice, s));
+  if (guesses_host) {
+    gb.h_guess.assign(guesses_host, guesses_host + (size_t)S * 16);
+    gb.guesses.ensure((size_t)S * 16);
+    MI_HIP(hipMemcpyAsync(gb.guesses.p, gb.h_guess.data(), (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_gicp_init, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, (const float*)gb.guesses.p, S, guesses_host ? 1 : 0);
+  const GicpDevParams P = dev_params(p);
+  const int G = gb.blocks_per_pair;
+  gb.ev_used = 0;
+  const int check_every = p.force_iterations ? 0 : 4;
+  for (int it = 0; it < p.max_iterations; it++) {
+    launch_linearize(s, gb, src, tgt, P);
+    hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, gb.partials.p, G, P);
+    if (p.optimizer == MI355_OPT_LM) {
+      hipLaunchKernelGGL(k_gicp_error, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
+                         gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p);
+      hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
+                         gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, G, P);
+    }
+    if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
+      // early stop: every few iterations ask the device whether any pair is still optimising
+      hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, gb.state.p, S, gb.n_active.p);
+      MI_HIP(hipMemcpyAsync(gb.h_active.p, gb.n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      if (gb.h_active.p[0] == 0) break;
+    }
+  }
+  MI_LAUNCH_CHECK();
+}
+
+// ---- P5: getFitnessScore ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kGicpBlock) void k_fitness(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
+                                                        const float4* __restrict__ tpts, const int* __restrict__ torig,
+                                                        const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
+                                                        size_t tslots, const int* __restrict__ tgt_of_src, const GicpPairState* __restrict__ state,
+                                                        const float* __restrict__ T_all, double* __restrict__ fit_partials, float search_d2,
+                                                        double max_range) {
+  __shared__ double smem[4 * 2];
+  const int pair = blockIdx.y;
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
+  const int n = scount[pair];
+  float Tf[12];
+  if (T_all) {
+    for (int k = 0; k < 12; k++) Tf[k] = T_all[16 * pair + k];
+  } else {
+    const Pose x0 = state[pair].x0;  // final_transformation_ = x0.cast<float>()
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) Tf[4 * r + c] = (float)x0.R[3 * r + c];
+      Tf[4 * r + 3] = (float)x0.t[r];
+    }
+  }
+  double acc[2] = {0.0, 0.0};
+  const size_t so = (size_t)pair * scap;
+  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
+    const float4 p = spts[so + i];
+    const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+    Nearest1 nn{g.orig, INFINITY, -1};
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, search_d2, nn);
+    if (nn.best_j >= 0 && (double)nn.best_d2 <= max_range) { acc[0] += (double)nn.best_d2; acc[1] += 1.0; }
+  }
+  block_sum<2, 4>(acc, smem);
+  if (threadIdx.x == 0) {
+    fit_partials[((size_t)pair * gridDim.x + blockIdx.x) * 2] = acc[0];
+    fit_partials[((size_t)pair * gridDim.x + blockIdx.x) * 2 + 1] = acc[1];
+  }
+}
+
+__global__ void k_fitness_final(const double* __restrict__ fit_partials, double* __restrict__ fitness, int S, int G) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S) return;
+  double s = 0, c = 0;
+  for (int g = 0; g < G; g++) { s += fit_partials[((size_t)p * G + g) * 2]; c += fit_partials[((size_t)p * G + g) * 2 + 1]; }
+  fitness[2 * p] = s;
+  fitness[2 * p + 1] = c;
+}
+
+void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
+                  const float* T16_host_all) {
+  const float* dTp = nullptr;
+  if (!use_final_pose) {
+    gb.h_fit_T.assign(T16_host_all, T16_host_all + (size_t)gb.S * 16);
+    gb.fit_T.ensure((size_t)gb.S * 16);
+    MI_HIP(hipMemcpyAsync(gb.fit_T.p, gb.h_fit_T.data(), (size_t)gb.S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+    dTp = gb.fit_T.p;
+  }
+  const float search_d2 = (max_range >= 3.0e38) ? INFINITY : (float)(max_range * (1.0 + 1e-6)) + 1e-30f;
+  hipLaunchKernelGGL(k_fitness, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
+                     tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, dTp, gb.fit_partials.p, search_d2, max_range);
+  hipLaunchKernelGGL(k_fitness_final, dim3(div_up(gb.S, 64)), dim3(64), 0, s, gb.fit_partials.p, gb.fitness.p, gb.S, gb.blocks_per_pair);
+  MI_LAUNCH_CHECK();
+}
+
+void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, mi355_result* out, double* fitness_out) {
+  const int S = gb.S;
+  std::vector<GicpPairState> st(S);
+  std::vector<int> ns(S), nt(tgt.B), map(S);
+  MI_HIP(hipMemcpyAsync(st.data(), gb.state.p, S * sizeof(GicpPairState), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipMemcpyAsync(ns.data(), src.count.p, S * sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipMemcpyAsync(nt.data(), tgt.count.p, tgt.B * sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipMemcpyAsync(map.data(), gb.tgt_of_src.p, S * sizeof(int), hipMemcpyDeviceToHost, s));
+  std::vector<double> fit;
+  if (fitness_out) {
+    fit.resize((size_t)S * 2);
+    MI_HIP(hipMemcpyAsync(fit.data(), gb.fitness.p, fit.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  MI_HIP(hipStreamSynchronize(s));
+  if (gb.time_kernels) gicp_finish_timing(gb);
+  for (int p = 0; p < S; p++) {
+    mi355_result& r = out[p];
+    memset(&r, 0, sizeof(r));
+    pose_to_rowmajor4x4f(st[p].x0, r.T);
+    r.converged = st[p].converged;
+    r.iterations = st[p].iter;
+    r.error = st[p].last_error;
+    memcpy(r.H, st[p].final_H, sizeof(r.H));
+    r.n_source = ns[p];
+    r.n_target = nt[map[p]];
+    r.n_inliers = st[p].n_inliers;
+    if (fitness_out) fitness_out[p] = fit[2 * p + 1] > 0 ? fit[2 * p] / fit[2 * p + 1] : 1.7976931348623157e308;
+  }
+}
+
+__global__ void k_set_pose(GicpPairState* st, Pose x) {
+  st[0].x0 = x;
+  st[0].active = 1;
+  st[0].need_error = 0;
+  st[0].lambda = -1.0;
+}
+
+void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T16,
+                         double* H36, double* b6, double* err, int* corr_caller_order) {
+  if (!src.has_cov || !tgt.has_cov) throw ArgError(MI355_ESTATE, "covariances missing");
+  const int zero = 0;
+  MI_HIP(hipMemcpyAsync(gb.tgt_of_src.p, &zero, sizeof(int), hipMemcpyHostToDevice, s));
+  MI_HIP(hipStreamSynchronize(s));
+  hipLaunchKernelGGL(k_gicp_init, dim3(1), dim3(64), 0, s, gb.state.p, (const float*)nullptr, 1, 0);
+  Pose x;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) x.R[3 * r + c] = T16[4 * r + c];
+    x.t[r] = T16[4 * r + 3];
+  }
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, s, gb.state.p, x);
+  GicpDevParams P = dev_params(p);
+  P.optimizer = MI355_OPT_LM;
+  const bool tk = gb.time_kernels;
+  gb.time_kernels = false;
+  launch_linearize(s, gb, src, tgt, P);
+  gb.time_kernels = tk;
+  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, gb.partials.p, gb.blocks_per_pair, P);
+  MI_LAUNCH_CHECK();
+  GicpPairState st;
+  MI_HIP(hipMemcpyAsync(&st, gb.state.p, sizeof(st), hipMemcpyDeviceToHost, s));
+  int n = 0;
+  MI_HIP(hipMemcpyAsync(&n, src.count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  memcpy(H36, st.H, sizeof(st.H));
+  memcpy(b6, st.b, sizeof(st.b));
+  *err = st.y0;
+  if (corr_caller_order) {
+    int nt = 0;
+    MI_HIP(hipMemcpy(&nt, tgt.count.p, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> c(n), so(n), to(nt);
+    MI_HIP(hipMemcpy(c.data(), gb.corr.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    MI_HIP(hipMemcpy(so.data(), src.orig.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    MI_HIP(hipMemcpy(to.data(), tgt.orig.p, nt * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) corr_caller_order[so[i]] = c[i] >= 0 ? to[c[i]] : -1;
+  }
+}
+
+}  // namespace mi355

@@ -1,0 +1,251 @@
+"""pcl::Registration mirror: the objects `lidar_scan_matcher` / `graph_based_slam` hold as `registration_`
+(lidar_scan_matcher.hpp:99, graph_based_slam.hpp:108), running on the MI355X through the C-ABI.
+
+Method names are the ones the reference calls (lidar_scan_matcher.cpp:48-52,65-70,149,162,165-172;
+graph_based_slam.cpp:315-322): setInputTarget / setInputSource / align / hasConverged / getFinalTransformation /
+getFitnessScore plus the engine-specific setters.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .context import Context, default_context
+
+
+class _Registration:
+    _method = None
+
+    def __init__(self, params, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        self.params = params
+        self.handle = self.ctx._lib.mi355_reg_create(self.ctx.handle, self._method, C.byref(params))
+        if not self.handle:
+            raise L.Mi355Error(L.EINVAL, "mi355_reg_create failed")
+        self._result = None
+        self._dirty = False
+        self._keep = []
+
+    def _push(self):
+        if self._dirty:
+            self.ctx.check(self.ctx._lib.mi355_reg_set_params(self.handle, C.byref(self.params)))
+            self._dirty = False
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            setattr(self.params, k, v)
+        self._dirty = True
+
+    # -- pcl::Registration interface ----------------------------------------------------------------------------
+    def setInputTarget(self, cloud):
+        self._push()
+        v, keep = L.view(cloud)
+        self.ctx.check(self.ctx._lib.mi355_reg_set_target(self.handle, C.byref(v)))
+
+    def setInputSource(self, cloud):
+        self._push()
+        v, keep = L.view(cloud)
+        self._n_src = v.n
+        self.ctx.check(self.ctx._lib.mi355_reg_set_source(self.handle, C.byref(v)))
+
+    def align(self, guess=None, return_cloud: bool = False):
+        """align(output, guess).  Returns the aligned cloud when ``return_cloud`` (the node never uses it)."""
+        self._push()
+        g = None
+        if guess is not None:
+            g = np.ascontiguousarray(guess, dtype=np.float32).reshape(16)
+        out = np.empty((max(self._n_src, 1), 4), dtype=np.float32) if return_cloud else None
+        r = L.Result()
+        self.ctx.check(self.ctx._lib.mi355_reg_align(self.handle, g.ctypes.data if g is not None else None, C.byref(r),
+                                                     out.ctypes.data if out is not None else None))
+        self._result = r.to_dict()
+        return out[: self._n_src] if return_cloud else None
+
+    def hasConverged(self) -> bool:
+        return bool(self._result and self._result["converged"])
+
+    def getFinalTransformation(self) -> np.ndarray:
+        return self._result["T"] if self._result else np.eye(4, dtype=np.float32)
+
+    def getFitnessScore(self, max_range: float = np.finfo(np.float64).max) -> float:
+        s = C.c_double(0)
+        self.ctx.check(self.ctx._lib.mi355_reg_fitness(self.handle, C.c_double(max_range), C.byref(s)))
+        return s.value
+
+    @property
+    def result(self):
+        return self._result
+
+    def setMaximumIterations(self, n):
+        self._set(max_iterations=int(n))
+
+    def setTransformationEpsilon(self, e):
+        self._set(transformation_epsilon=float(e))
+
+    def setNumThreads(self, n):
+        self._set(num_threads=int(n))  # accepted for interface parity; the GPU path has no thread count
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx._lib.mi355_reg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FastGICP(_Registration):
+    """fast_gicp::FastGICP<PointXYZI,PointXYZI> (lidar_scan_matcher.cpp:37-54)."""
+
+    _method = L.METHOD_FAST_GICP
+
+    def __init__(self, ctx: Context | None = None, **params):
+        super().__init__(L.gicp_params(**params), ctx)
+
+    def setCorrespondenceRandomness(self, k):
+        self._set(k_correspondences=int(k))
+
+    def setMaxCorrespondenceDistance(self, d):
+        self._set(max_correspondence_distance=float(d))
+
+    def setRotationEpsilon(self, e):
+        self._set(rotation_epsilon=float(e))
+
+    def setRegularizationMethod(self, m):
+        self._set(regularization_method=int(m))
+
+    def setLSQType(self, t):
+        self._set(optimizer=int(t))
+
+    def linearize(self, T):
+        """FastGICP::linearize at pose T: (H 6x6, b 6, error, correspondences in the caller's point order)."""
+        self._push()
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        H = np.empty(36)
+        b = np.empty(6)
+        err = C.c_double(0)
+        corr = np.full(max(self._n_src, 1), -2, dtype=np.int32)
+        self.ctx.check(self.ctx._lib.mi355_reg_gicp_linearize(self.handle, T.ctypes.data, H.ctypes.data, b.ctypes.data, C.byref(err), corr.ctypes.data))
+        return H.reshape(6, 6), b, err.value, corr[: self._n_src]
+
+
+class NormalDistributionsTransform(_Registration):
+    """pclomp::NormalDistributionsTransform<PointXYZI,PointXYZI> with DIRECT7 (lidar_scan_matcher.cpp:55-72)."""
+
+    _method = L.METHOD_NDT_OMP
+
+    def __init__(self, ctx: Context | None = None, **params):
+        super().__init__(L.ndt_params(**params), ctx)
+
+    def setStepSize(self, s):
+        self._set(step_size=float(s))
+
+    def setResolution(self, r):
+        self._set(resolution=float(r))
+
+    def setNeighborhoodSearchMethod(self, m):
+        if m != "DIRECT7":
+            raise ValueError("the reference selects pclomp::DIRECT7 (lidar_scan_matcher.cpp:69); other modes are not built")
+
+    def getTransformationProbability(self):
+        return self._result["trans_probability"] if self._result else 0.0
+
+    def derivatives(self, p6, hessian_fp64=False):
+        self._push()
+        p6 = np.ascontiguousarray(p6, dtype=np.float64).reshape(6)
+        score = C.c_double(0)
+        g = np.empty(6)
+        H = np.empty(36)
+        self.ctx.check(self.ctx._lib.mi355_reg_ndt_derivatives(self.handle, p6.ctypes.data, C.byref(score), g.ctypes.data, H.ctypes.data,
+                                                               1 if hessian_fp64 else 0))
+        return score.value, g, H.reshape(6, 6)
+
+    def cells(self):
+        n = C.c_size_t(0)
+        self.ctx.check(self.ctx._lib.mi355_reg_ndt_num_cells(self.handle, C.byref(n)))
+        m = max(n.value, 1)
+        idx = np.empty(m, dtype=np.int64)
+        cnt = np.empty(m, dtype=np.int32)
+        mean = np.empty((m, 3))
+        cov = np.empty((m, 3, 3))
+        icov = np.empty((m, 3, 3))
+        min_b = np.empty(3, dtype=np.int32)
+        div_b = np.empty(3, dtype=np.int32)
+        self.ctx.check(self.ctx._lib.mi355_reg_ndt_cells(self.handle, idx.ctypes.data, cnt.ctypes.data, mean.ctypes.data, cov.ctypes.data,
+                                                         icov.ctypes.data, min_b.ctypes.data, div_b.ctypes.data))
+        k = n.value
+        return {"idx": idx[:k], "n": cnt[:k], "mean": mean[:k], "cov": cov[:k], "icov": icov[:k], "min_b": min_b, "div_b": div_b}
+
+
+class BatchRegistration:
+    """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one GICP per pair."""
+
+    def __init__(self, n_sources: int, n_targets: int, capacity: int, ctx: Context | None = None, **params):
+        self.ctx = ctx or default_context()
+        self.params = L.gicp_params(**params)
+        self.n_sources, self.n_targets, self.capacity = int(n_sources), int(n_targets), int(capacity)
+        self.handle = self.ctx._lib.mi355_batch_create(self.ctx.handle, L.METHOD_FAST_GICP, C.byref(self.params), self.n_sources, self.n_targets,
+                                                       self.capacity)
+        if not self.handle:
+            raise L.Mi355Error(L.EINVAL, self.ctx._lib.mi355_last_error(self.ctx.handle).decode())
+
+    @staticmethod
+    def _counts(c, n):
+        c = np.ascontiguousarray(c, dtype=np.int32)
+        assert c.shape == (n,), c.shape
+        return c
+
+    def set_targets_dev(self, data_ptr: int, counts, prefilter=None):
+        c = self._counts(counts, self.n_targets)
+        self.ctx.check(self.ctx._lib.mi355_batch_set_targets_dev(self.handle, C.c_void_p(data_ptr), c.ctypes.data, C.byref(prefilter) if prefilter else None))
+
+    def set_sources_dev(self, data_ptr: int, counts, prefilter=None):
+        c = self._counts(counts, self.n_sources)
+        self.ctx.check(self.ctx._lib.mi355_batch_set_sources_dev(self.handle, C.c_void_p(data_ptr), c.ctypes.data, C.byref(prefilter) if prefilter else None))
+
+    def set_targets(self, points, counts, prefilter=None):
+        p = np.ascontiguousarray(points, dtype=np.float32)
+        assert p.shape == (self.n_targets, self.capacity, 4), p.shape
+        c = self._counts(counts, self.n_targets)
+        self.ctx.check(self.ctx._lib.mi355_batch_set_targets(self.handle, p.ctypes.data, c.ctypes.data, C.byref(prefilter) if prefilter else None))
+
+    def set_sources(self, points, counts, prefilter=None):
+        p = np.ascontiguousarray(points, dtype=np.float32)
+        assert p.shape == (self.n_sources, self.capacity, 4), p.shape
+        c = self._counts(counts, self.n_sources)
+        self.ctx.check(self.ctx._lib.mi355_batch_set_sources(self.handle, p.ctypes.data, c.ctypes.data, C.byref(prefilter) if prefilter else None))
+
+    def align(self, tgt_of_src=None, guesses=None, with_fitness=False):
+        t = None if tgt_of_src is None else np.ascontiguousarray(tgt_of_src, dtype=np.int32)
+        g = None if guesses is None else np.ascontiguousarray(guesses, dtype=np.float32).reshape(self.n_sources, 16)
+        self.ctx.check(self.ctx._lib.mi355_batch_align(self.handle, t.ctypes.data if t is not None else None, g.ctypes.data if g is not None else None,
+                                                       1 if with_fitness else 0))
+
+    def results(self, with_fitness=False):
+        res = (L.Result * self.n_sources)()
+        fit = np.empty(self.n_sources) if with_fitness else None
+        self.ctx.check(self.ctx._lib.mi355_batch_results(self.handle, res, fit.ctypes.data if fit is not None else None))
+        out = [r.to_dict() for r in res]
+        return (out, fit) if with_fitness else out
+
+    def kernel_time(self):
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        self.ctx.check(self.ctx._lib.mi355_batch_kernel_time(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx._lib.mi355_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

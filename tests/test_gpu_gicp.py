@@ -1,0 +1,177 @@
+"""GPU parity: the HIP GICP path vs the oracle, through the C-ABI.
+
+Tolerance (BASELINE.md §4 / SURVEY.md §8c): same init, fixed iteration count -> ||dt|| <= 1 mm, angle(dR) <= 1e-4 rad.
+The kernel computes the per-point Mahalanobis and Jacobian products in fp32 (the oracle in fp64) and accumulates the
+normal equations in fp64, so H, b and the error agree to ~1e-5 relative, correspondences exactly."""
+import numpy as np
+import pytest
+
+from lidar_graph_slam_amd import synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_R = 1e-3, 1e-4
+
+
+@pytest.fixture(scope="module")
+def R():
+    from lidar_graph_slam_amd import registration
+
+    return registration
+
+
+def _reg(R, s, t, **kw):
+    reg = R.FastGICP(**kw)
+    reg.setInputTarget(t)
+    reg.setInputSource(s)
+    return reg
+
+
+def test_linearize_parity(R, small_pair):
+    s, t, T = small_pair
+    cs, ct = O.covariances(s), O.covariances(t)
+    reg = _reg(R, s, t)
+    for guess in (np.eye(4), T, synth.se3(0.3, -0.1, 0.02, 0.01, -0.01, 0.02)):
+        H, b, err, corr = reg.linearize(guess)
+        H2, b2, err2, corr2, _ = O.gicp_linearize(s, cs, t, ct, guess, 2.0)
+        np.testing.assert_array_equal(corr, corr2)  # exact NN parity incl. the max-distance gate
+        np.testing.assert_allclose(H, H2, rtol=2e-5, atol=2e-5 * np.abs(H2).max())
+        np.testing.assert_allclose(b, b2, rtol=2e-5, atol=2e-5 * np.abs(b2).max())
+        np.testing.assert_allclose(err, err2, rtol=2e-5)
+
+
+def test_align_fixed_iterations(R, small_pair):
+    s, t, T = small_pair
+    reg = _reg(R, s, t, max_iterations=10, force_iterations=1)
+    reg.align()
+    ref = O.gicp_align(s, t, O.gicp_params(max_iterations=10, force_iterations=1))
+    dt, dr = synth.pose_error(reg.getFinalTransformation(), ref["T"])
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    assert reg.result["iterations"] == 10
+    assert reg.result["n_source"] == len(s) and reg.result["n_target"] == len(t)
+    np.testing.assert_allclose(reg.result["H"], ref["H"], rtol=1e-3, atol=1e-3 * np.abs(ref["H"]).max())
+
+
+def test_align_early_stop_and_guess(R, small_pair):
+    s, t, T = small_pair
+    reg = _reg(R, s, t)
+    reg.align()
+    ref = O.gicp_align(s, t, O.gicp_params())
+    assert reg.hasConverged() and ref["converged"]
+    dt, dr = synth.pose_error(reg.getFinalTransformation(), ref["T"])
+    assert dt <= 0.01 and dr <= 2e-3  # inside the convergence band (F9)
+    assert abs(reg.result["iterations"] - ref["iterations"]) <= 1
+    # previous pose as the initial guess (lidar_scan_matcher.cpp:165)
+    g = ref["T"]
+    reg.align(g)
+    ref2 = O.gicp_align(s, t, O.gicp_params(), guess=g)
+    dt, dr = synth.pose_error(reg.getFinalTransformation(), ref2["T"])
+    assert reg.hasConverged() and dt <= 0.01 and dr <= 2e-3
+    out = reg.align(g, return_cloud=True)
+    np.testing.assert_array_equal(out, O.transform(s, reg.getFinalTransformation()))
+
+
+def test_set_target_always_rebuilds(R, small_pair):
+    # the node mutates the same cloud object in place and re-passes it (lidar_scan_matcher.cpp:187,209,212)
+    s, t, T = small_pair
+    buf = t.copy()
+    reg = _reg(R, s, buf, max_iterations=8, force_iterations=1)
+    reg.align()
+    T1 = reg.getFinalTransformation().copy()
+    shift = synth.se3(0.5, 0.2, 0.0, 0, 0, 0.01).astype(np.float32)
+    buf[:] = O.transform(t, shift)
+    reg.setInputTarget(buf)
+    reg.align()
+    T2 = reg.getFinalTransformation()
+    ref = O.gicp_align(s, buf, O.gicp_params(max_iterations=8, force_iterations=1))
+    dt, dr = synth.pose_error(T2, ref["T"])
+    assert dt <= TOL_T and dr <= TOL_R
+    assert synth.pose_error(T1, T2)[0] > 0.3
+
+
+def test_gauss_newton_and_regularisations(R, small_pair):
+    from lidar_graph_slam_amd import _lib as L
+
+    s, t, _ = small_pair
+    for kw in (dict(optimizer=L.OPT_GN), dict(regularization_method=L.REG_MIN_EIG), dict(regularization_method=L.REG_FROBENIUS), dict(k_correspondences=10)):
+        reg = _reg(R, s, t, max_iterations=6, force_iterations=1, **kw)
+        reg.align()
+        ref = O.gicp_align(s, t, O.gicp_params(max_iterations=6, force_iterations=1, **kw))
+        dt, dr = synth.pose_error(reg.getFinalTransformation(), ref["T"])
+        assert dt <= TOL_T and dr <= 2 * TOL_R, (kw, dt, dr)
+
+
+def test_fitness_score(R, small_pair):
+    s, t, T = small_pair
+    reg = _reg(R, s, t)
+    f0 = reg.getFitnessScore()  # before align: final_transformation_ = identity
+    np.testing.assert_allclose(f0, O.fitness(s, t, np.eye(4, dtype=np.float32)), rtol=1e-9)
+    reg.align()
+    Tf = reg.getFinalTransformation()
+    np.testing.assert_allclose(reg.getFitnessScore(), O.fitness(s, t, Tf), rtol=1e-9)
+    np.testing.assert_allclose(reg.getFitnessScore(0.01), O.fitness(s, t, Tf, 0.01), rtol=1e-9)
+    assert reg.getFitnessScore(-1.0) == np.finfo(np.float64).max
+
+
+def test_no_correspondences_and_errors(R, small_pair):
+    from lidar_graph_slam_amd import _lib as L
+
+    s, t, _ = small_pair
+    reg = _reg(R, s, t, max_iterations=3)
+    reg.align(synth.se3(0, 0, 60.0).astype(np.float32))  # nothing within 2 m: H = 0 -> LM cannot step
+    assert not reg.hasConverged()
+    reg2 = R.FastGICP()
+    with pytest.raises(L.Mi355Error):
+        reg2.setInputSource(s[:5])  # fewer points than k_correspondences
+    reg3 = R.FastGICP()
+    reg3.setInputSource(s)
+    with pytest.raises(L.Mi355Error):
+        reg3.align()  # no target
+
+
+def test_full_size_pair_recovers_truth(R):
+    src, tgt, T = synth.make_pair()
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+    s, t = pre.callback_sensor_points(src), pre.callback_sensor_points(tgt)
+    reg = _reg(R, s, t, max_iterations=20, force_iterations=1)
+    reg.align()
+    ref = O.gicp_align(s, t, O.gicp_params(max_iterations=20, force_iterations=1))
+    dt, dr = synth.pose_error(reg.getFinalTransformation(), ref["T"])
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    dt, dr = synth.pose_error(reg.getFinalTransformation(), T)
+    assert dt < 0.015 and dr < 5e-4
+
+
+def test_batch_matches_single(R, small_pair):
+    s, t, T = small_pair
+    cap = max(len(s), len(t)) + 7
+    nS, nT = 5, 2
+    rng = np.random.default_rng(0)
+    srcs = np.zeros((nS, cap, 4), np.float32)
+    tgts = np.zeros((nT, cap, 4), np.float32)
+    ns, nt = [], []
+    shifts = [np.eye(4, dtype=np.float32), synth.se3(0.2, -0.1, 0, 0, 0, 0.01).astype(np.float32)]
+    for j in range(nT):
+        tj = O.transform(t, shifts[j])
+        tgts[j, : len(tj)] = tj
+        nt.append(len(tj))
+    for i in range(nS):
+        si = s[: len(s) - 11 * i]  # ragged sizes
+        srcs[i, : len(si)] = si
+        ns.append(len(si))
+    tgt_of_src = [0, 1, 0, 1, 1]
+    b = R.BatchRegistration(nS, nT, cap, max_iterations=8, force_iterations=1)
+    b.set_targets(tgts, nt)
+    b.set_sources(srcs, ns)
+    b.align(tgt_of_src, with_fitness=True)
+    res, fit = b.results(with_fitness=True)
+    for i in range(nS):
+        ref = O.gicp_align(srcs[i, : ns[i]], tgts[tgt_of_src[i], : nt[tgt_of_src[i]]], O.gicp_params(max_iterations=8, force_iterations=1))
+        dt, dr = synth.pose_error(res[i]["T"], ref["T"])
+        assert dt <= TOL_T and dr <= TOL_R, (i, dt, dr)
+        np.testing.assert_allclose(fit[i], O.fitness(srcs[i, : ns[i]], tgts[tgt_of_src[i], : nt[tgt_of_src[i]]], res[i]["T"]), rtol=1e-9)
+    ms, launches = b.kernel_time()
+    assert launches == 8 and ms > 0
