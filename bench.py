@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: scan-pairs/sec (64k-pt pairs, voxel 0.2 m + 20 GICP iterations) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One *step* = one pass of the whole hot path over one batch of `--pairs` independent synthetic scan pairs per GPU,
+inputs already resident in HBM: distance filter + VoxelGrid 0.2 m on both clouds -> voxel-hash build -> k=20
+covariances -> exactly 20 Levenberg-Marquardt GICP iterations -> poses copied back.  Pairs are sharded across ranks with
+no data-path collective (weak scaling); the only collective is the MAX of the elapsed time.  BASELINE.json configs[1].
+
+The JSON line also carries
+  roofline      k_gicp_linearize (the dominant kernel): algorithmic bytes (80 B per source point per launch) / mean launch
+                duration measured with HIP events on the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline  the oracle (CPU restatement of the reference's fast_gicp path, OpenMP) timed on this host's cores over a
+                bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+BYTES_PER_POINT_ITER = 80  # src pt 16 + src cov 24 + tgt pt 16 + tgt cov 24
+N_BASE = 4  # distinct ray-cast scenes/poses; every pair of the batch is a differently placed copy of one of them
+
+
+def base_pairs(rank: int):
+    from lidar_graph_slam_amd import synth
+
+    out = []
+    for i in range(N_BASE):
+        T_gt = synth.se3(1.0 - 0.1 * i, 0.1 + 0.05 * i, 0.0, 0.0, 0.0, np.deg2rad(2.0 - 0.4 * i))
+        T_tgt = synth.se3(7.0 * i + 3.0 * rank, 0.3 * i, 0.0, 0.0, 0.0, 0.02 * i)
+        src, tgt, _ = synth.make_pair(T_gt=T_gt, T_target=T_tgt, seed=11 + 17 * i + 101 * rank)
+        out.append((src, tgt, T_gt))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=128, help="scan pairs per GPU per step")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--leaf", type=float, default=0.2)
+    ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from lidar_graph_slam_amd import _lib as L
+    from lidar_graph_slam_amd import synth
+    from lidar_graph_slam_amd.context import Context
+    from lidar_graph_slam_amd.registration import BatchRegistration
+
+    ctx = Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.cell > 0:
+        ctx.set_grid_cell(args.cell)
+    dev_name, cus = ctx.device_info()
+
+    # ---- synthetic inputs, resident in HBM -----------------------------------------------------------------------
+    P = args.pairs
+    base = base_pairs(rank)
+    cap = base[0][0].shape[0]
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    src_d = torch.empty((P, cap, 4), dtype=torch.float32, device=dev)
+    tgt_d = torch.empty((P, cap, 4), dtype=torch.float32, device=dev)
+    base_src = [torch.from_numpy(b[0]).to(dev) for b in base]
+    base_tgt = [torch.from_numpy(b[1]).to(dev) for b in base]
+    world_T = []
+    for p in range(P):
+        k = p % N_BASE
+        yaw = float(torch.rand(1, generator=g)) * 2 * np.pi
+        tx, ty = (float(torch.rand(1, generator=g)) - 0.5) * 40.0, (float(torch.rand(1, generator=g)) - 0.5) * 40.0
+        W = torch.from_numpy(synth.se3(tx, ty, 0.0, 0.0, 0.0, yaw).astype(np.float32)).to(dev)
+        world_T.append(W.cpu().numpy())
+        for dst, b in ((src_d, base_src[k]), (tgt_d, base_tgt[k])):
+            valid = (b[:, :3].abs().sum(dim=1) > 0).unsqueeze(1)  # keep no-return points at the origin
+            xyz = b[:, :3] @ W[:3, :3].T + W[:3, 3]
+            dst[p, :, :3] = torch.where(valid, xyz, torch.zeros_like(xyz))
+            dst[p, :, 3] = b[:, 3]
+    counts = np.full(P, cap, dtype=np.int32)
+    torch.cuda.synchronize()
+    # NOTE: rotating both clouds of a pair by the same world transform W keeps the sensor-frame relative pose:
+    # aligned pose T' satisfies T' = W T_gt W^-1.
+
+    params = dict(max_iterations=args.iters, force_iterations=1)
+    batch = BatchRegistration(P, P, cap, ctx=ctx, **params)
+    pre = L.prefilter_params(min_distance=1.0, leaf_size=args.leaf, mean_k=0)
+
+    def step():
+        batch.set_targets_dev(tgt_d.data_ptr(), counts, pre)
+        batch.set_sources_dev(src_d.data_ptr(), counts, pre)
+        batch.align()
+        return batch.results()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lin_ms, lin_launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        ms, nl = batch.kernel_time()
+        lin_ms += ms
+        lin_launches += nl
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness of what was timed: pose error vs ground truth for every pair of this rank ------------------------
+    errs = []
+    for p in range(P):
+        W = world_T[p].astype(np.float64)
+        T_expected = W @ base[p % N_BASE][2] @ np.linalg.inv(W)
+        errs.append(synth.pose_error(res[p]["T"], T_expected))
+    errs = np.array(errs)
+    n_src = np.array([r["n_source"] for r in res])
+    n_tgt = np.array([r["n_target"] for r in res])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_pairs = P * world * args.steps
+    value = total_pairs / elapsed
+    # dominant kernel roofline (this rank's launches; every rank runs the same shape)
+    avg_launch_ms = lin_ms / max(lin_launches, 1)
+    bytes_per_launch = BYTES_PER_POINT_ITER * float(n_src.sum())
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    roofline = {
+        "kernel": "k_gicp_linearize",
+        "bound": "hbm",
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "avg_launch_ms": round(avg_launch_ms, 4),
+        "launches": lin_launches,
+        "algorithmic_bytes_per_launch": int(bytes_per_launch),
+        "linearize_share_of_step": round(lin_ms / (elapsed * 1e3), 3),
+    }
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle_py as O
+
+        threads = O.max_threads()
+        gp = O.gicp_params(max_iterations=args.iters, force_iterations=1)
+
+        def cpu_pair(k):
+            s, t, _ = base[k % N_BASE]
+            s2 = O.voxel_grid(O.distance_filter(s, 1.0), args.leaf)[0]
+            t2 = O.voxel_grid(O.distance_filter(t, 1.0), args.leaf)[0]
+            return O.gicp_align(s2, t2, gp)
+
+        cpu_pair(0)
+        cpu_pair(1)  # warm the OpenMP pool and the page cache
+        n_done, tc0 = 0, time.perf_counter()
+        while (time.perf_counter() - tc0 < args.cpu_seconds or n_done < 8) and n_done < 2000:
+            r = cpu_pair(n_done)
+            n_done += 1
+        tc = time.perf_counter() - tc0
+        dt, dr = synth.pose_error(res[0]["T"], world_T[0].astype(np.float64) @ cpu_pair(0)["T"].astype(np.float64) @ np.linalg.inv(world_T[0].astype(np.float64)))
+        cpu = {
+            "value": round(n_done / tc, 3),
+            "unit": "pairs/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"{n_done} of the same 64k-pt pairs (distance filter + voxel {args.leaf} m + k=20 covariances + {args.iters} LM iterations), "
+                      f"oracle/liboracle.so with {threads} OpenMP threads, {tc:.1f} s",
+            "gpu_vs_cpu_pose_dt_m": round(dt, 6),
+            "gpu_vs_cpu_pose_dr_rad": round(dr, 7),
+        }
+
+    out = {
+        "metric": "scan_pairs_per_sec",
+        "value": round(value, 2),
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: 64k-pt scan pairs, distance filter 1.0 m + voxel 0.2 m + GICP k=20, exactly 20 LM iterations, batched",
+            "pairs_per_gpu_per_step": P,
+            "raw_points_per_cloud": int(cap),
+            "points_after_voxel_src_mean": float(n_src.mean()),
+            "points_after_voxel_tgt_mean": float(n_tgt.mean()),
+            "gicp_iterations": args.iters,
+            "voxel_leaf_m": args.leaf,
+            "device": dev_name,
+            "compute_units": cus,
+            "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "accuracy": {
+            "pose_err_vs_truth_dt_m_max": round(float(errs[:, 0].max()), 5),
+            "pose_err_vs_truth_dr_rad_max": round(float(errs[:, 1].max()), 6),
+        },
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

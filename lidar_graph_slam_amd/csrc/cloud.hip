@@ -10,7 +10,7 @@ void CloudSet::alloc(int B_, size_t cap_) {
   B = B_;
   cap = cap_;
   size_t s = 16;
-  while (s < 2 * cap) s <<= 1;
+  while (s < 8 * cap) s <<= 1;  // up to 5 levels of cells, load factor <= 0.625 in the worst case
   slots_cap = s;
   pts.ensure((size_t)B * cap);
   orig.ensure((size_t)B * cap);
@@ -92,15 +92,19 @@ __global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __re
     dx = (int)floorf((mx[0] - mn[0]) * inv) + 1;
     dy = (int)floorf((mx[1] - mn[1]) * inv) + 1;
     dz = (int)floorf((mx[2] - mn[2]) * inv) + 1;
-    if ((double)dx * (double)dy * (double)dz < 2.0e9 && dx < (1 << 20) && dy < (1 << 20) && dz < (1 << 20)) break;
-    cs *= 2.0f;  // absurdly large extents: coarsen until the linear index fits 31 bits
+    if (dx <= 512 && dy <= 512 && dz <= 512) break;  // 9 Morton bits per axis
+    cs *= 2.0f;                                       // larger extents: coarsen the base cell
   }
   m.ox = mn[0]; m.oy = mn[1]; m.oz = mn[2];
   m.cell = cs;
   m.inv_cell = 1.0f / cs;
   m.dx = dx; m.dy = dy; m.dz = dz;
+  int top = 0;
+  while (top < kMaxLevel && (((max(dx, max(dy, dz)) - 1) >> top) > 0)) top++;
+  m.top_level = top;
+  m.pad[0] = m.pad[1] = m.pad[2] = 0;
   uint32_t slots = 16, lg = 4;
-  while (slots < 2u * (uint32_t)max(n, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  while (slots < 8u * (uint32_t)max(n, 1) && slots < slots_cap) { slots <<= 1; lg++; }
   m.hshift = 32 - lg;
   m.hmask = slots - 1;
   meta[c] = m;
@@ -110,7 +114,7 @@ __device__ __forceinline__ uint32_t cell_key(const GridMeta& m, float x, float y
   const int ix = min(max((int)floorf(cell_coord(x, m.ox, m.inv_cell)), 0), m.dx - 1);
   const int iy = min(max((int)floorf(cell_coord(y, m.oy, m.inv_cell)), 0), m.dy - 1);
   const int iz = min(max((int)floorf(cell_coord(z, m.oz, m.inv_cell)), 0), m.dz - 1);
-  return (uint32_t)ix + (uint32_t)m.dx * ((uint32_t)iy + (uint32_t)m.dy * (uint32_t)iz);
+  return morton27((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
 }
 
 __global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, uint32_t* __restrict__ keys,
@@ -152,12 +156,16 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
   pts[o + i] = in[o + v];
   orig[o + i] = v;
   const uint32_t key = keys[o + i];
-  const bool head = (i == 0) || (keys[o + i - 1] != key);
-  const bool tail = (i == m.n - 1) || (keys[o + i + 1] != key);
-  if (head || tail) {
-    HashSlot* sl = table_insert(table + (size_t)c * slots_cap, m, key);
-    if (head) sl->start = i;
-    if (tail) sl->end = i + 1;
+  const uint32_t kprev = (i > 0) ? keys[o + i - 1] : 0u, knext = (i < m.n - 1) ? keys[o + i + 1] : 0u;
+  HashSlot* tab = table + (size_t)c * slots_cap;
+  for (int l = 0; l <= m.top_level; l++) {  // one (start, end) entry per occupied cell of every level
+    const bool head = (i == 0) || ((kprev >> (3 * l)) != (key >> (3 * l)));
+    const bool tail = (i == m.n - 1) || ((knext >> (3 * l)) != (key >> (3 * l)));
+    if (head || tail) {
+      HashSlot* sl = table_insert(tab, m, level_key(key, l));
+      if (head) sl->start = i;
+      if (tail) sl->end = i + 1;
+    }
   }
 }
 
@@ -176,7 +184,7 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   const dim3 grid(div_up((long)cap, 256), B);
   hipLaunchKernelGGL(k_cell_keys, grid, dim3(256), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
   sort_pairs(s, ws, B, cap, cnt_in, 4);
-  hipLaunchKernelGGL(k_table_clear, dim3(std::max(1, std::min(64, (int)(out.slots_cap / 1024))), B), dim3(256), 0, s, out.table.p, out.meta.p,
+  hipLaunchKernelGGL(k_table_clear, dim3(std::max(1, std::min(256, (int)(out.slots_cap / 1024))), B), dim3(256), 0, s, out.table.p, out.meta.p,
                      out.slots_cap);
   hipLaunchKernelGGL(k_gather_insert, grid, dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p, out.table.p, cap,
                      out.slots_cap);
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256) void k_knn_cov(const float4* __restrict__ pts,
   const float4 q = g.pts[i];
   NearestK<K> nk;
   nk.init(g.orig, k);
-  grid_search(g, q.x, q.y, q.z, INFINITY, nk);
+  grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k), 1);
   // neighbours as fp64, mean-subtracted, cov = D D^T / k  (divide by k, not k-1)
   double mx = 0, my = 0, mz = 0;
 #pragma unroll
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void k_knn_query(const float4* __restrict__ pt
   const float4 q = queries[qi];
   NearestK<K> nk;
   nk.init(g.orig, k);
-  grid_search(g, q.x, q.y, q.z, INFINITY, nk);
+  grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k), 1);
 #pragma unroll
   for (int j = 0; j < K; j++)
     if (j < k) {
@@ -353,6 +361,8 @@ __global__ void k_voxel_meta(const uint32_t* __restrict__ bounds, const int* __r
   m.inv_cell = inv;
   m.cell = leaf;
   m.hshift = 0; m.hmask = 0;
+  m.top_level = 0;
+  m.pad[0] = m.pad[1] = m.pad[2] = 0;
   vmeta[c] = m;
 }
 
@@ -442,7 +452,7 @@ __global__ __launch_bounds__(256) void k_sor_meandist(const float4* __restrict__
   const float4 q = g.pts[i];
   NearestK<K> nk;
   nk.init(g.orig, mean_k + 1);
-  grid_search(g, q.x, q.y, q.z, INFINITY, nk);
+  grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, mean_k + 1), 1);
   double dist_sum = 0.0;
 #pragma unroll
   for (int j = 1; j < K; j++)  // j = 0 is the query point itself

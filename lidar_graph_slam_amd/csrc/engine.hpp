@@ -7,7 +7,7 @@
 //   pts   float4 (x,y,z,intensity)  16 B/pt   sorted by NN-grid cell key (x fastest)
 //   orig  int32                      4 B/pt   index of the point in the caller's order
 //   cov   2 x float4 (xx,xy,xz,yy | yz,zz,0,0) 32 B/pt (24 B algorithmic)
-//   table HashSlot{key,start,end,-} 16 B/slot open-addressing voxel hash: cell key -> point range
+//   table HashSlot{key,start,end,-} 16 B/slot open-addressing voxel hash: (level, Morton cell key) -> point range
 #pragma once
 #include <stdint.h>
 
@@ -33,7 +33,10 @@ struct GridMeta {
   uint32_t hmask;     // n_slots - 1
   int n;              // points in this cloud
   int overflow;       // VoxelGrid index overflow flag (pass-through)
+  int top_level;      // coarsest level of the multi-level voxel hash (cell edge = cell * 2^level)
+  int pad[3];
 };
+constexpr int kMaxLevel = 4;
 
 struct Workspace {
   DevBuf<uint32_t> keys_a, keys_b;

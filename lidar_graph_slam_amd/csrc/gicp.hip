@@ -81,15 +81,25 @@ __device__ __forceinline__ Sym3<float> load_cov(const float4* cov, size_t i) {
   return {a.x, a.y, a.z, a.w, b.x, b.y};
 }
 
+// e^T M e with the residual in fp64 and the stored fp32 Mahalanobis matrix: y0 (linearize) and yi (compute_error) must
+// resolve cost decreases far below fp32 resolution or the LM rho test degenerates into a coin flip near convergence.
+__device__ __forceinline__ double cost64(double ex, double ey, double ez, float mxx, float mxy, float mxz, float myy, float myz, float mzz) {
+  const double a = (double)mxx * ex + (double)mxy * ey + (double)mxz * ez;
+  const double b = (double)mxy * ex + (double)myy * ey + (double)myz * ez;
+  const double c = (double)mxz * ex + (double)myz * ey + (double)mzz * ez;
+  return ex * a + ey * b + ez * c;
+}
+
 __device__ __forceinline__ void residual(const Pose& x, const float4& p, const float4& q, float& ax, float& ay, float& az, float& ex, float& ey,
-                                         float& ez) {
+                                         float& ez, double& dex, double& dey, double& dez) {
   // transed_mean_A = trans * mean_A in fp64 (as upstream); the small residual is then handed to fp32
   const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
   const double dax = x.R[0] * px + x.R[1] * py + x.R[2] * pz + x.t[0];
   const double day = x.R[3] * px + x.R[4] * py + x.R[5] * pz + x.t[1];
   const double daz = x.R[6] * px + x.R[7] * py + x.R[8] * pz + x.t[2];
   ax = (float)dax; ay = (float)day; az = (float)daz;
-  ex = (float)((double)q.x - dax); ey = (float)((double)q.y - day); ez = (float)((double)q.z - daz);
+  dex = (double)q.x - dax; dey = (double)q.y - day; dez = (double)q.z - daz;
+  ex = (float)dex; ey = (float)dey; ez = (float)dez;
 }
 
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const float4* __restrict__ scov,
@@ -123,7 +133,15 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
     const float4 p = spts[so + i];
     const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
     Nearest1 nn{g.orig, INFINITY, -1};
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, max_corr_d2, nn);
+    // the previous iteration's correspondent is a real candidate: its distance bounds the search from the start
+    // (pure pruning — the result is still the exact nearest neighbour)
+    const int jprev = corr[so + i];
+    if (jprev >= 0 && jprev < g.m.n) {
+      const float4 pp = g.pts[jprev];
+      nn.best_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
+      nn.best_j = jprev;
+    }
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, max_corr_d2, nn, 0, 2);
     const int j = (nn.best_j >= 0 && nn.best_d2 < max_corr_d2) ? nn.best_j : -1;
     corr[so + i] = j;
     if (j < 0) continue;
@@ -135,7 +153,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
     mahal[2 * (so + i)] = make_float4(M.xx, M.xy, M.xz, M.yy);
     mahal[2 * (so + i) + 1] = make_float4(M.yz, M.zz, 0.f, 0.f);
     float ax, ay, az, ex, ey, ez;
-    residual(x0, p, g.pts[j], ax, ay, az, ex, ey, ez);
+    double dex, dey, dez;
+    residual(x0, p, g.pts[j], ax, ay, az, ex, ey, ez, dex, dey, dez);
     const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
     const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
     const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
     acc[22] += (double)(ax * Me2 - az * Me0);
     acc[23] += (double)(ay * Me0 - ax * Me1);
     acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
-    acc[27] += (double)(ex * Me0 + ey * Me1 + ez * Me2);
+    acc[27] += cost64(dex, dey, dez, M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
     acc[28] += 1.0;
   }
   block_sum<kNAcc, 4>(acc, smem);
@@ -253,11 +272,9 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
 
 __device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const float4& ma, const float4& mb) {
   float ax, ay, az, ex, ey, ez;
-  residual(x, p, q, ax, ay, az, ex, ey, ez);
-  const float Me0 = ma.x * ex + ma.y * ey + ma.z * ez;
-  const float Me1 = ma.y * ex + ma.w * ey + mb.x * ez;
-  const float Me2 = ma.z * ex + mb.x * ey + mb.y * ez;
-  return (double)(ex * Me0 + ey * Me1 + ez * Me2);
+  double dex, dey, dez;
+  residual(x, p, q, ax, ay, az, ex, ey, ez, dex, dey, dez);
+  return cost64(dex, dey, dez, ma.x, ma.y, ma.z, ma.w, mb.x, mb.y);
 }
 
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
@@ -419,6 +436,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     MI_HIP(hipMemcpyAsync(gb.guesses.p, gb.h_guess.data(), (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   }
   hipLaunchKernelGGL(k_gicp_init, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, (const float*)gb.guesses.p, S, guesses_host ? 1 : 0);
+  MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, (size_t)S * gb.cap * sizeof(int), s));  // no previous correspondences yet
   const GicpDevParams P = dev_params(p);
   const int G = gb.blocks_per_pair;
   gb.ev_used = 0;
@@ -470,7 +488,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_fitness(const float4* __restrict
     const float4 p = spts[so + i];
     const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
     Nearest1 nn{g.orig, INFINITY, -1};
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, search_d2, nn);
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, search_d2, nn, 0, 2);
     if (nn.best_j >= 0 && (double)nn.best_d2 <= max_range) { acc[0] += (double)nn.best_d2; acc[1] += 1.0; }
   }
   block_sum<2, 4>(acc, smem);
@@ -555,6 +573,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
     x.t[r] = T16[4 * r + 3];
   }
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, s, gb.state.p, x);
+  MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, gb.cap * sizeof(int), s));
   GicpDevParams P = dev_params(p);
   P.optimizer = MI355_OPT_LM;
   const bool tk = gb.time_kernels;

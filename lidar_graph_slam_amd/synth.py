@@ -119,8 +119,10 @@ def sensor_dirs(n_rings: int = 64, n_azimuth: int = 1024) -> np.ndarray:
 
 
 def cast_scan(scene: Scene, T_world_sensor: np.ndarray, *, n_rings: int = 64, n_azimuth: int = 1024,
-              noise_sigma: float = 0.02, seed: int = 1) -> np.ndarray:
-    """One scan in the SENSOR frame, float32 [n_rings*n_azimuth, 4]."""
+              noise_sigma: float = 0.02, seed: int = 1, jitter_sigma: float = 0.002) -> np.ndarray:
+    """One scan in the SENSOR frame, float32 [n_rings*n_azimuth, 4].  ``noise_sigma`` acts along the ray; ``jitter_sigma``
+    is a small isotropic 3-D jitter (beam divergence / angular encoder noise) so that the returns of one azimuth column
+    are not EXACTLY coplanar — exactly singular neighbourhoods make eigenvalue-sign tests implementation-defined."""
     T = np.asarray(T_world_sensor, dtype=np.float64)
     d_s = sensor_dirs(n_rings, n_azimuth)
     d_w = d_s @ T[:3, :3].T
@@ -130,6 +132,8 @@ def cast_scan(scene: Scene, T_world_sensor: np.ndarray, *, n_rings: int = 64, n_
         rng_ = np.where(rng_ >= MAX_RANGE, rng_, rng_ + rng.normal(0.0, noise_sigma, size=rng_.shape))
     no_return = rng_ >= MAX_RANGE
     pts = d_s * rng_[:, None]
+    if jitter_sigma > 0:
+        pts = pts + rng.normal(0.0, jitter_sigma, size=pts.shape)
     pts[no_return] = 0.0
     out = np.empty((pts.shape[0], 4), dtype=np.float32)
     out[:, :3] = pts.astype(np.float32)

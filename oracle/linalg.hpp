@@ -165,7 +165,10 @@ inline bool ldlt6_solve(const double* A_in, const double* rhs, double* x) {
     }
     D[k] = A[k * N + k];
     L[k * N + k] = 1.0;
-    if (D[k] == 0.0) return false;
+    if (D[k] == 0.0) {  // singular (e.g. no correspondences): Eigen's LDLT::solve returns the zero vector here
+      for (int i = 0; i < N; i++) x[i] = 0.0;
+      return false;
+    }
     for (int i = k + 1; i < N; i++) L[i * N + k] = A[i * N + k] / D[k];
     for (int i = k + 1; i < N; i++)
       for (int j = k + 1; j < N; j++) A[i * N + j] -= L[i * N + k] * D[k] * L[j * N + k];

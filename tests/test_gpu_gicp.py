@@ -119,8 +119,12 @@ def test_no_correspondences_and_errors(R, small_pair):
 
     s, t, _ = small_pair
     reg = _reg(R, s, t, max_iterations=3)
-    reg.align(synth.se3(0, 0, 60.0).astype(np.float32))  # nothing within 2 m: H = 0 -> LM cannot step
-    assert not reg.hasConverged()
+    far = synth.se3(0, 0, 60.0).astype(np.float32)
+    reg.align(far)  # nothing within 2 m: H = b = 0 -> zero step -> "converged" at the guess, exactly as upstream behaves
+    ref = O.gicp_align(s, t, O.gicp_params(max_iterations=3), guess=far)
+    assert reg.hasConverged() == ref["converged"]
+    np.testing.assert_array_equal(reg.getFinalTransformation(), ref["T"])
+    assert reg.result["n_inliers"] == 0
     reg2 = R.FastGICP()
     with pytest.raises(L.Mi355Error):
         reg2.setInputSource(s[:5])  # fewer points than k_correspondences
