@@ -58,7 +58,8 @@ typedef struct mi355_gicp_params {
   int optimizer;                      /* MI355_OPT_LM */
   int lm_max_iterations;              /* 10 */
   double lm_init_lambda_factor;       /* 1e-9 */
-  int force_iterations;               /* 1 = run exactly max_iterations (benchmark config: "20 GICP iters") */
+  int force_iterations;               /* 1 = benchmark config "20 GICP iters": run exactly max_iterations — neither the
+                                         convergence test nor an exhausted LM trial loop ends the optimisation */
   int num_threads;                    /* setNumThreads — accepted for interface parity, unused on the GPU */
 } mi355_gicp_params;
 

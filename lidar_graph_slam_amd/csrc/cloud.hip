@@ -193,11 +193,25 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   out.has_cov = false;
 }
 
+// Upper bound of the k-th NN distance of sorted point i: the farthest of the k points at sorted positions around i
+// (Morton order keeps them close; they are k distinct real points, the query itself included, so the bound is valid).
+__device__ __forceinline__ float morton_window_hint(const GridView& g, int i, const float4& q, int k) {
+  int lo = i - k / 2;
+  lo = max(0, min(lo, g.m.n - k));
+  float d2max = 0.f;
+  for (int j = lo; j < lo + k; j++) {
+    const float4 p = g.pts[j];
+    d2max = fmaxf(d2max, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+  }
+  return d2max;
+}
+
 // ---- k-NN covariances (F2) --------------------------------------------------------------------------------------
+// Step 1: exact k-NN of every point in its own cloud -> neighbour lists (sorted indices), k ints per point.
+// Kept apart from the covariance maths so that the divergent, latency-bound search runs at higher occupancy.
 template <int K>
-__global__ __launch_bounds__(256) void k_knn_cov(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
-                                                 const GridMeta* __restrict__ meta, float4* __restrict__ cov, size_t cap, size_t slots_cap, int k,
-                                                 int method) {
+__global__ __launch_bounds__(256, 3) void k_knn_self(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+                                                  const GridMeta* __restrict__ meta, int* __restrict__ nbr, size_t cap, size_t slots_cap, int k) {
   const int c = blockIdx.y;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,24 +220,38 @@ __global__ __launch_bounds__(256) void k_knn_cov(const float4* __restrict__ pts,
   NearestK<K> nk;
   nk.init(g.orig, k);
   grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k), 1);
-  // neighbours as fp64, mean-subtracted, cov = D D^T / k  (divide by k, not k-1)
-  double mx = 0, my = 0, mz = 0;
+  int* o = nbr + ((size_t)c * cap + i) * k;
 #pragma unroll
   for (int j = 0; j < K; j++)
-    if (j < k && nk.idx[j] >= 0) {
-      const float4 p = g.pts[nk.idx[j]];
-      mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
-    }
+    if (j < k) o[j] = nk.idx[j];
+}
+
+// Step 2: neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation, 2 x float4 per point.
+__global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, const int* __restrict__ nbr,
+                                                      float4* __restrict__ cov, size_t cap, int k, int method) {
+  const int c = blockIdx.y;
+  const int n = meta[c].n;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4* p0 = pts + (size_t)c * cap;
+  const int* nb = nbr + ((size_t)c * cap + i) * k;
+  double mx = 0, my = 0, mz = 0;
+  for (int j = 0; j < k; j++) {
+    const int t = nb[j];
+    if (t < 0) continue;
+    const float4 p = p0[t];
+    mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
+  }
   const double invk = 1.0 / (double)k;
   mx *= invk; my *= invk; mz *= invk;
   Sym3<double> cv = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < K; j++)
-    if (j < k && nk.idx[j] >= 0) {
-      const float4 p = g.pts[nk.idx[j]];
-      const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
-      cv.xx += x * x; cv.xy += x * y; cv.xz += x * z; cv.yy += y * y; cv.yz += y * z; cv.zz += z * z;
-    }
+  for (int j = 0; j < k; j++) {
+    const int t = nb[j];
+    if (t < 0) continue;
+    const float4 p = p0[t];
+    const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
+    cv.xx += x * x; cv.xy += x * y; cv.xz += x * z; cv.yy += y * y; cv.yz += y * z; cv.zz += z * z;
+  }
   cv.xx *= invk; cv.xy *= invk; cv.xz *= invk; cv.yy *= invk; cv.yz *= invk; cv.zz *= invk;
   const Sym3<double> r = regularize_covariance(cv, method);
   float4* o = cov + ((size_t)c * cap + i) * 2;
@@ -232,19 +260,22 @@ __global__ __launch_bounds__(256) void k_knn_cov(const float4* __restrict__ pts,
 }
 
 template <int K>
-static void launch_knn_cov(hipStream_t s, CloudSet& set, int k, int method) {
-  hipLaunchKernelGGL(k_knn_cov<K>, dim3(div_up((long)set.cap, 256), set.B), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p,
-                     set.cov.p, set.cap, set.slots_cap, k, method);
+static void launch_knn_self(hipStream_t s, CloudSet& set, int k) {
+  hipLaunchKernelGGL(k_knn_self<K>, dim3(div_up((long)set.cap, 256), set.B), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p,
+                     set.nbr.p, set.cap, set.slots_cap, k);
 }
 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k_correspondences must be in [1, 64]");
   set.cov.ensure((size_t)set.B * set.cap * 2);
-  if (k == 20) launch_knn_cov<20>(s, set, k, method);
-  else if (k <= 8) launch_knn_cov<8>(s, set, k, method);
-  else if (k <= 16) launch_knn_cov<16>(s, set, k, method);
-  else if (k <= 32) launch_knn_cov<32>(s, set, k, method);
-  else launch_knn_cov<64>(s, set, k, method);
+  set.nbr.ensure((size_t)set.B * set.cap * k);
+  if (k == 20) launch_knn_self<20>(s, set, k);
+  else if (k <= 8) launch_knn_self<8>(s, set, k);
+  else if (k <= 16) launch_knn_self<16>(s, set, k);
+  else if (k <= 32) launch_knn_self<32>(s, set, k);
+  else launch_knn_self<64>(s, set, k);
+  hipLaunchKernelGGL(k_cov_from_knn, dim3(div_up((long)set.cap, 256), set.B), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k,
+                     method);
   MI_LAUNCH_CHECK();
   set.has_cov = true;
 }

@@ -59,6 +59,7 @@ struct CloudSet {
   DevBuf<int> orig;
   DevBuf<int> count;
   DevBuf<float4> cov;
+  DevBuf<int> nbr;  // [B*cap*k] k-NN lists (sorted indices) between the search and the covariance kernels
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false;
@@ -101,6 +102,7 @@ struct GicpBatch {
   DevBuf<int> tgt_of_src;
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
   DevBuf<float4> mahal;      // [S*cap*2] Mahalanobis (6 floats + pad)
+  DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;
   DevBuf<int> n_active;
@@ -114,6 +116,10 @@ struct GicpBatch {
   std::vector<hipEvent_t> ev;
   int ev_used = 0;
   bool time_kernels = false;
+  int debug_flags = 0;      // MI355_DEBUG_FLAGS: timing ablations (never set in production)
+  int blocks_override = 0;  // MI355_BLOCKS_PER_PAIR
+  DevBuf<unsigned long long> stats;
+  int iter_counter = 0;
   double last_linearize_ms = 0;
   int last_linearize_launches = 0;
   ~GicpBatch();

@@ -41,15 +41,20 @@ GicpBatch::~GicpBatch() {
 }
 
 void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
+  if (const char* e = getenv("MI355_DEBUG_FLAGS")) gb.debug_flags = atoi(e);
+  if (const char* e = getenv("MI355_BLOCKS_PER_PAIR")) gb.blocks_override = atoi(e);
   gb.S = S;
   gb.cap = cap;
   const int cu = compute_units > 0 ? compute_units : 256;
   int G = (4 * cu + S - 1) / S;
+  if (gb.blocks_override > 0) G = gb.blocks_override;
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock)));
   gb.blocks_per_pair = G;
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
   gb.mahal.ensure((size_t)S * cap * 2);
+  gb.qsearch.ensure((size_t)S * cap);
+  gb.stats.ensure(64);
   gb.partials.ensure((size_t)S * G * kPartStride);
   gb.state.ensure(S);
   gb.n_active.ensure(1);
@@ -102,94 +107,200 @@ __device__ __forceinline__ void residual(const Pose& x, const float4& p, const f
   ex = (float)dex; ey = (float)dey; ez = (float)dez;
 }
 
-__global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const float4* __restrict__ scov,
-                                                               const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
-                                                               const int* __restrict__ torig, const float4* __restrict__ tcov,
-                                                               const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
+// Full (re-)search of one source point: exact nearest neighbour in the target + how far the query may move before the
+// answer can change.  Seeded with the previous correspondent when there is one.
+__device__ __forceinline__ void search_point(const GridView& g, float qx, float qy, float qz, int jprev, float max_corr_d2, int debug_flags,
+                                             int& j_out, float& margin_out) {
+  Nearest2 nn{g.orig, INFINITY, -1, INFINITY, INFINITY};
+  float explored2;
+  if (jprev >= 0 && jprev < g.m.n && !(debug_flags & 2)) {
+    const float4 pp = g.pts[jprev];
+    nn.d1 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
+    nn.j1 = jprev;
+  }
+  const float max_corr = sqrtf(max_corr_d2);
+  if (nn.j1 >= 0 && nn.d1 < 0.36f * g.m.cell * g.m.cell) {
+    // close seed: scan the ball a little larger than the seed distance (so that an isolated nearest neighbour still
+    // earns a non-zero margin) — a handful of base cells
+    const float r = sqrtf(nn.d1) * 1.25f + 0.02f;
+    nn.limit = r * r;
+    grid_ball_search(g, qx, qy, qz, nn, 2.1f);
+    explored2 = nn.limit;
+  } else {
+    // far or no seed: shell search with escalation.  The bound reaches a little past max_corr so that a point with
+    // nothing in range learns HOW far the nearest thing is and is not searched again at every iteration.
+    const float ext = max_corr + 0.25f * g.m.cell + 0.25f;
+    explored2 = grid_search(g, qx, qy, qz, isfinite(max_corr) ? ext * ext : INFINITY, nn, 0, 2);
+  }
+  float margin;
+  if (nn.j1 >= 0 && nn.d1 < max_corr_d2) {
+    j_out = nn.j1;
+    margin = 0.5f * (sqrtf(fminf(nn.d2nd, explored2)) - sqrtf(nn.d1));
+  } else {
+    // nothing within range: stays so until the query has moved by (distance to the nearest thing) - max_corr
+    j_out = -1;
+    margin = sqrtf(fminf(nn.j1 >= 0 ? nn.d1 : INFINITY, fmaxf(explored2, max_corr_d2))) - max_corr;
+  }
+  margin_out = margin * (1.f - 1e-4f) - 1e-5f;  // fp32 slack
+}
+
+constexpr int kLinPointsPerThread = 4;
+constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;  // points a block handles per pass
+
+// F3 update_correspondences, incremental and exact.
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __restrict__ spts,
+                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
+                                                                const int* __restrict__ torig,
+                                                                const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
-                                                               float4* __restrict__ mahal, double* __restrict__ partials, float max_corr_d2) {
-  __shared__ double smem[4 * kNAcc];
+                                                               float4* __restrict__ qsearch, float max_corr_d2, int debug_flags,
+                                                                unsigned long long* __restrict__ stats, int iter) {
+  __shared__ int queue[kLinTile];
+  __shared__ int qcount;
   const int pair = blockIdx.y;
   const GicpPairState* st = state + pair;
   if (!st->active) return;
   const int t = tgt_of_src[pair];
   const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
-  const float4* tc = tcov + (size_t)t * tcap * 2;
   const int n = scount[pair];
   const Pose x0 = st->x0;
-  float Tf[12], Rf[9];
+  float Tf[12];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) { Tf[4 * r + c] = (float)x0.R[3 * r + c]; Rf[3 * r + c] = Tf[4 * r + c]; }
+    for (int c = 0; c < 3; c++) Tf[4 * r + c] = (float)x0.R[3 * r + c];
     Tf[4 * r + 3] = (float)x0.t[r];
   }
+  const size_t so = (size_t)pair * scap;
+  for (int base = blockIdx.x * kLinTile; base < n; base += gridDim.x * kLinTile) {
+    // ---- phase 1: which points of this tile need a new nearest-neighbour search?  
+    // The last full search of a point left, at query position qs.xyz, a margin qs.w: while the query has moved less
+    // than that, its nearest neighbour provably cannot change (triangle inequality on the nearest / runner-up
+    // distances).  Points that do need a search are COMPACTED into an LDS queue so that the (divergent, latency-bound)
+    // search runs on dense waves instead of stalling every wave of the block behind a few lanes.
+    if (threadIdx.x == 0) qcount = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kLinPointsPerThread; u++) {
+      const int i = base + u * kGicpBlock + threadIdx.x;
+      if (i >= n) continue;
+      const float4 p = spts[so + i];
+      const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+      const float4 qs = qsearch[so + i];
+      const bool finite_q = isfinite(qx) && isfinite(qy) && isfinite(qz);
+      const float moved = sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z));
+      bool need_search = !(moved < qs.w) || (debug_flags & 4);  // NaN margin (never searched) -> search
+      if (!need_search) {
+        const int jprev = corr[so + i];
+        if (jprev >= 0) {
+          const float4 pp = g.pts[jprev];
+          need_search = !(dist2f(qx, qy, qz, pp.x, pp.y, pp.z) < max_corr_d2);  // drifted out of range: re-establish the state
+        }
+      }
+      if (!finite_q) {
+        corr[so + i] = -1;
+      } else if (need_search) {
+        queue[atomicAdd(&qcount, 1)] = i;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: dense search of the queued points
+    const int nq = qcount;
+    if ((debug_flags & 64) && threadIdx.x == 0) atomicAdd(&stats[iter], (unsigned long long)nq);
+    for (int tq = threadIdx.x; tq < nq; tq += kGicpBlock) {
+      const int i = queue[tq];
+      const float4 p = spts[so + i];
+      const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+      int j;
+      float margin;
+      search_point(g, qx, qy, qz, corr[so + i], max_corr_d2, debug_flags, j, margin);
+      corr[so + i] = j;
+      qsearch[so + i] = make_float4(qx, qy, qz, margin);
+    }
+    __syncthreads();  // correspondences written by other threads of this block are visible from here on
+  }
+}
+
+// F4 linearize given the correspondences: Mahalanobis + normal equations, a pure streaming pass — per source point it
+// reads src pt 16 + src cov 24(32) + tgt pt 16 + tgt cov 24(32) B (the 80 algorithmic bytes of SURVEY.md §8d) and the
+// 4-byte correspondence, writes the 24(32)-byte Mahalanobis matrix, and accumulates 21+6+1 terms in fp64 registers.
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const float4* __restrict__ scov,
+                                                               const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
+                                                               const float4* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
+                                                               const GicpPairState* __restrict__ state, const int* __restrict__ corr,
+                                                               float4* __restrict__ mahal, double* __restrict__ partials, int debug_flags) {
+  __shared__ double smem[4 * kNAcc];
+  const int pair = blockIdx.y;
+  const GicpPairState* st = state + pair;
+  if (!st->active) return;
+  const int t = tgt_of_src[pair];
+  const float4* tp = tpts + (size_t)t * tcap;
+  const float4* tc = tcov + (size_t)t * tcap * 2;
+  const int n = scount[pair];
+  const Pose x0 = st->x0;
+  float Rf[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rf[k] = (float)x0.R[k];
+  const size_t so = (size_t)pair * scap;
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
-  const size_t so = (size_t)pair * scap;
-  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
-    const float4 p = spts[so + i];
-    const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
-    Nearest1 nn{g.orig, INFINITY, -1};
-    // the previous iteration's correspondent is a real candidate: its distance bounds the search from the start
-    // (pure pruning — the result is still the exact nearest neighbour)
-    const int jprev = corr[so + i];
-    if (jprev >= 0 && jprev < g.m.n) {
-      const float4 pp = g.pts[jprev];
-      nn.best_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
-      nn.best_j = jprev;
+  for (int base = blockIdx.x * kLinTile; base < n; base += gridDim.x * kLinTile) {
+#pragma unroll
+    for (int u = 0; u < kLinPointsPerThread; u++) {
+      const int i = base + u * kGicpBlock + threadIdx.x;
+      if (i >= n) continue;
+      const int j = corr[so + i];
+      if (j < 0) continue;
+      if (debug_flags & 8) { acc[28] += 1.0; continue; }
+      const float4 p = spts[so + i];
+      const Sym3<float> CA = load_cov(scov, so + i);
+      const Sym3<float> CB = load_cov(tc, (size_t)j);
+      Sym3<float> RCR = sym3_rotate(Rf, CA);
+      RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
+      const Sym3<float> M = sym3_inverse(RCR);
+      mahal[2 * (so + i)] = make_float4(M.xx, M.xy, M.xz, M.yy);
+      mahal[2 * (so + i) + 1] = make_float4(M.yz, M.zz, 0.f, 0.f);
+      float ax, ay, az, ex, ey, ez;
+      double dex, dey, dez;
+      residual(x0, p, tp[j], ax, ay, az, ex, ey, ez, dex, dey, dez);
+      const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
+      const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
+      const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
+      // MS = M * skew(a)
+      const float m0[3] = {M.xx, M.xy, M.xz}, m1[3] = {M.xy, M.yy, M.yz}, m2[3] = {M.xz, M.yz, M.zz};
+      float MS[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const float* mr = (r == 0) ? m0 : ((r == 1) ? m1 : m2);
+        MS[r][0] = mr[1] * az - mr[2] * ay;
+        MS[r][1] = mr[2] * ax - mr[0] * az;
+        MS[r][2] = mr[0] * ay - mr[1] * ax;
+      }
+      // Hrr = skew(a)^T * MS  (symmetric)
+      acc[0] += (double)(az * MS[1][0] - ay * MS[2][0]);
+      acc[1] += (double)(az * MS[1][1] - ay * MS[2][1]);
+      acc[2] += (double)(az * MS[1][2] - ay * MS[2][2]);
+      acc[3] += (double)(ax * MS[2][1] - az * MS[0][1]);
+      acc[4] += (double)(ax * MS[2][2] - az * MS[0][2]);
+      acc[5] += (double)(ay * MS[0][2] - ax * MS[1][2]);
+      // Hrt[i][c] = -(MS)[c][i]
+#pragma unroll
+      for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[6 + 3 * i2 + c] -= (double)MS[c][i2];
+      // Htt = M
+      acc[15] += (double)M.xx; acc[16] += (double)M.xy; acc[17] += (double)M.xz;
+      acc[18] += (double)M.yy; acc[19] += (double)M.yz; acc[20] += (double)M.zz;
+      // b = J^T M e
+      acc[21] += (double)(az * Me1 - ay * Me2);
+      acc[22] += (double)(ax * Me2 - az * Me0);
+      acc[23] += (double)(ay * Me0 - ax * Me1);
+      acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
+      acc[27] += cost64(dex, dey, dez, M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
+      acc[28] += 1.0;
     }
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, max_corr_d2, nn, 0, 2);
-    const int j = (nn.best_j >= 0 && nn.best_d2 < max_corr_d2) ? nn.best_j : -1;
-    corr[so + i] = j;
-    if (j < 0) continue;
-    const Sym3<float> CA = load_cov(scov, so + i);
-    const Sym3<float> CB = load_cov(tc, (size_t)j);
-    Sym3<float> RCR = sym3_rotate(Rf, CA);
-    RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
-    const Sym3<float> M = sym3_inverse(RCR);
-    mahal[2 * (so + i)] = make_float4(M.xx, M.xy, M.xz, M.yy);
-    mahal[2 * (so + i) + 1] = make_float4(M.yz, M.zz, 0.f, 0.f);
-    float ax, ay, az, ex, ey, ez;
-    double dex, dey, dez;
-    residual(x0, p, g.pts[j], ax, ay, az, ex, ey, ez, dex, dey, dez);
-    const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
-    const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
-    const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
-    // MS = M * skew(a)
-    const float m0[3] = {M.xx, M.xy, M.xz}, m1[3] = {M.xy, M.yy, M.yz}, m2[3] = {M.xz, M.yz, M.zz};
-    float MS[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const float* mr = (r == 0) ? m0 : ((r == 1) ? m1 : m2);
-      MS[r][0] = mr[1] * az - mr[2] * ay;
-      MS[r][1] = mr[2] * ax - mr[0] * az;
-      MS[r][2] = mr[0] * ay - mr[1] * ax;
-    }
-    // Hrr = skew(a)^T * MS  (symmetric)
-    acc[0] += (double)(az * MS[1][0] - ay * MS[2][0]);
-    acc[1] += (double)(az * MS[1][1] - ay * MS[2][1]);
-    acc[2] += (double)(az * MS[1][2] - ay * MS[2][2]);
-    acc[3] += (double)(ax * MS[2][1] - az * MS[0][1]);
-    acc[4] += (double)(ax * MS[2][2] - az * MS[0][2]);
-    acc[5] += (double)(ay * MS[0][2] - ax * MS[1][2]);
-    // Hrt[i][c] = -(MS)[c][i]
-#pragma unroll
-    for (int i2 = 0; i2 < 3; i2++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) acc[6 + 3 * i2 + c] -= (double)MS[c][i2];
-    // Htt = M
-    acc[15] += (double)M.xx; acc[16] += (double)M.xy; acc[17] += (double)M.xz;
-    acc[18] += (double)M.yy; acc[19] += (double)M.yz; acc[20] += (double)M.zz;
-    // b = J^T M e
-    acc[21] += (double)(az * Me1 - ay * Me2);
-    acc[22] += (double)(ax * Me2 - az * Me0);
-    acc[23] += (double)(ay * Me0 - ax * Me1);
-    acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
-    acc[27] += cost64(dex, dey, dez, M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
-    acc[28] += 1.0;
   }
   block_sum<kNAcc, 4>(acc, smem);
   if (threadIdx.x == 0) {
@@ -223,7 +334,11 @@ __device__ __forceinline__ void lm_trial(GicpPairState& s) {
 __device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParams& P, bool ok) {
   s.iter += 1;
   s.need_error = 0;
-  if (!ok) { s.lm_failed = 1; s.active = 0; return; }  // "lm not converged!!" -> break
+  if (!ok) {  // "lm not converged!!" -> break (benchmark mode keeps iterating: fixed work per pair)
+    s.lm_failed = 1;
+    if (!P.force_iterations || s.iter >= P.max_iterations) s.active = 0;
+    return;
+  }
   const bool conv = is_converged(s.delta, P.rotation_epsilon, P.transformation_epsilon);
   s.converged = conv ? 1 : 0;
   if ((conv && !P.force_iterations) || s.iter >= P.max_iterations) s.active = 0;
@@ -299,12 +414,13 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
   if (threadIdx.x == 0) partials[((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + 30] = acc[0];
 }
 
-__global__ __launch_bounds__(kGicpBlock) void k_gicp_decide(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
+constexpr int kDecideBlock = 1024;
+__global__ __launch_bounds__(kDecideBlock) void k_gicp_decide(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
                                                             const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
                                                             GicpPairState* __restrict__ state, const int* __restrict__ corr,
                                                             const float4* __restrict__ mahal, const double* __restrict__ partials, int G,
                                                             GicpDevParams P) {
-  __shared__ double smem[4];
+  __shared__ double smem[16];
   __shared__ GicpPairState s;
   __shared__ int again;
   const int pair = blockIdx.x;
@@ -353,12 +469,12 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_decide(const float4* __rest
     // rejected trial: evaluate compute_error at the new trial pose inside this block (rare path)
     const Pose xi = s.xi;
     double acc[1] = {0.0};
-    for (int i = threadIdx.x; i < n; i += kGicpBlock) {
+    for (int i = threadIdx.x; i < n; i += kDecideBlock) {
       const int j = corr[so + i];
       if (j < 0) continue;
       acc[0] += point_error(xi, spts[so + i], tp[j], mahal[2 * (so + i)], mahal[2 * (so + i) + 1]);
     }
-    block_sum<1, 4>(acc, smem);
+    block_sum<1, 16>(acc, smem);
     if (threadIdx.x == 0) s.yi = acc[0];
     __syncthreads();
   }
@@ -391,6 +507,9 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
 }
 
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P) {
+  hipLaunchKernelGGL(k_gicp_correspond, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
+                     tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
+                     gb.debug_flags, gb.stats.p, gb.iter_counter++ % 64);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (gb.time_kernels) {
     while ((int)gb.ev.size() < gb.ev_used + 2) {
@@ -404,8 +523,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     MI_HIP(hipEventRecord(e0, s));
   }
   hipLaunchKernelGGL(k_gicp_linearize, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap, tgt.pts.p,
-                     tgt.orig.p, tgt.cov.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p,
-                     gb.partials.p, P.max_corr_d2);
+                     tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.debug_flags);
   if (gb.time_kernels) MI_HIP(hipEventRecord(e1, s));
 }
 
@@ -436,9 +554,12 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     MI_HIP(hipMemcpyAsync(gb.guesses.p, gb.h_guess.data(), (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   }
   hipLaunchKernelGGL(k_gicp_init, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, (const float*)gb.guesses.p, S, guesses_host ? 1 : 0);
-  MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, (size_t)S * gb.cap * sizeof(int), s));  // no previous correspondences yet
+  MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, (size_t)S * gb.cap * sizeof(int), s));        // no previous correspondences yet
+  MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, (size_t)S * gb.cap * sizeof(float4), s));  // NaN margins: first pass searches
   const GicpDevParams P = dev_params(p);
   const int G = gb.blocks_per_pair;
+  gb.iter_counter = 0;
+  MI_HIP(hipMemsetAsync(gb.stats.p, 0, 64 * sizeof(unsigned long long), s));
   gb.ev_used = 0;
   const int check_every = p.force_iterations ? 0 : 4;
   for (int it = 0; it < p.max_iterations; it++) {
@@ -447,7 +568,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     if (p.optimizer == MI355_OPT_LM) {
       hipLaunchKernelGGL(k_gicp_error, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
                          gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p);
-      hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
+      hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(kDecideBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
                          gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, G, P);
     }
     if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
@@ -537,6 +658,13 @@ void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
     MI_HIP(hipMemcpyAsync(fit.data(), gb.fitness.p, fit.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   MI_HIP(hipStreamSynchronize(s));
+  if (gb.debug_flags & 64) {
+    unsigned long long st64[64];
+    MI_HIP(hipMemcpy(st64, gb.stats.p, sizeof(st64), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[mi355] searched points per iteration:");
+    for (int i = 0; i < 24; i++) fprintf(stderr, " %llu", st64[i]);
+    fprintf(stderr, "\n");
+  }
   if (gb.time_kernels) gicp_finish_timing(gb);
   for (int p = 0; p < S; p++) {
     mi355_result& r = out[p];
@@ -574,6 +702,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   }
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, s, gb.state.p, x);
   MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, gb.cap * sizeof(int), s));
+  MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
   GicpDevParams P = dev_params(p);
   P.optimizer = MI355_OPT_LM;
   const bool tk = gb.time_kernels;

@@ -69,17 +69,38 @@ __device__ __forceinline__ int own_cell_count(const GridView& g, int bx, int by,
   return e - s;
 }
 
+// Scan the points of one cell range, two loads in flight.
+template <typename Visitor>
+__device__ __forceinline__ void scan_range(const GridView& g, int s, int e, float qx, float qy, float qz, Visitor& vis) {
+  int j = s;
+  if (Visitor::kScanWidth >= 2)
+  for (; j + 1 < e; j += 2) {
+    const float4 p0 = g.pts[j], p1 = g.pts[j + 1];
+    vis.visit(j, dist2f(qx, qy, qz, p0.x, p0.y, p0.z));
+    vis.visit(j + 1, dist2f(qx, qy, qz, p1.x, p1.y, p1.z));
+  }
+  for (; j < e; j++) {
+    const float4 p0 = g.pts[j];
+    vis.visit(j, dist2f(qx, qy, qz, p0.x, p0.y, p0.z));
+  }
+}
+
 // Visitor interface:
 //   float bound()            pruning squared distance: nothing farther can enter the result
 //   float complete()         k-th best squared distance of the CURRENT scan (+inf while the list is not full)
 //   void  visit(j, d2)       candidate (sorted index j)
 //   void  restart()          called when the search escalates to a coarser level (the scan starts over)
 // max_d2: nothing at or beyond this squared distance is wanted.  level0: level to start at; level_step: levels to
-// climb per escalation.
+// climb per escalation.  Returns the squared radius inside which EVERY point has been seen (or pruned as unable to
+// improve the result).
+//
+// SIMT shape: for the shells r <= 1 every lane first builds a 27-bit mask of the neighbour cells that can still matter
+// (pure ALU), then walks only its own set bits — a wave iterates max-popcount times instead of 27, and no lane drags the
+// others through cells only it needs.
 template <typename Visitor>
-__device__ __forceinline__ void grid_search(const GridView& g, float qx, float qy, float qz, float max_d2, Visitor& vis, int level0, int level_step) {
+__device__ __forceinline__ float grid_search(const GridView& g, float qx, float qy, float qz, float max_d2, Visitor& vis, int level0, int level_step) {
   const GridMeta& m = g.m;
-  if (m.n <= 0) return;
+  if (m.n <= 0) return INFINITY;
   const float bx = cell_coord(qx, m.ox, m.inv_cell), by = cell_coord(qy, m.oy, m.inv_cell), bz = cell_coord(qz, m.oz, m.inv_cell);
   const float margin = 1.0e-3f;  // in cell units: covers the fp32 fuzz of the cell lattice
   int l = min(level0, m.top_level);
@@ -98,57 +119,143 @@ __device__ __forceinline__ void grid_search(const GridView& g, float qx, float q
     const int rmax = max(max(max(cx, dx - 1 - cx), max(cy, dy - 1 - cy)), max(cz, dz - 1 - cz));
     // a query farther outside the grid than max_d2 has nothing to find
     if (r0 >= 1) {
-      const float gap = ((float)(r0 - 1) + 0.f) * cell;
-      if (gap * gap >= max_d2) return;
+      const float gap = (float)(r0 - 1) * cell;
+      if (gap * gap >= max_d2) return gap * gap;
     }
-    const int rlast = top ? rmax : min(rmax, 1);
+    float explored2 = 0.f;
     bool done = false;
-    for (int r = r0; r <= rlast; r++) {
-      const int z0 = max(cz - r, 0), z1 = min(cz + r, dz - 1);
-      const int y0 = max(cy - r, 0), y1 = min(cy + r, dy - 1);
-      for (int iz = z0; iz <= z1; iz++) {
-        const float gz = (iz > cz) ? ((float)iz - tz) : ((iz < cz) ? (tz - (float)(iz + 1)) : 0.f);
-        const bool zface = (iz - cz == r) || (cz - iz == r);
-        const uint32_t mz = morton_expand9((uint32_t)iz) << 2;
-        for (int iy = y0; iy <= y1; iy++) {
-          const float gy = (iy > cy) ? ((float)iy - ty) : ((iy < cy) ? (ty - (float)(iy + 1)) : 0.f);
-          const bool face = zface || (iy - cy == r) || (cy - iy == r);
-          const float gyz2 = gy * gy + gz * gz;
-          const uint32_t myz = mz | (morton_expand9((uint32_t)iy) << 1);
-          const int xa = cx - r, xb = cx + r;
-          // on a face row visit the whole x range, otherwise only the two x end caps
-          const int step = face ? 1 : max(2 * r, 1);
-          for (int ix = xa; ix <= xb; ix += step) {
-            if (ix < 0 || ix >= dx) continue;
-            const float gx = (ix > cx) ? ((float)ix - tx) : ((ix < cx) ? (tx - (float)(ix + 1)) : 0.f);
-            // lower bound (metres) of the distance from the query to anything inside this cell
-            const float lb = (sqrtf(gx * gx + gyz2) - margin) * cell;
-            if (lb > 0.f && lb * lb > fminf(vis.bound(), max_d2)) continue;
-            const uint32_t key = ((uint32_t)l << 27) | myz | morton_expand9((uint32_t)ix);
-            int s, e;
-            if (!cell_range(g, key, s, e)) continue;
-            for (int j = s; j < e; j++) {
-              const float4 p = g.pts[j];
-              vis.visit(j, dist2f(qx, qy, qz, p.x, p.y, p.z));
+    if (r0 <= 1) {
+      // ---- shell 0: the query's own cell
+      if (r0 == 0) {
+        int s, e;
+        if (cell_range(g, ((uint32_t)l << 27) | morton27((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), s, e)) scan_range(g, s, e, qx, qy, qz, vis);
+        const float gr = (minfrac - margin) * cell;
+        if (gr > 0.f) {
+          explored2 = gr * gr;
+          if (vis.complete() < explored2 || explored2 >= max_d2) done = true;
+        }
+      }
+      // ---- shell 1: mask of the 26 neighbours that can still hold something useful
+      if (!done && rmax >= 1) {
+        const float gxs[3] = {fx, 0.f, 1.f - fx}, gys[3] = {fy, 0.f, 1.f - fy}, gzs[3] = {fz, 0.f, 1.f - fz};
+        const float b_units = fminf(vis.bound(), max_d2) / (cell * cell);
+        uint32_t mask = 0;
+#pragma unroll
+        for (int c = 0; c < 27; c++) {
+          if (c == 13) continue;
+          const int a0 = c % 3, a1 = (c / 3) % 3, a2 = c / 9;
+          const int ix = cx + a0 - 1, iy = cy + a1 - 1, iz = cz + a2 - 1;
+          const float lbu = fmaxf(sqrtf(gxs[a0] * gxs[a0] + gys[a1] * gys[a1] + gzs[a2] * gzs[a2]) - margin, 0.f);
+          const bool ok = ix >= 0 && ix < dx && iy >= 0 && iy < dy && iz >= 0 && iz < dz && !(lbu * lbu > b_units);
+          mask |= ok ? (1u << c) : 0u;
+        }
+        while (mask) {
+          const int c = __ffs(mask) - 1;
+          mask &= mask - 1;
+          const int a0 = c % 3, a1 = (c / 3) % 3, a2 = c / 9;
+          const float gx = (a0 == 0) ? fx : ((a0 == 2) ? 1.f - fx : 0.f);
+          const float gy = (a1 == 0) ? fy : ((a1 == 2) ? 1.f - fy : 0.f);
+          const float gz = (a2 == 0) ? fz : ((a2 == 2) ? 1.f - fz : 0.f);
+          const float lb = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - margin, 0.f) * cell;
+          if (lb * lb > fminf(vis.bound(), max_d2)) continue;  // the bound shrank since the mask was built
+          int s, e;
+          if (cell_range(g, ((uint32_t)l << 27) | morton27((uint32_t)(cx + a0 - 1), (uint32_t)(cy + a1 - 1), (uint32_t)(cz + a2 - 1)), s, e))
+            scan_range(g, s, e, qx, qy, qz, vis);
+        }
+        const float gr = (1.f + minfrac - margin) * cell;
+        explored2 = gr * gr;
+        if (vis.complete() < explored2 || explored2 >= max_d2) done = true;
+      }
+      if (!done && rmax <= 1 && top) return INFINITY;  // the whole grid fits in these shells
+    }
+    if (done) return explored2;
+    if (top) {
+      // ---- shells r >= 2 (or a query outside the grid): generic walk, top level only
+      for (int r = max(r0, 2); r <= rmax; r++) {
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, dz - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, dy - 1);
+        for (int iz = z0; iz <= z1; iz++) {
+          const float gz = (iz > cz) ? ((float)iz - tz) : ((iz < cz) ? (tz - (float)(iz + 1)) : 0.f);
+          const bool zface = (iz - cz == r) || (cz - iz == r);
+          const uint32_t mz = morton_expand9((uint32_t)iz) << 2;
+          for (int iy = y0; iy <= y1; iy++) {
+            const float gy = (iy > cy) ? ((float)iy - ty) : ((iy < cy) ? (ty - (float)(iy + 1)) : 0.f);
+            const bool face = zface || (iy - cy == r) || (cy - iy == r);
+            const float gyz2 = gy * gy + gz * gz;
+            const uint32_t myz = mz | (morton_expand9((uint32_t)iy) << 1);
+            const int xa = cx - r, xb = cx + r;
+            const int step = face ? 1 : 2 * r;  // face row: whole x range; otherwise the two x end caps
+            for (int ix = xa; ix <= xb; ix += step) {
+              if (ix < 0 || ix >= dx) continue;
+              const float gx = (ix > cx) ? ((float)ix - tx) : ((ix < cx) ? (tx - (float)(ix + 1)) : 0.f);
+              const float lb = fmaxf(sqrtf(gx * gx + gyz2) - margin, 0.f) * cell;
+              if (lb * lb > fminf(vis.bound(), max_d2)) continue;
+              int s, e;
+              if (cell_range(g, ((uint32_t)l << 27) | myz | morton_expand9((uint32_t)ix), s, e)) scan_range(g, s, e, qx, qy, qz, vis);
             }
           }
         }
+        const float gr = ((float)r + minfrac - margin) * cell;
+        explored2 = gr * gr;
+        if (vis.complete() < explored2 || explored2 >= max_d2) return explored2;
       }
-      // every point closer than gr has now been seen
-      const float gr = ((float)r + minfrac - margin) * cell;
-      if (gr > 0.f) {
-        const float gr2 = gr * gr;
-        if (vis.complete() < gr2 || gr2 >= max_d2) { done = true; break; }
-      }
+      return INFINITY;  // the whole grid has been scanned
     }
-    if (done || top) return;  // top level: the whole grid has been scanned when the shells run out
     l = min(l + level_step, m.top_level);
     vis.restart();
   }
 }
 
+// Ball query: the visitor already holds a finite bound (squared radius) — from the previous iteration's correspondent,
+// or from k real points near the query — so every point that can still improve the result lies inside the ball
+// B(q, sqrt(bound)).  One pass over the cells that intersect that ball, at the level whose cell edge is about
+// `cells_per_radius` radii: no shells, no escalation, and all lanes of a wave walk a box of similar (small) size.
+// The result is exact for the same reason the kd-tree's is: nothing outside the ball can beat the bound, and the bound
+// only shrinks while scanning.  Ties on the ball surface are visited (closed ball, lower caller index wins).
+template <typename Visitor>
+__device__ __forceinline__ void grid_ball_search(const GridView& g, float qx, float qy, float qz, Visitor& vis, float cells_per_radius) {
+  const GridMeta& m = g.m;
+  if (m.n <= 0) return;
+  const float radius = sqrtf(vis.bound());
+  const float rel = radius * m.inv_cell * cells_per_radius;  // wanted cell edge, in base cells
+  const int l = (rel <= 1.f) ? 0 : min(m.top_level, (int)ceilf(log2f(rel)));
+  const float scale = 1.0f / (float)(1 << l);
+  const float cell = m.cell * (float)(1 << l);
+  const float margin = 1.0e-3f;
+  const float tx = cell_coord(qx, m.ox, m.inv_cell) * scale, ty = cell_coord(qy, m.oy, m.inv_cell) * scale, tz = cell_coord(qz, m.oz, m.inv_cell) * scale;
+  const float rr = radius / cell + margin;
+  const int dx = ((m.dx - 1) >> l) + 1, dy = ((m.dy - 1) >> l) + 1, dz = ((m.dz - 1) >> l) + 1;
+  const int x0 = max((int)floorf(tx - rr), 0), x1 = min((int)floorf(tx + rr), dx - 1);
+  const int y0 = max((int)floorf(ty - rr), 0), y1 = min((int)floorf(ty + rr), dy - 1);
+  const int z0 = max((int)floorf(tz - rr), 0), z1 = min((int)floorf(tz + rr), dz - 1);
+  const int cx = (int)floorf(tx), cy = (int)floorf(ty), cz = (int)floorf(tz);
+  // own cell first: it fills the list / tightens the bound before the neighbours are tested
+  if (cx >= x0 && cx <= x1 && cy >= y0 && cy <= y1 && cz >= z0 && cz <= z1) {
+    int s, e;
+    if (cell_range(g, ((uint32_t)l << 27) | morton27((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), s, e)) scan_range(g, s, e, qx, qy, qz, vis);
+  }
+  for (int iz = z0; iz <= z1; iz++) {
+    const float gz = (iz > cz) ? ((float)iz - tz) : ((iz < cz) ? (tz - (float)(iz + 1)) : 0.f);
+    const uint32_t mz = morton_expand9((uint32_t)iz) << 2;
+    for (int iy = y0; iy <= y1; iy++) {
+      const float gy = (iy > cy) ? ((float)iy - ty) : ((iy < cy) ? (ty - (float)(iy + 1)) : 0.f);
+      const float gyz2 = gy * gy + gz * gz;
+      const uint32_t myz = mz | (morton_expand9((uint32_t)iy) << 1);
+      for (int ix = x0; ix <= x1; ix++) {
+        if (ix == cx && iy == cy && iz == cz) continue;
+        const float gx = (ix > cx) ? ((float)ix - tx) : ((ix < cx) ? (tx - (float)(ix + 1)) : 0.f);
+        const float lb = (sqrtf(gx * gx + gyz2) - margin) * cell;
+        if (lb > 0.f && lb * lb > vis.bound()) continue;
+        int s, e;
+        if (cell_range(g, ((uint32_t)l << 27) | myz | morton_expand9((uint32_t)ix), s, e)) scan_range(g, s, e, qx, qy, qz, vis);
+      }
+    }
+  }
+}
+
 // ---- visitors -----------------------------------------------------------------------------------------------------
 struct Nearest1 {
+  static constexpr int kScanWidth = 2;
   const int* orig;
   float best_d2;
   int best_j;
@@ -160,9 +267,34 @@ struct Nearest1 {
   }
 };
 
+// Nearest + distance of the runner-up: what the incremental correspondence update needs (gicp.hip).  The search
+// prunes with the runner-up distance, so both are exact inside the explored region; `limit` caps a ball query.
+struct Nearest2 {
+  static constexpr int kScanWidth = 2;
+  const int* orig;
+  float d1;
+  int j1;
+  float d2nd;
+  float limit;
+  __device__ __forceinline__ float bound() const { return fminf(d2nd, limit); }
+  __device__ __forceinline__ float complete() const { return d1; }
+  __device__ __forceinline__ void restart() {}
+  __device__ __forceinline__ void visit(int j, float dd) {
+    if (j == j1) return;  // a coarser level re-visits points
+    if (dd < d1 || (dd == d1 && j1 >= 0 && orig[j] < orig[j1]) || j1 < 0) {
+      if (j1 >= 0) d2nd = fminf(d2nd, d1);
+      d1 = dd;
+      j1 = j;
+    } else if (dd < d2nd) {
+      d2nd = dd;
+    }
+  }
+};
+
 // Sorted (ascending by (d2, caller index)) list of the K best, fully in registers.
 template <int K>
 struct NearestK {
+  static constexpr int kScanWidth = 1;  // the insertion is register-hungry: keep one candidate in flight
   const int* orig;
   int k;        // 1..K actually wanted
   float hint;   // k-th distance of the previous (finer) level: an upper bound of the true k-th distance
@@ -188,6 +320,8 @@ struct NearestK {
   }
   __device__ __forceinline__ float bound() const { return fminf(kth(), hint); }
   __device__ __forceinline__ float complete() const { return kth(); }
+  // squared distance to the farthest of k DISTINCT points of the cloud: an upper bound of the k-th NN distance
+  __device__ __forceinline__ void set_hint(float d2max) { hint = d2max; }
   __device__ __forceinline__ void restart() {
     hint = fminf(hint, kth());
     clear();

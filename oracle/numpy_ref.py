@@ -177,7 +177,7 @@ def gicp_align(src, tgt, *, k=20, max_iterations=64, transformation_epsilon=0.01
             lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
             accepted = True
             break
-        if not accepted:
+        if not accepted and not force_iterations:
             break
         converged = (not force_iterations) and is_conv(delta)
     return x0.astype(np.float32), converged, iters

@@ -42,7 +42,8 @@ typedef struct orc_gicp_params {
   int optimizer;                      /* fast_gicp default LevenbergMarquardt */
   int lm_max_iterations;              /* fast_gicp default 10 */
   double lm_init_lambda_factor;       /* fast_gicp default 1e-9 */
-  int force_iterations;               /* 0 = reference behaviour; 1 = never early-stop (benchmark config: exactly max_iterations) */
+  int force_iterations;               /* 0 = reference behaviour; 1 = benchmark config "exactly max_iterations": neither the
+                                         convergence test nor an exhausted LM trial loop ends the optimisation */
   int num_threads;                    /* setNumThreads (lidar_scan_matcher.cpp:52, yaml:10 -> 4); 0 = all */
 } orc_gicp_params;
 

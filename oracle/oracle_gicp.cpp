@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -357,6 +359,7 @@ extern "C" int orc_gicp_align(const float* src, size_t n, const float* tgt, size
         double denom = 0;
         for (int k = 0; k < 6; k++) denom += d[k] * (lm_lambda * d[k] - b[k]);
         const double rho = (y0 - yi) / denom;
+        if (getenv("ORC_DEBUG")) fprintf(stderr, "[orc] iter %d trial %d y0 %.9g yi %.9g rho %.4g lambda %.3g |d| %.3g\n", i, it, y0, yi, rho, lm_lambda, std::sqrt(d[0]*d[0]+d[1]*d[1]+d[2]*d[2]+d[3]*d[3]+d[4]*d[4]+d[5]*d[5]));
         if (rho < 0) {
           if (!p->force_iterations && is_converged(delta, p->rotation_epsilon, p->transformation_epsilon)) { ok = true; break; }
           lm_lambda = nu * lm_lambda;
@@ -371,7 +374,7 @@ extern "C" int orc_gicp_align(const float* src, size_t n, const float* tgt, size
         break;
       }
     }
-    if (!ok) break;  // "lm not converged!!"
+    if (!ok && !p->force_iterations) break;  // "lm not converged!!" (benchmark mode keeps iterating: fixed work per pair)
     converged = !p->force_iterations && is_converged(delta, p->rotation_epsilon, p->transformation_epsilon);
   }
   const auto t2 = clk::now();
