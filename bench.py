@@ -76,7 +76,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from lidar_graph_slam_amd import _lib as L
-    from lidar_graph_slam_amd import synth
+    from lidar_graph_slam_amd import sharding, synth
     from lidar_graph_slam_amd.context import Context
     from lidar_graph_slam_amd.registration import BatchRegistration
 
@@ -139,10 +139,7 @@ def main():
         lin_launches += nl
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed)  # MAX over ranks (RCCL all-reduce of one double)
 
     # ---- correctness of what was timed: pose error vs ground truth for every pair of this rank ------------------------
     errs = []

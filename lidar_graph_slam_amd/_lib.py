@@ -104,6 +104,40 @@ EXPORTS = [
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
     "mi355_batch_set_sources", "mi355_batch_align", "mi355_batch_results", "mi355_batch_kernel_time",
 ]
+# include/mi355_scan_matcher.h
+EXPORTS_SCAN_MATCHER = [
+    "mi355_scan_matcher_create", "mi355_scan_matcher_destroy", "mi355_scan_matcher_last_error", "mi355_scan_matcher_callback_cloud",
+    "mi355_scan_matcher_target",
+]
+
+
+class ScanMatcherParams(C.Structure):
+    _fields_ = [
+        ("registration_method", C.c_int),
+        ("displacement", C.c_double),
+        ("max_scan_accumulate_num", C.c_int),
+        ("max_iteration", C.c_int),
+        ("omp_num_thread", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("step_size", C.c_double),
+        ("ndt_resolution", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("correspondence_randomness", C.c_int),
+    ]
+
+
+class ScanOutput(C.Structure):
+    _fields_ = [
+        ("first_scan", C.c_int),
+        ("converged", C.c_int),
+        ("new_key_frame", C.c_int),
+        ("pose", C.c_float * 16),
+        ("key_frame_id", C.c_long),
+        ("target_points", C.c_size_t),
+        ("iterations", C.c_int),
+        ("n_key_frames", C.c_long),
+        ("accum_distance", C.c_double),
+    ]
 
 
 def lib():
@@ -155,6 +189,14 @@ def lib():
         L.mi355_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.mi355_scan_matcher_create.restype = C.c_void_p
+        L.mi355_scan_matcher_create.argtypes = [C.c_int, C.POINTER(ScanMatcherParams)]
+        L.mi355_scan_matcher_destroy.argtypes = [C.c_void_p]
+        L.mi355_scan_matcher_destroy.restype = None
+        L.mi355_scan_matcher_last_error.restype = C.c_char_p
+        L.mi355_scan_matcher_last_error.argtypes = [C.c_void_p]
+        L.mi355_scan_matcher_callback_cloud.argtypes = [C.c_void_p, PV, C.c_void_p, C.POINTER(ScanOutput)]
+        L.mi355_scan_matcher_target.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB = L
     return _LIB
 

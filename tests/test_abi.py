@@ -11,8 +11,8 @@ from lidar_graph_slam_amd import _lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "mi355_lidar.h")).read()
+def _header_symbols(name="mi355_lidar.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", text)))
 
@@ -24,6 +24,8 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(L.EXPORTS) == syms  # the Python binding lists exactly the header's entry points
+    sm = [s for s in _header_symbols("mi355_scan_matcher.h") if s.startswith("mi355_scan_matcher")]
+    assert sorted(L.EXPORTS_SCAN_MATCHER) == sm and all(hasattr(lib, s) for s in sm)
 
 
 def test_default_params_match_reference_yaml():

@@ -1,0 +1,76 @@
+"""The N > 1 path on CPU: two gloo ranks shard a loop-closure batch (pairs grouped by sub-map), "register" their shards
+(a deterministic stand-in result per pair — no GPU here) and all-gather the fixed-size results."""
+import os
+
+import numpy as np
+import pytest
+
+from lidar_graph_slam_amd import sharding
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 4096):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_shard_by_target_keeps_submaps_together():
+    rng = np.random.default_rng(0)
+    tgt = rng.integers(0, 64, 4096)
+    for world in (1, 2, 4, 8):
+        shards = sharding.shard_by_target(tgt, world)
+        allidx = np.concatenate(shards)
+        assert sorted(allidx.tolist()) == list(range(4096))
+        owners = {}
+        for r, idx in enumerate(shards):
+            for t in np.unique(tgt[idx]):
+                assert owners.setdefault(int(t), r) == r  # one rank per sub-map
+        sizes = [len(s) for s in shards]
+        assert max(sizes) - min(sizes) <= 0.15 * 4096 / world + 64
+
+
+def _worker(rank, world, port, n_pairs, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(1)
+        tgt = rng.integers(0, 5, n_pairs)
+        mine = sharding.shard_by_target(tgt, world)[rank]
+        T = np.zeros((len(mine), 4, 4), np.float32)
+        for k, p in enumerate(mine):  # stand-in for the GPU registration of pair p
+            T[k] = np.eye(4)
+            T[k, :3, 3] = (p, tgt[p], rank)
+        fit = mine.astype(np.float64) * 0.5
+        Tall, fall = sharding.gather_results(mine, T, fit, n_pairs)
+        tmax = sharding.max_over_ranks(1.0 + rank)
+        q.put((rank, Tall, fall, tmax, len(mine)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather():
+    import torch.multiprocessing as mp
+
+    world, n_pairs = 2, 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r[4] for r in results) == n_pairs
+    for rank, Tall, fall, tmax, _ in results:
+        assert tmax == 2.0
+        np.testing.assert_array_equal(Tall[:, 0, 3], np.arange(n_pairs))  # every pair present, in global order
+        np.testing.assert_allclose(fall, np.arange(n_pairs) * 0.5)
+    np.testing.assert_array_equal(results[0][1], results[1][1])  # all ranks hold the same gathered result
