@@ -1,0 +1,125 @@
+// PCL-typed adapter: lets the reference's nodes keep `pcl::Registration<PointType, PointType>::Ptr registration_`
+// (lidar_scan_matcher.hpp:99, graph_based_slam.hpp:108) and swap only the three `new ...` expressions
+// (lidar_scan_matcher.cpp:38-39,56-57; graph_based_slam.cpp:84-85,103-104).  Header-only, pure forwarding to the C-ABI.
+//
+// NOT compiled in this repository: PCL, Eigen and ROS 2 are absent from the build image.  It is the
+// binding a maintainer adds on a machine that has them — see INTEGRATION.md.  Kept under 150 lines on purpose.
+#pragma once
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include <pcl/registration/registration.h>
+
+#include <stdexcept>
+
+#include "mi355_lidar.h"
+
+namespace mi355_pcl {
+
+namespace detail {
+inline mi355_cloud_view view(const pcl::PointCloud<pcl::PointXYZI>& c) {
+  // pcl::PointXYZI: float data[4] at +0, intensity at +16, sizeof == 32
+  return mi355_cloud_view{c.points.data(), c.points.size(), sizeof(pcl::PointXYZI), offsetof(pcl::PointXYZI, intensity)};
+}
+inline void check(mi355_ctx* ctx, int rc) {
+  if (rc != MI355_OK) throw std::runtime_error(mi355_last_error(ctx));
+}
+}  // namespace detail
+
+template <int METHOD, typename Params>
+class RegistrationBase : public pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float> {
+ public:
+  using Base = pcl::Registration<pcl::PointXYZI, pcl::PointXYZI, float>;
+  using PointCloudSource = typename Base::PointCloudSource;
+  using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
+  using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
+  using Matrix4 = typename Base::Matrix4;
+
+  explicit RegistrationBase(int device_id = 0) : ctx_(mi355_create(device_id)) {
+    if (!ctx_) throw std::runtime_error("mi355_create failed: no HIP device");
+    reg_ = mi355_reg_create(ctx_, METHOD, nullptr);
+  }
+  ~RegistrationBase() override {
+    mi355_reg_destroy(reg_);
+    mi355_destroy(ctx_);
+  }
+
+  // The node clears and refills the SAME cloud object and passes the same pointer again (lidar_scan_matcher.cpp:187-212):
+  // always rebuild, never short-circuit on pointer identity.
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
+    Base::setInputTarget(cloud);
+    push();
+    const mi355_cloud_view v = detail::view(*cloud);
+    detail::check(ctx_, mi355_reg_set_target(reg_, &v));
+  }
+  void setInputSource(const PointCloudSourceConstPtr& cloud) override {
+    Base::setInputSource(cloud);
+    push();
+    const mi355_cloud_view v = detail::view(*cloud);
+    detail::check(ctx_, mi355_reg_set_source(reg_, &v));
+  }
+  // pcl::Registration::getFitnessScore runs a CPU kd-tree; the device version is the same statistic
+  double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    double s = 0;
+    detail::check(ctx_, mi355_reg_fitness(reg_, max_range, &s));
+    return s;
+  }
+
+ protected:
+  void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {
+    push();
+    float g[16];
+    for (int r = 0; r < 4; r++)
+      for (int c = 0; c < 4; c++) g[4 * r + c] = guess(r, c);  // Eigen is column-major, the C-ABI row-major
+    mi355_result res;
+    std::vector<float> packed(4 * std::max<size_t>(this->input_->size(), 1));
+    detail::check(ctx_, mi355_reg_align(reg_, g, &res, packed.data()));
+    for (int r = 0; r < 4; r++)
+      for (int c = 0; c < 4; c++) this->final_transformation_(r, c) = res.T[4 * r + c];
+    this->converged_ = res.converged != 0;
+    this->nr_iterations_ = res.iterations;
+    output = *this->input_;
+    for (size_t i = 0; i < output.size(); i++) {
+      output[i].x = packed[4 * i]; output[i].y = packed[4 * i + 1]; output[i].z = packed[4 * i + 2];
+    }
+  }
+  void push() {
+    if (dirty_) {
+      detail::check(ctx_, mi355_reg_set_params(reg_, &p_));
+      dirty_ = false;
+    }
+  }
+  mi355_ctx* ctx_;
+  mi355_reg* reg_;
+  Params p_;
+  bool dirty_ = true;
+};
+
+// replaces `new fast_gicp::FastGICP<PointType, PointType>` (lidar_scan_matcher.cpp:38-39)
+class FastGICP : public RegistrationBase<MI355_METHOD_FAST_GICP, mi355_gicp_params> {
+ public:
+  using Ptr = pcl::shared_ptr<FastGICP>;
+  explicit FastGICP(int device_id = 0) : RegistrationBase(device_id) { mi355_gicp_default_params(&p_); reg_name_ = "mi355::FastGICP"; }
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; dirty_ = true; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; max_iterations_ = n; dirty_ = true; }
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; transformation_epsilon_ = e; dirty_ = true; }
+  void setMaxCorrespondenceDistance(double d) { p_.max_correspondence_distance = d; corr_dist_threshold_ = d; dirty_ = true; }
+  void setNumThreads(int n) { p_.num_threads = n; dirty_ = true; }
+};
+
+// replaces `new pclomp::NormalDistributionsTransform<PointType, PointType>` (lidar_scan_matcher.cpp:56-57)
+class NormalDistributionsTransform : public RegistrationBase<MI355_METHOD_NDT_OMP, mi355_ndt_params> {
+ public:
+  using Ptr = pcl::shared_ptr<NormalDistributionsTransform>;
+  explicit NormalDistributionsTransform(int device_id = 0) : RegistrationBase(device_id) { mi355_ndt_default_params(&p_); reg_name_ = "mi355::NDT"; }
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; transformation_epsilon_ = e; dirty_ = true; }
+  void setStepSize(double s) { p_.step_size = s; dirty_ = true; }
+  void setResolution(float r) { p_.resolution = r; dirty_ = true; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; max_iterations_ = n; dirty_ = true; }
+  template <typename T> void setNeighborhoodSearchMethod(T) {}  // DIRECT7 is the only mode (lidar_scan_matcher.cpp:69)
+  void setNumThreads(int n) { p_.num_threads = n; dirty_ = true; }
+  double getTransformationProbability() const { return trans_probability_; }
+ private:
+  double trans_probability_ = 0;
+};
+
+}  // namespace mi355_pcl

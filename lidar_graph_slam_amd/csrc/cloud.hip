@@ -211,10 +211,12 @@ __device__ __forceinline__ float morton_window_hint(const GridView& g, int i, co
 // Kept apart from the covariance maths so that the divergent, latency-bound search runs at higher occupancy.
 template <int K>
 __global__ __launch_bounds__(256, 3) void k_knn_self(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
-                                                  const GridMeta* __restrict__ meta, int* __restrict__ nbr, size_t cap, size_t slots_cap, int k) {
-  const int c = blockIdx.y;
+                                                  const GridMeta* __restrict__ meta, int* __restrict__ nbr, size_t cap, size_t slots_cap, int k, int G,
+                                                  int B) {
+  int c, bx;
+  if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bx * blockDim.x + threadIdx.x;
   if (i >= g.m.n) return;
   const float4 q = g.pts[i];
   NearestK<K> nk;
@@ -228,10 +230,11 @@ __global__ __launch_bounds__(256, 3) void k_knn_self(const float4* __restrict__ 
 
 // Step 2: neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation, 2 x float4 per point.
 __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, const int* __restrict__ nbr,
-                                                      float4* __restrict__ cov, size_t cap, int k, int method) {
-  const int c = blockIdx.y;
+                                                      float4* __restrict__ cov, size_t cap, int k, int method, int G, int B) {
+  int c, bx;
+  if (!xcd_item_chunk(G, B, c, bx)) return;
   const int n = meta[c].n;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bx * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4* p0 = pts + (size_t)c * cap;
   const int* nb = nbr + ((size_t)c * cap + i) * k;
@@ -261,8 +264,9 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
 
 template <int K>
 static void launch_knn_self(hipStream_t s, CloudSet& set, int k) {
-  hipLaunchKernelGGL(k_knn_self<K>, dim3(div_up((long)set.cap, 256), set.B), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p,
-                     set.nbr.p, set.cap, set.slots_cap, k);
+  const int G = div_up((long)set.cap, 256);
+  hipLaunchKernelGGL(k_knn_self<K>, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p, set.cap,
+                     set.slots_cap, k, G, set.B);
 }
 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
@@ -274,8 +278,9 @@ void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   else if (k <= 16) launch_knn_self<16>(s, set, k);
   else if (k <= 32) launch_knn_self<32>(s, set, k);
   else launch_knn_self<64>(s, set, k);
-  hipLaunchKernelGGL(k_cov_from_knn, dim3(div_up((long)set.cap, 256), set.B), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k,
-                     method);
+  const int Gc = div_up((long)set.cap, 256);
+  hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(Gc, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, Gc,
+                     set.B);
   MI_LAUNCH_CHECK();
   set.has_cov = true;
 }

@@ -98,7 +98,8 @@ struct GicpPairState;  // device-side LM state, one per source cloud
 struct GicpBatch {
   int S = 0;           // sources (= pairs)
   size_t cap = 0;
-  int blocks_per_pair = 0;
+  int blocks_per_pair = 0;   // k_gicp_correspond geometry
+  int blocks_lin = 0;        // streaming kernels geometry
   DevBuf<int> tgt_of_src;
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
   DevBuf<float4> mahal;      // [S*cap*2] Mahalanobis (6 floats + pad)
@@ -118,6 +119,7 @@ struct GicpBatch {
   bool time_kernels = false;
   int debug_flags = 0;      // MI355_DEBUG_FLAGS: timing ablations (never set in production)
   int blocks_override = 0;  // MI355_BLOCKS_PER_PAIR
+  int ppt = 1;              // points per thread and pass in correspond/linearize (MI355_PPT)
   DevBuf<unsigned long long> stats;
   int iter_counter = 0;
   double last_linearize_ms = 0;

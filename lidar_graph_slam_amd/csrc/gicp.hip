@@ -43,23 +43,29 @@ GicpBatch::~GicpBatch() {
 void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   if (const char* e = getenv("MI355_DEBUG_FLAGS")) gb.debug_flags = atoi(e);
   if (const char* e = getenv("MI355_BLOCKS_PER_PAIR")) gb.blocks_override = atoi(e);
+  if (const char* e = getenv("MI355_PPT")) gb.ppt = atoi(e) == 1 ? 1 : 4;
   gb.S = S;
   gb.cap = cap;
-  const int cu = compute_units > 0 ? compute_units : 256;
-  int G = (4 * cu + S - 1) / S;
+  // One pair is worked on by (up to) 64 blocks of 256 threads that all land on one XCD (primitives.hpp): enough waves to
+  // fill that XCD's 32 CUs while only ~2 pairs' working sets compete for its 4 MB L2.
+  (void)compute_units;
+  int G = 64;
   if (gb.blocks_override > 0) G = gb.blocks_override;
-  G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock)));
+  G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
+  // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
+  gb.blocks_lin = std::max(1, std::min(16, div_up((long)cap, kGicpBlock * 4)));
+  if (const char* e = getenv("MI355_BLOCKS_LIN")) gb.blocks_lin = std::max(1, atoi(e));
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
   gb.mahal.ensure((size_t)S * cap * 2);
   gb.qsearch.ensure((size_t)S * cap);
   gb.stats.ensure(64);
-  gb.partials.ensure((size_t)S * G * kPartStride);
+  gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
   gb.n_active.ensure(1);
   gb.h_active.ensure(1);
-  gb.fit_partials.ensure((size_t)S * G * 2);
+  gb.fit_partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * 2);
   gb.fitness.ensure((size_t)S * 2);
 }
 
@@ -144,10 +150,9 @@ __device__ __forceinline__ void search_point(const GridView& g, float qx, float 
   margin_out = margin * (1.f - 1e-4f) - 1e-5f;  // fp32 slack
 }
 
-constexpr int kLinPointsPerThread = 4;
-constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;  // points a block handles per pass
 
-// F3 update_correspondences, incremental and exact.
+// F3 update_correspondences, incremental and exact.  PPT = points per thread and pass (tile = 256 * PPT points).
+template <int kLinPointsPerThread>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __restrict__ spts,
                                                                 const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
                                                                 const int* __restrict__ torig,
@@ -155,10 +160,12 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                float4* __restrict__ qsearch, float max_corr_d2, int debug_flags,
-                                                                unsigned long long* __restrict__ stats, int iter) {
+                                                                unsigned long long* __restrict__ stats, int iter, int G, int S) {
+  constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ int queue[kLinTile];
   __shared__ int qcount;
-  const int pair = blockIdx.y;
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
   if (!st->active) return;
   const int t = tgt_of_src[pair];
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
     Tf[4 * r + 3] = (float)x0.t[r];
   }
   const size_t so = (size_t)pair * scap;
-  for (int base = blockIdx.x * kLinTile; base < n; base += gridDim.x * kLinTile) {
+  for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
     // ---- phase 1: which points of this tile need a new nearest-neighbour search?  
     // The last full search of a point left, at query position qs.xyz, a margin qs.w: while the query has moved less
     // than that, its nearest neighbour provably cannot change (triangle inequality on the nearest / runner-up
@@ -225,13 +232,17 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
 // F4 linearize given the correspondences: Mahalanobis + normal equations, a pure streaming pass — per source point it
 // reads src pt 16 + src cov 24(32) + tgt pt 16 + tgt cov 24(32) B (the 80 algorithmic bytes of SURVEY.md §8d) and the
 // 4-byte correspondence, writes the 24(32)-byte Mahalanobis matrix, and accumulates 21+6+1 terms in fp64 registers.
+template <int kLinPointsPerThread>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const float4* __restrict__ scov,
                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
                                                                const float4* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                               float4* __restrict__ mahal, double* __restrict__ partials, int debug_flags) {
+                                                               float4* __restrict__ mahal, double* __restrict__ partials, int debug_flags, int G,
+                                                               int S) {
+  constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ double smem[4 * kNAcc];
-  const int pair = blockIdx.y;
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
   if (!st->active) return;
   const int t = tgt_of_src[pair];
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
-  for (int base = blockIdx.x * kLinTile; base < n; base += gridDim.x * kLinTile) {
+  for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
   }
   block_sum<kNAcc, 4>(acc, smem);
   if (threadIdx.x == 0) {
-    double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride;
+    double* out = partials + ((size_t)pair * G + bx) * kPartStride;
 #pragma unroll
     for (int k = 0; k < kNAcc; k++) out[k] = acc[k];
   }
@@ -507,9 +518,11 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
 }
 
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P) {
-  hipLaunchKernelGGL(k_gicp_correspond, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
+  auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
+  auto kl = k_gicp_linearize<4>;
+  hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                      tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                     gb.debug_flags, gb.stats.p, gb.iter_counter++ % 64);
+                     gb.debug_flags, gb.stats.p, gb.iter_counter++ % 64, gb.blocks_per_pair, gb.S);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (gb.time_kernels) {
     while ((int)gb.ev.size() < gb.ev_used + 2) {
@@ -522,8 +535,9 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     gb.ev_used += 2;
     MI_HIP(hipEventRecord(e0, s));
   }
-  hipLaunchKernelGGL(k_gicp_linearize, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap, tgt.pts.p,
-                     tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.debug_flags);
+  hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
+                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.debug_flags,
+                     gb.blocks_lin, gb.S);
   if (gb.time_kernels) MI_HIP(hipEventRecord(e1, s));
 }
 
@@ -557,7 +571,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
   MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, (size_t)S * gb.cap * sizeof(int), s));        // no previous correspondences yet
   MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, (size_t)S * gb.cap * sizeof(float4), s));  // NaN margins: first pass searches
   const GicpDevParams P = dev_params(p);
-  const int G = gb.blocks_per_pair;
+  const int G = gb.blocks_lin;
   gb.iter_counter = 0;
   MI_HIP(hipMemsetAsync(gb.stats.p, 0, 64 * sizeof(unsigned long long), s));
   gb.ev_used = 0;
@@ -638,9 +652,9 @@ void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
     dTp = gb.fit_T.p;
   }
   const float search_d2 = (max_range >= 3.0e38) ? INFINITY : (float)(max_range * (1.0 + 1e-6)) + 1e-30f;
-  hipLaunchKernelGGL(k_fitness, dim3(gb.blocks_per_pair, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
+  hipLaunchKernelGGL(k_fitness, dim3(gb.blocks_lin, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                      tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, dTp, gb.fit_partials.p, search_d2, max_range);
-  hipLaunchKernelGGL(k_fitness_final, dim3(div_up(gb.S, 64)), dim3(64), 0, s, gb.fit_partials.p, gb.fitness.p, gb.S, gb.blocks_per_pair);
+  hipLaunchKernelGGL(k_fitness_final, dim3(div_up(gb.S, 64)), dim3(64), 0, s, gb.fit_partials.p, gb.fitness.p, gb.S, gb.blocks_lin);
   MI_LAUNCH_CHECK();
 }
 
@@ -709,7 +723,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   gb.time_kernels = false;
   launch_linearize(s, gb, src, tgt, P);
   gb.time_kernels = tk;
-  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, gb.partials.p, gb.blocks_per_pair, P);
+  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, gb.partials.p, gb.blocks_lin, P);
   MI_LAUNCH_CHECK();
   GicpPairState st;
   MI_HIP(hipMemcpyAsync(&st, gb.state.p, sizeof(st), hipMemcpyDeviceToHost, s));

@@ -69,19 +69,34 @@ __device__ __forceinline__ int own_cell_count(const GridView& g, int bx, int by,
   return e - s;
 }
 
-// Scan the points of one cell range, two loads in flight.
+// Scan the points of one cell range, Visitor::kScanWidth loads in flight per step.  The search is latency-bound on these
+// dependent loads (one wave-instruction per candidate under SIMT); issuing W of them back to back overlaps their latency
+// and cuts the wave-level iteration count by W.
 template <typename Visitor>
 __device__ __forceinline__ void scan_range(const GridView& g, int s, int e, float qx, float qy, float qz, Visitor& vis) {
-  int j = s;
-  if (Visitor::kScanWidth >= 2)
-  for (; j + 1 < e; j += 2) {
-    const float4 p0 = g.pts[j], p1 = g.pts[j + 1];
-    vis.visit(j, dist2f(qx, qy, qz, p0.x, p0.y, p0.z));
-    vis.visit(j + 1, dist2f(qx, qy, qz, p1.x, p1.y, p1.z));
+  constexpr int W = Visitor::kScanWidth;
+  for (int j = s; j < e; j += W) {
+    float4 p[W];
+#pragma unroll
+    for (int u = 0; u < W; u++) p[u] = g.pts[min(j + u, e - 1)];
+#pragma unroll
+    for (int u = 0; u < W; u++)
+      if (j + u < e) vis.visit(j + u, dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z));
   }
-  for (; j < e; j++) {
-    const float4 p0 = g.pts[j];
-    vis.visit(j, dist2f(qx, qy, qz, p0.x, p0.y, p0.z));
+}
+
+// First probe of a cell: the slot the key hashes to (one 16-byte load, issued early by the callers).
+__device__ __forceinline__ int4 first_slot(const GridView& g, uint32_t key) {
+  return *reinterpret_cast<const int4*>(&g.table[hash_slot(key, g.m.hshift)]);
+}
+// Finish a lookup whose first slot has already been loaded.
+__device__ __forceinline__ bool resolve_range(const GridView& g, uint32_t key, int4 sl, int& s, int& e) {
+  uint32_t h = hash_slot(key, g.m.hshift);
+  for (;;) {
+    if ((uint32_t)sl.x == key) { s = sl.y; e = sl.z; return true; }
+    if ((uint32_t)sl.x == kEmptyKey) return false;
+    h = (h + 1) & g.m.hmask;
+    sl = *reinterpret_cast<const int4*>(&g.table[h]);
   }
 }
 
@@ -132,11 +147,13 @@ __device__ __forceinline__ float grid_search(const GridView& g, float qx, float 
         const float gr = (minfrac - margin) * cell;
         if (gr > 0.f) {
           explored2 = gr * gr;
+          vis.flush();
           if (vis.complete() < explored2 || explored2 >= max_d2) done = true;
         }
       }
       // ---- shell 1: mask of the 26 neighbours that can still hold something useful
       if (!done && rmax >= 1) {
+        vis.flush();
         const float gxs[3] = {fx, 0.f, 1.f - fx}, gys[3] = {fy, 0.f, 1.f - fy}, gzs[3] = {fz, 0.f, 1.f - fz};
         const float b_units = fminf(vis.bound(), max_d2) / (cell * cell);
         uint32_t mask = 0;
@@ -149,21 +166,46 @@ __device__ __forceinline__ float grid_search(const GridView& g, float qx, float 
           const bool ok = ix >= 0 && ix < dx && iy >= 0 && iy < dy && iz >= 0 && iz < dz && !(lbu * lbu > b_units);
           mask |= ok ? (1u << c) : 0u;
         }
-        while (mask) {
-          const int c = __ffs(mask) - 1;
-          mask &= mask - 1;
+        // walk the set bits; the hash slot of the NEXT cell is fetched while the current cell's points are scanned
+        auto cell_key = [&](int c) {
           const int a0 = c % 3, a1 = (c / 3) % 3, a2 = c / 9;
+          return ((uint32_t)l << 27) | morton27((uint32_t)(cx + a0 - 1), (uint32_t)(cy + a1 - 1), (uint32_t)(cz + a2 - 1));
+        };
+        int c_cur = -1;
+        uint32_t key_cur = 0;
+        int4 slot_cur = make_int4(0, 0, 0, 0);
+        if (mask) {
+          c_cur = __ffs(mask) - 1;
+          mask &= mask - 1;
+          key_cur = cell_key(c_cur);
+          slot_cur = first_slot(g, key_cur);
+        }
+        while (c_cur >= 0) {
+          int c_nxt = -1;
+          uint32_t key_nxt = 0;
+          int4 slot_nxt = make_int4(0, 0, 0, 0);
+          if (mask) {
+            c_nxt = __ffs(mask) - 1;
+            mask &= mask - 1;
+            key_nxt = cell_key(c_nxt);
+            slot_nxt = first_slot(g, key_nxt);
+          }
+          const int a0 = c_cur % 3, a1 = (c_cur / 3) % 3, a2 = c_cur / 9;
           const float gx = (a0 == 0) ? fx : ((a0 == 2) ? 1.f - fx : 0.f);
           const float gy = (a1 == 0) ? fy : ((a1 == 2) ? 1.f - fy : 0.f);
           const float gz = (a2 == 0) ? fz : ((a2 == 2) ? 1.f - fz : 0.f);
           const float lb = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - margin, 0.f) * cell;
-          if (lb * lb > fminf(vis.bound(), max_d2)) continue;  // the bound shrank since the mask was built
-          int s, e;
-          if (cell_range(g, ((uint32_t)l << 27) | morton27((uint32_t)(cx + a0 - 1), (uint32_t)(cy + a1 - 1), (uint32_t)(cz + a2 - 1)), s, e))
-            scan_range(g, s, e, qx, qy, qz, vis);
+          if (!(lb * lb > fminf(vis.bound(), max_d2))) {  // the bound may have shrunk since the mask was built
+            int s, e;
+            if (resolve_range(g, key_cur, slot_cur, s, e)) scan_range(g, s, e, qx, qy, qz, vis);
+          }
+          c_cur = c_nxt;
+          key_cur = key_nxt;
+          slot_cur = slot_nxt;
         }
         const float gr = (1.f + minfrac - margin) * cell;
         explored2 = gr * gr;
+        vis.flush();
         if (vis.complete() < explored2 || explored2 >= max_d2) done = true;
       }
       if (!done && rmax <= 1 && top) return INFINITY;  // the whole grid fits in these shells
@@ -197,11 +239,13 @@ __device__ __forceinline__ float grid_search(const GridView& g, float qx, float 
         }
         const float gr = ((float)r + minfrac - margin) * cell;
         explored2 = gr * gr;
+        vis.flush();
         if (vis.complete() < explored2 || explored2 >= max_d2) return explored2;
       }
       return INFINITY;  // the whole grid has been scanned
     }
     l = min(l + level_step, m.top_level);
+    vis.flush();
     vis.restart();
   }
 }
@@ -261,6 +305,7 @@ struct Nearest1 {
   int best_j;
   __device__ __forceinline__ float bound() const { return best_d2; }
   __device__ __forceinline__ float complete() const { return best_d2; }
+  __device__ __forceinline__ void flush() {}
   __device__ __forceinline__ void restart() {}  // re-visiting a point cannot change a 1-NN result
   __device__ __forceinline__ void visit(int j, float d2) {
     if (d2 < best_d2 || (d2 == best_d2 && best_j >= 0 && j != best_j && orig[j] < orig[best_j])) { best_d2 = d2; best_j = j; }
@@ -278,6 +323,7 @@ struct Nearest2 {
   float limit;
   __device__ __forceinline__ float bound() const { return fminf(d2nd, limit); }
   __device__ __forceinline__ float complete() const { return d1; }
+  __device__ __forceinline__ void flush() {}
   __device__ __forceinline__ void restart() {}
   __device__ __forceinline__ void visit(int j, float dd) {
     if (j == j1) return;  // a coarser level re-visits points
@@ -294,7 +340,7 @@ struct Nearest2 {
 // Sorted (ascending by (d2, caller index)) list of the K best, fully in registers.
 template <int K>
 struct NearestK {
-  static constexpr int kScanWidth = 1;  // the insertion is register-hungry: keep one candidate in flight
+  static constexpr int kScanWidth = 1;
   const int* orig;
   int k;        // 1..K actually wanted
   float hint;   // k-th distance of the previous (finer) level: an upper bound of the true k-th distance
@@ -320,6 +366,7 @@ struct NearestK {
   }
   __device__ __forceinline__ float bound() const { return fminf(kth(), hint); }
   __device__ __forceinline__ float complete() const { return kth(); }
+  __device__ __forceinline__ void flush() {}
   // squared distance to the farthest of k DISTINCT points of the cloud: an upper bound of the k-th NN distance
   __device__ __forceinline__ void set_hint(float d2max) { hint = d2max; }
   __device__ __forceinline__ void restart() {
@@ -345,6 +392,43 @@ struct NearestK {
       placed = placed || !lt;
     }
     if (!placed) { d2[0] = dd; idx[0] = j; }
+  }
+};
+
+// NearestK with an LDS staging queue.  The sorted insertion is ~170 instructions; under SIMT a wave executes it for a
+// candidate whenever ANY of its 64 lanes wants that candidate, i.e. for almost every candidate.  Here a lane only appends
+// (d2, j) of candidates that beat its current worst to a small private queue in LDS; the queues are drained together —
+// when one of them fills up and at shell boundaries — so the insertion block runs with most lanes active.  The bound
+// used for pruning between drains is the (looser) bound of the last drain, which is always safe.
+template <int K, int Q>
+struct NearestKQ : NearestK<K> {
+  int2* queue;  // this wave's Q x 64 slots, slot t of lane l at [t * 64 + l]
+  int lane, len;
+  __device__ __forceinline__ void init_queue(int2* wave_queue) {
+    queue = wave_queue;
+    lane = threadIdx.x & 63;
+    len = 0;
+  }
+  __device__ __forceinline__ void flush() {
+    for (int t = 0; t < Q; t++) {
+      if (!__any(t < len)) break;
+      if (t < len) {
+        const int2 c = queue[t * 64 + lane];
+        NearestK<K>::visit(c.y, __int_as_float(c.x));
+      }
+    }
+    len = 0;
+  }
+  __device__ __forceinline__ void restart() {
+    flush();
+    NearestK<K>::restart();
+  }
+  __device__ __forceinline__ void visit(int j, float dd) {
+    if (dd > this->hint) return;
+    if (!this->less(dd, j, this->d2[K - 1], this->idx[K - 1])) return;
+    queue[len * 64 + lane] = make_int2(__float_as_int(dd), j);
+    len++;
+    if (__any(len >= Q)) flush();
   }
 };
 

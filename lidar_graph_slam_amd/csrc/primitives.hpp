@@ -45,6 +45,25 @@ __device__ __forceinline__ void block_sum(double* acc, double* smem) {
   __syncthreads();
 }
 
+// XCD-aware work mapping (perf only, never correctness).  MI355X deals workgroups round-robin over its 8 XCDs, each with
+// a private 4 MB L2; consecutive block ids therefore land on DIFFERENT L2s.  A 1-D grid of ceil(S/8)*8*G blocks is
+// remapped so that all G blocks of one item (scan pair / cloud) share blockIdx % 8, i.e. one XCD: the item's points,
+// covariances and hash table then stay resident in that XCD's L2 while it is being worked on, instead of every XCD
+// touching every item.
+__device__ __forceinline__ bool xcd_item_chunk(int G, int S, int& item, int& chunk) {
+  const int id = blockIdx.x;
+  if (S < 8) {  // fewer items than XCDs: spread every item over the whole chip instead
+    item = id / G;
+    chunk = id % G;
+    return item < S;
+  }
+  const int xcd = id & 7, slot = id >> 3;
+  item = (slot / G) * 8 + xcd;
+  chunk = slot % G;
+  return item < S;
+}
+inline int xcd_grid(int G, int S) { return (S < 8) ? S * G : ((S + 7) / 8) * 8 * G; }
+
 // float <-> order-preserving uint (for atomicMin/atomicMax bounding boxes)
 __device__ __forceinline__ uint32_t float_to_ordered(float f) {
   const uint32_t u = __float_as_uint(f);
