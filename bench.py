@@ -125,8 +125,12 @@ def main():
             batch.set_targets(tgt_h, counts, pre)
             batch.set_sources(src_h, counts, pre)
         else:
-            batch.set_targets_dev(tgt_d.data_ptr(), counts, pre)
-            batch.set_sources_dev(src_d.data_ptr(), counts, pre)
+            if os.environ.get("BENCH_SRC_FIRST"):
+                batch.set_sources_dev(src_d.data_ptr(), counts, pre)
+                batch.set_targets_dev(tgt_d.data_ptr(), counts, pre)
+            else:
+                batch.set_targets_dev(tgt_d.data_ptr(), counts, pre)
+                batch.set_sources_dev(src_d.data_ptr(), counts, pre)
         batch.align()
         return batch.results()
 

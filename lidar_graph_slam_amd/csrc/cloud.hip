@@ -58,18 +58,22 @@ __global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pts, 
       mn[d] = fminf(mn[d], __shfl_down(mn[d], off, kWave));
       mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off, kWave));
     }
-  if (lane_id() == 0 && mn[0] <= mx[0]) {
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      atomicMin(&bounds[c * 6 + d], float_to_ordered(mn[d]));
-      atomicMax(&bounds[c * 6 + 3 + d], float_to_ordered(mx[d]));
-    }
+  __shared__ float red[4][6];
+  if (lane_id() == 0)
+    for (int d = 0; d < 3; d++) { red[wave_id()][d] = mn[d]; red[wave_id()][3 + d] = mx[d]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {  // one atomic per block and component
+    const int d = threadIdx.x;
+    float v = red[0][d];
+    for (int w = 1; w < 4; w++) v = (d < 3) ? fminf(v, red[w][d]) : fmaxf(v, red[w][d]);
+    if (d < 3) { if (v < INFINITY) atomicMin(&bounds[c * 6 + d], float_to_ordered(v)); }
+    else { if (v > -INFINITY) atomicMax(&bounds[c * 6 + d], float_to_ordered(v)); }
   }
 }
 
 static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const int* cnt, int B, size_t cap) {
   hipLaunchKernelGGL(k_bounds_init, dim3(div_up(B * 6, 256)), dim3(256), 0, s, ws.bounds.p, B);
-  const int gx = std::max(1, std::min(64, div_up((long)cap, 1024)));
+  const int gx = std::max(1, std::min(16, div_up((long)cap, 4096)));
   hipLaunchKernelGGL(k_bounds, dim3(gx, B), dim3(256), 0, s, in, cnt, ws.bounds.p, cap);
 }
 
@@ -207,10 +211,28 @@ __device__ __forceinline__ float morton_window_hint(const GridView& g, int i, co
 }
 
 // ---- k-NN covariances (F2) --------------------------------------------------------------------------------------
-// Step 1: exact k-NN of every point in its own cloud -> neighbour lists (sorted indices), k ints per point.
-// Kept apart from the covariance maths so that the divergent, latency-bound search runs at higher occupancy.
+// next point at exactly tau2 whose caller index is the smallest one greater than `last` (tie resolution, rare path)
+struct NextEq {
+  static constexpr int kScanWidth = 1;
+  const int* orig; float tau2; int last; int best_j; int best_o;
+  __device__ __forceinline__ float bound() const { return tau2; }
+  __device__ __forceinline__ float complete() const { return tau2; }
+  __device__ __forceinline__ void flush() {}
+  __device__ __forceinline__ void restart() {}
+  __device__ __forceinline__ void visit(int j, float dd) {
+    if (dd != tau2) return;
+    const int oj = orig[j];
+    if (oj > last && (best_j < 0 || oj < best_o)) { best_j = j; best_o = oj; }
+  }
+};
+
+// Step 1: exact k-NN of every point in its own cloud -> neighbour lists (sorted-array indices, k ints per point, in no
+// particular order — the covariance only needs the set).
+//   pass A  distances of the k nearest by the branch-free median network (NearestKD) over the escalating shell search;
+//   pass B  one ball query with the exact k-th distance collects the neighbour indices (ties at the k-th distance:
+//           lowest caller index first, like the oracle).
 template <int K>
-__global__ __launch_bounds__(256, 3) void k_knn_self(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+__global__ __launch_bounds__(256) void k_knn_self(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
                                                   const GridMeta* __restrict__ meta, int* __restrict__ nbr, size_t cap, size_t slots_cap, int k, int G,
                                                   int B) {
   int c, bx;
@@ -219,13 +241,36 @@ __global__ __launch_bounds__(256, 3) void k_knn_self(const float4* __restrict__ 
   const int i = bx * blockDim.x + threadIdx.x;
   if (i >= g.m.n) return;
   const float4 q = g.pts[i];
-  NearestK<K> nk;
-  nk.init(g.orig, k);
-  grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k), 1);
   int* o = nbr + ((size_t)c * cap + i) * k;
-#pragma unroll
-  for (int j = 0; j < K; j++)
-    if (j < k) o[j] = nk.idx[j];
+  float tau2;
+  {
+    NearestKD<K> nk;
+    nk.init(k);
+    grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k), 1);
+    tau2 = nk.kth();
+  }
+  if (!(tau2 < INFINITY)) {  // fewer than k points in the whole cloud (the API rejects this; keep the lists defined)
+    for (int j = 0; j < k; j++) o[j] = -1;
+    return;
+  }
+  BallCollector bc{g.orig, o, k, tau2, 0, 0, -1};
+  grid_ball_search(g, q.x, q.y, q.z, bc, 1.0f);
+  if (bc.n_lt + bc.n_eq == k && bc.n_eq == 1) {
+    o[k - 1] = bc.eq_first;  // the common case: exactly one point at the k-th distance
+    return;
+  }
+  // ties at the k-th distance: take the (k - n_lt) lowest caller indices among the points at tau2 (rare, slow path)
+  int filled = min(bc.n_lt, k);
+  int last = -1;
+  while (filled < k) {
+    // next point at tau2 whose caller index is the smallest one greater than `last`
+    NextEq ne{g.orig, tau2, last, -1, 0x7fffffff};
+    grid_ball_search(g, q.x, q.y, q.z, ne, 1.0f);
+    if (ne.best_j < 0) break;
+    o[filled++] = ne.best_j;
+    last = ne.best_o;
+  }
+  for (; filled < k; filled++) o[filled] = -1;
 }
 
 // Step 2: neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation, 2 x float4 per point.
@@ -435,31 +480,63 @@ __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict_
   flags[o + i] = f;
 }
 
-__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
-                                                         const GridMeta* __restrict__ vmeta, const int* __restrict__ flags,
-                                                         const int* __restrict__ local, const int* __restrict__ blockoff,
-                                                         const int* __restrict__ totals, float4* __restrict__ out, int* __restrict__ cnt_out,
-                                                         size_t cap, int nblk) {
-  const int c = blockIdx.y;
+constexpr int kCentroidBlock = 1024;
+__global__ __launch_bounds__(kCentroidBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
+                                                                    const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
+                                                                    const int* __restrict__ flags, const int* __restrict__ local,
+                                                                    const int* __restrict__ blockoff, const int* __restrict__ totals,
+                                                                    float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G,
+                                                                    int B) {
+  // Every thread gathers ITS point (fully parallel) into LDS; the head thread of a voxel then adds its run in ascending
+  // index order — the oracle's order, so the fp32 sums are bit-equal — reading from LDS.  Only the part of a run that
+  // continues past the end of this block's 1 024 points is read from memory (eight gathers in flight).
+  __shared__ float4 spt[kCentroidBlock];
+  __shared__ uint32_t skey[kCentroidBlock];
+  int c, bx;
+  if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = vmeta[c];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bx * kCentroidBlock + threadIdx.x;
   if (i == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
-  if (i >= m.n) return;
+  if (bx * kCentroidBlock >= m.n) return;  // whole block past the end (uniform)
   const size_t o = (size_t)c * cap;
   if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input
-    out[o + i] = in[o + i];
+    if (i < m.n) out[o + i] = in[o + i];
     return;
   }
-  if (!flags[o + i]) return;
-  const uint32_t k = keys[o + i];
-  float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-  int j = i;
-  for (; j < m.n && keys[o + j] == k; j++) {  // ascending point index inside the voxel (stable sort)
-    const float4 p = in[o + vals[o + j]];
-    ax += p.x; ay += p.y; az += p.z; aw += p.w;
+  const bool valid = i < m.n;
+  uint32_t k = kEmptyKey;
+  if (valid) {
+    k = keys[o + i];
+    spt[threadIdx.x] = in[o + vals[o + i]];
   }
-  const float cnt = (float)(j - i);
-  out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(ax / cnt, ay / cnt, az / cnt, aw / cnt);
+  skey[threadIdx.x] = valid ? k : kEmptyKey;
+  __syncthreads();
+  if (!valid || !flags[o + i]) return;
+  float4 a = spt[threadIdx.x];
+  int cnt = 1;
+  int t = threadIdx.x + 1;
+  for (; t < kCentroidBlock && skey[t] == k; t++) {
+    const float4 p = spt[t];
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    cnt++;
+  }
+  if (t == kCentroidBlock) {  // the run may continue in the next block's points
+    int j = i + cnt;
+    while (j < m.n && keys[o + j] == k) {
+      int len = 1;
+      while (len < 8 && j + len < m.n && keys[o + j + len] == k) len++;
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) p[u] = in[o + vals[o + min(j + u, j + len - 1)]];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (u < len) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; }
+      cnt += len;
+      j += len;
+    }
+  }
+  const float fc = (float)cnt;
+  out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc);
 }
 
 void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf) {
@@ -471,8 +548,9 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   sort_pairs(s, ws, B, cap, cnt_in, 4);
   hipLaunchKernelGGL(k_voxel_heads, grid, dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap);
   scan_flags(s, ws, B, cap, cnt_in);
-  hipLaunchKernelGGL(k_voxel_centroids, grid, dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
-                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, div_up((long)cap, kScanTile));
+  const int Gv = div_up((long)cap, kCentroidBlock);
+  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kCentroidBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
+                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, div_up((long)cap, kScanTile), Gv, B);
   MI_LAUNCH_CHECK();
 }
 
@@ -486,8 +564,8 @@ __global__ __launch_bounds__(256) void k_sor_meandist(const float4* __restrict__
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.m.n) return;
   const float4 q = g.pts[i];
-  NearestK<K> nk;
-  nk.init(g.orig, mean_k + 1);
+  NearestKD<K> nk;  // distances only: the statistic needs no neighbour identities
+  nk.init(mean_k + 1);
   grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, mean_k + 1), 1);
   double dist_sum = 0.0;
 #pragma unroll

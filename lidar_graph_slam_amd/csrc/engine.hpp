@@ -106,6 +106,7 @@ struct GicpBatch {
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;
+  DevBuf<unsigned char> trials;  // [S][16] LmTrial (gicp.hip)
   DevBuf<int> n_active;
   PinnedBuf<int> h_active;
   DevBuf<double> fit_partials;

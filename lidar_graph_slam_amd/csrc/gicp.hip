@@ -24,6 +24,17 @@ struct GicpPairState {
   double final_H[36];
   double last_error;
   int iter, trial, active, converged, n_inliers, lm_failed, need_error, pad;
+  double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
+};
+
+// One Levenberg-Marquardt trial step.  step_lm's trial sequence is fully determined by (H, b, lambda): trial t uses
+// lambda_t = lambda * 2 * 4 * ... * 2^t, so ALL trial poses are computed up front, ONE pass over the points evaluates all
+// their costs (10x the flops — the chip has them — but 1x the memory traffic), and the decision walks the trials in order.
+// Same result as the sequential loop, but no data-dependent number of passes over the points.
+struct LmTrial {
+  Pose xi, delta;
+  double d[6];
+  double lambda;
 };
 
 struct GicpDevParams {
@@ -33,8 +44,10 @@ struct GicpDevParams {
 };
 
 constexpr int kNAcc = 29;      // 6 Hrr + 9 Hrt + 6 Htt + 6 b + 1 cost + 1 inlier count
-constexpr int kPartStride = 32;
+constexpr int kPartStride = 64;  // doubles per (pair, block): 0..28 linearize, 32..47 one cost per LM trial
+constexpr int kTrialSlot = 32;
 constexpr int kGicpBlock = 256;
+constexpr int kMaxTrials = 16;  // lm_max_iterations is capped here (fast_gicp default 10)
 
 GicpBatch::~GicpBatch() {
   for (auto e : ev) (void)hipEventDestroy(e);
@@ -63,6 +76,7 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.stats.ensure(64);
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
+  gb.trials.ensure((size_t)S * kMaxTrials * sizeof(LmTrial));
   gb.n_active.ensure(1);
   gb.h_active.ensure(1);
   gb.fit_partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * 2);
@@ -83,6 +97,7 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   s.nu = 2.0;
   s.last_error = 0;
   s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.pad = 0;
+  s.last_step = 1.0e9;
   st[p] = s;
 }
 
@@ -116,7 +131,25 @@ __device__ __forceinline__ void residual(const Pose& x, const float4& p, const f
 // Full (re-)search of one source point: exact nearest neighbour in the target + how far the query may move before the
 // answer can change.  Seeded with the previous correspondent when there is one.
 __device__ __forceinline__ void search_point(const GridView& g, float qx, float qy, float qz, int jprev, float max_corr_d2, int debug_flags,
-                                             int& j_out, float& margin_out) {
+                                             bool track_margin, int& j_out, float& margin_out) {
+  const float max_corr = sqrtf(max_corr_d2);
+  if (!track_margin) {
+    // The pose is still moving by more than any margin could absorb: plain exact 1-NN (prunes with the best distance, not
+    // the runner-up), seeded with the previous correspondent and started at the level whose cell is about that far.
+    Nearest1 nn{g.orig, INFINITY, -1};
+    int level0 = 0;
+    if (jprev >= 0 && jprev < g.m.n && !(debug_flags & 2)) {
+      const float4 pp = g.pts[jprev];
+      nn.best_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
+      nn.best_j = jprev;
+      const float rel = sqrtf(nn.best_d2) * g.m.inv_cell;
+      level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
+    }
+    grid_search(g, qx, qy, qz, max_corr_d2, nn, level0, 1);
+    j_out = (nn.best_j >= 0 && nn.best_d2 < max_corr_d2) ? nn.best_j : -1;
+    margin_out = 0.f;  // search again next iteration
+    return;
+  }
   Nearest2 nn{g.orig, INFINITY, -1, INFINITY, INFINITY};
   float explored2;
   if (jprev >= 0 && jprev < g.m.n && !(debug_flags & 2)) {
@@ -124,7 +157,6 @@ __device__ __forceinline__ void search_point(const GridView& g, float qx, float 
     nn.d1 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
     nn.j1 = jprev;
   }
-  const float max_corr = sqrtf(max_corr_d2);
   if (nn.j1 >= 0 && nn.d1 < 0.36f * g.m.cell * g.m.cell) {
     // close seed: scan the ball a little larger than the seed distance (so that an isolated nearest neighbour still
     // earns a non-zero margin) — a handful of base cells
@@ -132,9 +164,14 @@ __device__ __forceinline__ void search_point(const GridView& g, float qx, float 
     nn.limit = r * r;
     grid_ball_search(g, qx, qy, qz, nn, 2.1f);
     explored2 = nn.limit;
+  } else if (nn.j1 >= 0 && nn.d1 < max_corr_d2) {
+    // far seed (sparse far field): shell search started at the level whose cell is about the seed distance
+    const float rel = sqrtf(nn.d1) * g.m.inv_cell;
+    const int level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
+    explored2 = grid_search(g, qx, qy, qz, max_corr_d2, nn, level0, 1);
   } else {
-    // far or no seed: shell search with escalation.  The bound reaches a little past max_corr so that a point with
-    // nothing in range learns HOW far the nearest thing is and is not searched again at every iteration.
+    // no seed / nothing in range so far: shell search with escalation.  The bound reaches a little past max_corr so that a
+    // point with nothing in range learns HOW far the nearest thing is and is not searched again at every iteration.
     const float ext = max_corr + 0.25f * g.m.cell + 0.25f;
     explored2 = grid_search(g, qx, qy, qz, isfinite(max_corr) ? ext * ext : INFINITY, nn, 0, 2);
   }
@@ -149,7 +186,6 @@ __device__ __forceinline__ void search_point(const GridView& g, float qx, float 
   }
   margin_out = margin * (1.f - 1e-4f) - 1e-5f;  // fp32 slack
 }
-
 
 // F3 update_correspondences, incremental and exact.  PPT = points per thread and pass (tile = 256 * PPT points).
 template <int kLinPointsPerThread>
@@ -172,6 +208,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
   const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
   const int n = scount[pair];
   const Pose x0 = st->x0;
+  // margins only pay once the updates are small enough to stay inside them (cm); before that use the cheap 1-NN search
+  const bool track_margin = (st->last_step < 0.03) || (debug_flags & 128);
   float Tf[12];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -221,7 +259,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
       int j;
       float margin;
-      search_point(g, qx, qy, qz, corr[so + i], max_corr_d2, debug_flags, j, margin);
+      search_point(g, qx, qy, qz, corr[so + i], max_corr_d2, debug_flags, track_margin, j, margin);
       corr[so + i] = j;
       qsearch[so + i] = make_float4(qx, qy, qz, margin);
     }
@@ -332,13 +370,14 @@ __device__ __forceinline__ void unpack_normal_equations(const double* a, double*
   for (int i = 0; i < 6; i++) b[i] = a[21 + i];
 }
 
-__device__ __forceinline__ void lm_trial(GicpPairState& s) {
+__device__ __forceinline__ void lm_make_trial(const double* H, const double* b, const Pose& x0, double lambda, LmTrial& tr) {
   double A[36], nb[6];
-  for (int i = 0; i < 36; i++) A[i] = s.H[i];
-  for (int i = 0; i < 6; i++) { A[7 * i] += s.lambda; nb[i] = -s.b[i]; }
-  ldlt6_solve(A, nb, s.d);
-  s.delta = se3_exp(s.d);
-  s.xi = pose_compose(s.delta, s.x0);
+  for (int i = 0; i < 36; i++) A[i] = H[i];
+  for (int i = 0; i < 6; i++) { A[7 * i] += lambda; nb[i] = -b[i]; }
+  ldlt6_solve(A, nb, tr.d);
+  tr.delta = se3_exp(tr.d);
+  tr.xi = pose_compose(tr.delta, x0);
+  tr.lambda = lambda;
 }
 
 // After a step_optimize completed: iteration bookkeeping + convergence (F6).
@@ -352,11 +391,21 @@ __device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParam
   }
   const bool conv = is_converged(s.delta, P.rotation_epsilon, P.transformation_epsilon);
   s.converged = conv ? 1 : 0;
+  {
+    double rmax = 0, tmax = 0;
+    for (int k = 0; k < 9; k++) rmax = fmax(rmax, fabs(s.delta.R[k] - ((k % 4 == 0) ? 1.0 : 0.0)));
+    for (int k = 0; k < 3; k++) tmax = fmax(tmax, fabs(s.delta.t[k]));
+    s.last_step = tmax + 50.0 * rmax;
+  }
   if ((conv && !P.force_iterations) || s.iter >= P.max_iterations) s.active = 0;
 }
 
-__global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, const double* __restrict__ partials, int G, GicpDevParams P) {
+__global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, LmTrial* __restrict__ trials, const double* __restrict__ partials,
+                                                   int G, GicpDevParams P) {
   __shared__ double sums[kPartStride];
+  __shared__ double sH[36], sb[6], slambda;
+  __shared__ Pose sx0;
+  __shared__ int do_trials;
   const int pair = blockIdx.x;
   GicpPairState* st = state + pair;
   if (!st->active) return;
@@ -368,32 +417,45 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
     sums[l] = s;
   }
   __syncthreads();
-  if (l != 0) return;
-  GicpPairState s = *st;
-  unpack_normal_equations(sums, s.H, s.b);
-  s.y0 = sums[27];
-  s.n_inliers = (int)(sums[28] + 0.5);
-  if (P.optimizer == MI355_OPT_GN) {
-    double nb[6];
-    for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
-    ldlt6_solve(s.H, nb, s.d);
-    s.delta = se3_exp(s.d);
-    s.x0 = pose_compose(s.delta, s.x0);
-    for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
-    s.last_error = s.y0;
-    finish_step(s, P, true);
-  } else {
-    if (s.lambda < 0.0) {
-      double mx = 0;
-      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(s.H[7 * i]));
-      s.lambda = P.lm_init_lambda_factor * mx;
+  if (l == 0) {
+    GicpPairState s = *st;
+    unpack_normal_equations(sums, s.H, s.b);
+    s.y0 = sums[27];
+    s.n_inliers = (int)(sums[28] + 0.5);
+    do_trials = 0;
+    if (P.optimizer == MI355_OPT_GN) {
+      double nb[6];
+      for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
+      ldlt6_solve(s.H, nb, s.d);
+      s.delta = se3_exp(s.d);
+      s.x0 = pose_compose(s.delta, s.x0);
+      for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
+      s.last_error = s.y0;
+      finish_step(s, P, true);
+    } else {
+      if (s.lambda < 0.0) {
+        double mx = 0;
+        for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(s.H[7 * i]));
+        s.lambda = P.lm_init_lambda_factor * mx;
+      }
+      s.need_error = 1;
+      do_trials = 1;
+      for (int i = 0; i < 36; i++) sH[i] = s.H[i];
+      for (int i = 0; i < 6; i++) sb[i] = s.b[i];
+      slambda = s.lambda;
+      sx0 = s.x0;
     }
-    s.nu = 2.0;
-    s.trial = 0;
-    lm_trial(s);
-    s.need_error = 1;
+    *st = s;
   }
-  *st = s;
+  __syncthreads();
+  if (do_trials && l < P.lm_max_iterations) {
+    // lambda of trial l: step_lm multiplies by nu = 2, 4, 8, ... after each rejection
+    double lam = slambda, nu = 2.0;
+    for (int i = 0; i < l; i++) { lam = nu * lam; nu = 2 * nu; }
+    LmTrial tr;
+    lm_make_trial(sH, sb, sx0, lam, tr);
+    trials[(size_t)pair * kMaxTrials + l] = tr;
+  }
 }
 
 __device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const float4& ma, const float4& mb) {
@@ -403,93 +465,92 @@ __device__ __forceinline__ double point_error(const Pose& x, const float4& p, co
   return cost64(dex, dey, dez, ma.x, ma.y, ma.z, ma.w, mb.x, mb.y);
 }
 
+// F5 compute_error for every LM trial pose in one pass (frozen correspondences and Mahalanobis matrices).
+template <int NT>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
-                                                           const GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                           const float4* __restrict__ mahal, double* __restrict__ partials) {
-  __shared__ double smem[4];
+                                                           const GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
+                                                           const int* __restrict__ corr, const float4* __restrict__ mahal,
+                                                           double* __restrict__ partials, int n_trials) {
+  __shared__ double smem[4 * NT];
+  __shared__ Pose sxi[NT];
   const int pair = blockIdx.y;
   const GicpPairState* st = state + pair;
   if (!st->active || !st->need_error) return;
-  const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
-  const int n = scount[pair];
-  const Pose xi = st->xi;
-  const size_t so = (size_t)pair * scap;
-  double acc[1] = {0.0};
-  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
-    const int j = corr[so + i];
-    if (j < 0) continue;
-    acc[0] += point_error(xi, spts[so + i], tp[j], mahal[2 * (so + i)], mahal[2 * (so + i) + 1]);
-  }
-  block_sum<1, 4>(acc, smem);
-  if (threadIdx.x == 0) partials[((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + 30] = acc[0];
-}
-
-constexpr int kDecideBlock = 1024;
-__global__ __launch_bounds__(kDecideBlock) void k_gicp_decide(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
-                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
-                                                            GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                            const float4* __restrict__ mahal, const double* __restrict__ partials, int G,
-                                                            GicpDevParams P) {
-  __shared__ double smem[16];
-  __shared__ GicpPairState s;
-  __shared__ int again;
-  const int pair = blockIdx.x;
-  if (!state[pair].active || !state[pair].need_error) return;
-  if (threadIdx.x == 0) {
-    s = state[pair];
-    double yi = 0;
-    for (int g = 0; g < G; g++) yi += partials[((size_t)pair * G + g) * kPartStride + 30];
-    s.yi = yi;
-  }
+  if (threadIdx.x < NT) sxi[threadIdx.x] = trials[(size_t)pair * kMaxTrials + min((int)threadIdx.x, n_trials - 1)].xi;
   __syncthreads();
   const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
   const int n = scount[pair];
   const size_t so = (size_t)pair * scap;
-  for (;;) {
-    if (threadIdx.x == 0) {
-      again = 0;
-      double denom = 0;
-      for (int i = 0; i < 6; i++) denom += s.d[i] * (s.lambda * s.d[i] - s.b[i]);
-      const double rho = (s.y0 - s.yi) / denom;
-      if (rho < 0) {
-        if (!P.force_iterations && is_converged(s.delta, P.rotation_epsilon, P.transformation_epsilon)) {
-          finish_step(s, P, true);  // step_lm returns true without moving x0
-        } else {
-          s.lambda = s.nu * s.lambda;
-          s.nu = 2 * s.nu;
-          s.trial += 1;
-          if (s.trial >= P.lm_max_iterations) {
-            finish_step(s, P, false);
-          } else {
-            lm_trial(s);
-            again = 1;
-          }
-        }
-      } else {
-        s.x0 = s.xi;
-        const double t = 2 * rho - 1;
-        s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
-        for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
-        s.last_error = s.yi;
-        finish_step(s, P, true);
-      }
-    }
-    __syncthreads();
-    if (!again) break;
-    // rejected trial: evaluate compute_error at the new trial pose inside this block (rare path)
-    const Pose xi = s.xi;
-    double acc[1] = {0.0};
-    for (int i = threadIdx.x; i < n; i += kDecideBlock) {
-      const int j = corr[so + i];
-      if (j < 0) continue;
-      acc[0] += point_error(xi, spts[so + i], tp[j], mahal[2 * (so + i)], mahal[2 * (so + i) + 1]);
-    }
-    block_sum<1, 16>(acc, smem);
-    if (threadIdx.x == 0) s.yi = acc[0];
-    __syncthreads();
+  double acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = 0.0;
+  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
+    const int j = corr[so + i];
+    if (j < 0) continue;
+    const float4 p = spts[so + i], q = tp[j], ma = mahal[2 * (so + i)], mb = mahal[2 * (so + i) + 1];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] += point_error(sxi[t], p, q, ma, mb);
   }
-  if (threadIdx.x == 0) state[pair] = s;
+  block_sum<NT, 4>(acc, smem);
+  if (threadIdx.x == 0) {
+    double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + kTrialSlot;
+#pragma unroll
+    for (int t = 0; t < NT; t++) out[t] = acc[t];
+  }
+}
+
+// step_lm's accept / reject walk over the pre-evaluated trials + iteration bookkeeping.
+__global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
+                                                    const double* __restrict__ partials, int G, GicpDevParams P) {
+  __shared__ double yi[kMaxTrials];
+  const int pair = blockIdx.x;
+  if (!state[pair].active || !state[pair].need_error) return;
+  const int l = threadIdx.x;
+  if (l < P.lm_max_iterations) {
+    double s = 0;
+    for (int g = 0; g < G; g++) s += partials[((size_t)pair * G + g) * kPartStride + kTrialSlot + l];
+    yi[l] = s;
+  }
+  __syncthreads();
+  if (l != 0) return;
+  GicpPairState s = state[pair];
+  bool finished = false;
+  double lam_next = s.lambda, nu = 2.0;
+  for (int t = 0; t < P.lm_max_iterations && !finished; t++) {
+    const LmTrial& tr = trials[(size_t)pair * kMaxTrials + t];
+    double denom = 0;
+    for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - s.b[i]);
+    const double rho = (s.y0 - yi[t]) / denom;
+    s.trial = t;
+    if (rho < 0) {
+      if (!P.force_iterations && is_converged(tr.delta, P.rotation_epsilon, P.transformation_epsilon)) {
+        s.delta = tr.delta;  // step_lm returns true without moving x0 (and without touching lambda)
+        s.lambda = tr.lambda;
+        finish_step(s, P, true);
+        finished = true;
+      } else {
+        lam_next = nu * tr.lambda;
+        nu = 2 * nu;
+      }
+    } else {
+      s.x0 = tr.xi;
+      s.delta = tr.delta;
+      for (int i = 0; i < 6; i++) s.d[i] = tr.d[i];
+      const double c = 2 * rho - 1;
+      s.lambda = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
+      for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
+      s.last_error = yi[t];
+      s.yi = yi[t];
+      finish_step(s, P, true);
+      finished = true;
+    }
+  }
+  if (!finished) {  // every trial rejected: "lm not converged!!"
+    s.lambda = lam_next;
+    finish_step(s, P, false);
+  }
+  state[pair] = s;
 }
 
 __global__ void k_count_active(const GicpPairState* __restrict__ st, int S, int* __restrict__ n_active) {
@@ -507,6 +568,7 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
   GicpDevParams P;
   P.max_iterations = p.max_iterations;
   P.optimizer = p.optimizer;
+  if (p.lm_max_iterations < 1 || p.lm_max_iterations > kMaxTrials) throw ArgError(MI355_EINVAL, "lm_max_iterations must be in [1, 16]");
   P.lm_max_iterations = p.lm_max_iterations;
   P.force_iterations = p.force_iterations;
   P.transformation_epsilon = p.transformation_epsilon;
@@ -578,12 +640,12 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
   const int check_every = p.force_iterations ? 0 : 4;
   for (int it = 0; it < p.max_iterations; it++) {
     launch_linearize(s, gb, src, tgt, P);
-    hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, gb.partials.p, G, P);
+    hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P);
     if (p.optimizer == MI355_OPT_LM) {
-      hipLaunchKernelGGL(k_gicp_error, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                         gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p);
-      hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(kDecideBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                         gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, G, P);
+      auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
+      hipLaunchKernelGGL(ke, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
+                         gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, P.lm_max_iterations);
+      hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P);
     }
     if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
       // early stop: every few iterations ask the device whether any pair is still optimising
@@ -723,7 +785,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   gb.time_kernels = false;
   launch_linearize(s, gb, src, tgt, P);
   gb.time_kernels = tk;
-  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, gb.partials.p, gb.blocks_lin, P);
+  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P);
   MI_LAUNCH_CHECK();
   GicpPairState st;
   MI_HIP(hipMemcpyAsync(&st, gb.state.p, sizeof(st), hipMemcpyDeviceToHost, s));

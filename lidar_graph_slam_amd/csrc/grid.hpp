@@ -395,6 +395,75 @@ struct NearestK {
   }
 };
 
+// Distances of the K nearest only (sorted ascending), maintained by a BRANCH-FREE insertion network: for a sorted list
+// a <= b and a new value c, the new element at that position is median(a, b, c) — one v_med3_f32 per position, executed
+// for every candidate whether it enters the list or not.  Under SIMT that beats a conditional insertion by a wide margin:
+// the conditional version ran its ~170-instruction body whenever ANY of the 64 lanes wanted the candidate (21 % lane
+// utilisation measured); this version has no data-dependent branch inside the candidate loop at all.  The identities of
+// the neighbours are recovered afterwards by one ball query with the (exact) k-th distance — see k_knn_self.
+template <int K>
+struct NearestKD {
+  static constexpr int kScanWidth = 2;
+  int k;
+  float hint;
+  float d2[K];
+  __device__ __forceinline__ void init(int kk) {
+    k = kk;
+    hint = INFINITY;
+    clear();
+  }
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < K; i++) d2[i] = INFINITY;
+  }
+  __device__ __forceinline__ float kth() const {
+    if (k == K) return d2[K - 1];
+    float b = INFINITY;
+#pragma unroll
+    for (int i = 0; i < K; i++)
+      if (i == k - 1) b = d2[i];
+    return b;
+  }
+  __device__ __forceinline__ float bound() const { return fminf(kth(), hint); }
+  __device__ __forceinline__ float complete() const { return kth(); }
+  __device__ __forceinline__ void flush() {}
+  __device__ __forceinline__ void restart() {
+    hint = fminf(hint, kth());
+    clear();
+  }
+  __device__ __forceinline__ void visit(int, float dd) {
+    dd = (dd > hint) ? INFINITY : dd;  // cannot be among the k nearest (ties with the hint are kept)
+#pragma unroll
+    for (int i = K - 1; i > 0; i--) d2[i] = __builtin_amdgcn_fmed3f(d2[i - 1], d2[i], dd);
+    d2[0] = fminf(d2[0], dd);
+  }
+};
+
+// Collects the indices of the points within a known k-th distance tau2: everything strictly closer, plus as many of the
+// points AT tau2 as are needed to make k, lowest caller index first (the oracle's tie rule).
+struct BallCollector {
+  static constexpr int kScanWidth = 2;
+  const int* orig;
+  int* out;       // k slots
+  int k;
+  float tau2;
+  int n_lt, n_eq; // strictly closer / exactly at tau2
+  int eq_first;   // first point seen at tau2
+  __device__ __forceinline__ float bound() const { return tau2; }
+  __device__ __forceinline__ float complete() const { return tau2; }
+  __device__ __forceinline__ void flush() {}
+  __device__ __forceinline__ void restart() {}
+  __device__ __forceinline__ void visit(int j, float dd) {
+    if (dd < tau2) {
+      if (n_lt < k) out[n_lt] = j;
+      n_lt++;
+    } else if (dd == tau2) {
+      if (n_eq == 0) eq_first = j;
+      n_eq++;
+    }
+  }
+};
+
 // NearestK with an LDS staging queue.  The sorted insertion is ~170 instructions; under SIMT a wave executes it for a
 // candidate whenever ANY of its 64 lanes wants that candidate, i.e. for almost every candidate.  Here a lane only appends
 // (d2, j) of candidates that beat its current worst to a small private queue in LDS; the queues are drained together —

