@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE.json configs that are not the headline bench line (they are parity-test shapes; these numbers
+go into DESIGN.md / profiles, not into bench.py's JSON):
+
+  config 2  single 64 k-pt pair, voxel 0.2 m + GICP 20 iterations, latency of one registration object
+  config 3  NDT: 64 k-pt scan vs ~1 M-pt sub-map, 1.0 m cells
+  config 4  KITTI-shaped stream through ScanMatcherCore (scan-to-keyframe), scans/s and end-point drift
+  config 5  loop-closure batch: many candidate scans against shared sub-maps (0.5 m voxel), GICP + fitness
+
+usage: python benchmarks/other_configs.py [--scans 40] [--cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lidar_graph_slam_amd import _lib as L  # noqa: E402
+from lidar_graph_slam_amd import synth  # noqa: E402
+from lidar_graph_slam_amd.filters import PointsPreFiltering  # noqa: E402
+from lidar_graph_slam_amd.registration import BatchRegistration, FastGICP, NormalDistributionsTransform  # noqa: E402
+from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher  # noqa: E402
+
+
+def timed(f, reps=5, warm=2):
+    for _ in range(warm):
+        f()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        f()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=40)
+    ap.add_argument("--cpu", action="store_true", help="also time the oracle (CPU) where it is cheap enough")
+    args = ap.parse_args()
+    out = {}
+    scene = synth.Scene(1234)
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+
+    # ---- config 2: single pair latency (host buffers in, pose out)
+    src, tgt, T = synth.make_pair()
+    s, t = pre.callback_sensor_points(src), pre.callback_sensor_points(tgt)
+    reg = FastGICP(max_iterations=20, force_iterations=1)
+
+    def one_pair():
+        reg.setInputTarget(t)
+        reg.setInputSource(s)
+        reg.align()
+
+    med, mn = timed(one_pair)
+    out["config2_single_pair"] = {"ms_median": med * 1e3, "ms_min": mn * 1e3, "n_src": len(s), "n_tgt": len(t),
+                                  "pose_err_vs_truth": synth.pose_error(reg.getFinalTransformation(), T)}
+    med, mn = timed(lambda: pre.callback_sensor_points(src))
+    out["prefilter_64k_voxel0.2"] = {"ms_median": med * 1e3}
+    pre_full = PointsPreFiltering(leaf_size=0.1, mean_k=30, stddev=1.2, min_distance_cloud=1.0)
+    med, mn = timed(lambda: pre_full.callback_sensor_points(src))
+    out["prefilter_64k_reference_defaults(leaf0.1,sor30)"] = {"ms_median": med * 1e3, "n_out": len(pre_full.callback_sensor_points(src))}
+
+    # ---- config 3: NDT vs ~1 M-point sub-map, 1.0 m cells
+    poses = [synth.se3(1.0 * i, 0.02 * i, 0, 0, 0, 0.002 * i) for i in range(16)]
+    casts = [synth.cast_scan(scene, P, seed=200 + i) for i, P in enumerate(poses)]
+    sub = np.concatenate([synth_transform(c, P) for c, P in zip(casts, poses)], axis=0)
+    sub = sub[np.abs(sub[:, :3]).sum(1) > 0]
+    T_true = synth.se3(7.5, 0.15, 0, 0, 0, 0.015)
+    scan = synth.cast_scan(scene, T_true, seed=999)
+    scan = scan[np.abs(scan[:, :3]).sum(1) > 0]
+    guess = synth.se3(7.2, 0.1, 0, 0, 0, 0.01).astype(np.float32)
+    ndt = NormalDistributionsTransform(resolution=1.0)
+    t0 = time.perf_counter()
+    ndt.setInputTarget(sub)
+    t_build = time.perf_counter() - t0
+    ndt.setInputSource(scan)
+    med, mn = timed(lambda: ndt.align(guess), reps=5, warm=1)
+    out["config3_ndt_1M_submap"] = {"target_points": len(sub), "source_points": len(scan), "set_target_ms": t_build * 1e3, "align_ms_median": med * 1e3,
+                                    "iterations": ndt.result["iterations"], "pose_err_vs_truth": synth.pose_error(ndt.getFinalTransformation(), T_true)}
+    if args.cpu:
+        from oracle import oracle_py as O
+        t0 = time.perf_counter()
+        r = O.ndt_align(scan, sub, O.ndt_params(resolution=1.0), guess=guess)
+        out["config3_ndt_1M_submap"]["cpu_ms"] = (time.perf_counter() - t0) * 1e3
+        out["config3_ndt_1M_submap"]["gpu_vs_cpu"] = synth.pose_error(ndt.getFinalTransformation(), r["T"])
+
+    # ---- config 4: stream through ScanMatcherCore
+    n = args.scans
+    traj = synth.trajectory(n, seed=3)
+    scans = [pre.callback_sensor_points(synth.cast_scan(scene, traj[i], seed=300 + i)) for i in range(n)]
+    for method in ("FAST_GICP", "NDT_OMP"):
+        sm = LidarScanMatcher(registration_method=method)
+        t0 = time.perf_counter()
+        last = None
+        n_kf = 0
+        for sc in scans:
+            o = sm.callback_cloud(sc)
+            n_kf += o["new_key_frame"]
+            if o["converged"]:
+                last = o
+        dt = time.perf_counter() - t0
+        gt = np.linalg.inv(traj[0]) @ traj[n - 1]
+        out[f"config4_stream_{method}"] = {"scans": n, "scans_per_s": n / dt, "ms_per_scan": dt / n * 1e3, "key_frames": n_kf,
+                                          "target_points_end": last["target_points"] if last else 0,
+                                          "end_pose_err_vs_truth": synth.pose_error(last["pose"], gt) if last else None}
+
+    # ---- config 5: loop-closure batch with shared sub-maps
+    n_sub, n_cand = 8, 64
+    subs, counts_t = [], []
+    rng = np.random.default_rng(5)
+    for k in range(n_sub):
+        base = 20.0 * k
+        parts = []
+        for j in range(-2, 3):
+            P = synth.se3(base + 1.0 * j, 0.0, 0, 0, 0, 0.0)
+            c = synth.cast_scan(scene, P, seed=500 + 10 * k + j)
+            c = c[np.abs(c[:, :3]).sum(1) > 0]
+            parts.append(synth_transform(c, P))
+        subs.append(np.concatenate(parts, axis=0))
+    cap = max(max(len(x) for x in subs), 65536)
+    tg = np.zeros((n_sub, cap, 4), np.float32)
+    for k, x in enumerate(subs):
+        tg[k, : len(x)] = x
+        counts_t.append(len(x))
+    sr = np.zeros((n_cand, cap, 4), np.float32)
+    counts_s, tgt_of_src, truth = [], [], []
+    for i in range(n_cand):
+        k = i % n_sub
+        P = synth.se3(20.0 * k, 0, 0) @ synth.random_perturbation(rng, 1.0, 2.0)
+        c = synth.cast_scan(scene, P, seed=900 + i)
+        c = c[np.abs(c[:, :3]).sum(1) > 0]
+        cm = synth_transform(c, synth.se3(20.0 * k, 0, 0))  # candidate placed at its (wrong) graph pose: truth = P * inv(graph pose)
+        sr[i, : len(cm)] = cm
+        counts_s.append(len(cm))
+        tgt_of_src.append(k)
+        truth.append(P @ np.linalg.inv(synth.se3(20.0 * k, 0, 0)))
+    b = BatchRegistration(n_cand, n_sub, cap, max_iterations=64)
+    vox = L.prefilter_params(min_distance=0.0, leaf_size=0.5, mean_k=0)  # graph_based_slam.cpp:61,311-313
+
+    def batch():
+        b.set_targets(tg, counts_t, vox)
+        b.set_sources(sr, counts_s, None)
+        b.align(tgt_of_src, with_fitness=True)
+        return b.results(with_fitness=True)
+
+    med, mn = timed(batch, reps=3, warm=1)
+    res, fit = batch()
+    errs = np.array([synth.pose_error(r["T"], truth[i]) for i, r in enumerate(res)])
+    acc = np.array([r["converged"] and f < 0.3 for r, f in zip(res, fit)])
+    out["config5_loop_closure_batch"] = {"candidates": n_cand, "submaps": n_sub, "ms_median": med * 1e3, "pairs_per_s": n_cand / med,
+                                         "accepted(fitness<0.3)": int(acc.sum()), "median_pose_err_m": float(np.median(errs[:, 0])),
+                                         "mean_iterations": float(np.mean([r["iterations"] for r in res]))}
+    print(json.dumps(out, indent=1, default=lambda o: list(o) if isinstance(o, tuple) else float(o)))
+
+
+def synth_transform(c, P):
+    o = c.copy()
+    o[:, :3] = (c[:, :3].astype(np.float64) @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+    return o
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+// TEST INFRASTRUCTURE: compiles the PRODUCT's shared host/device maths header (lidar_graph_slam_amd/csrc/devmath.hpp)
+// with g++ so that the CPU suite can check it against the oracle / NumPy without a GPU.  Never shipped.
+#include "../lidar_graph_slam_amd/csrc/devmath.hpp"
+
+using namespace mi355;
+
+extern "C" {
+void hm_se3_exp(const double* d, double* T16) {
+  const Pose p = se3_exp(d);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) T16[4 * r + c] = p.R[3 * r + c];
+    T16[4 * r + 3] = p.t[r];
+  }
+  T16[12] = T16[13] = T16[14] = 0;
+  T16[15] = 1;
+}
+int hm_ldlt6(const double* A, const double* rhs, double* x) { return ldlt6_solve(A, rhs, x) ? 1 : 0; }
+void hm_svd6(const double* H, const double* rhs, double* x) { svd6_solve_sym(H, rhs, x); }
+void hm_regularize(const double* cov6, int method, double* out6) {
+  const Sym3<double> c = {cov6[0], cov6[1], cov6[2], cov6[3], cov6[4], cov6[5]};
+  const Sym3<double> r = regularize_covariance(c, method);
+  out6[0] = r.xx; out6[1] = r.xy; out6[2] = r.xz; out6[3] = r.yy; out6[4] = r.yz; out6[5] = r.zz;
+}
+void hm_sym3_inverse_f(const float* a6, float* out6) {
+  const Sym3<float> a = {a6[0], a6[1], a6[2], a6[3], a6[4], a6[5]};
+  const Sym3<float> r = sym3_inverse(a);
+  out6[0] = r.xx; out6[1] = r.xy; out6[2] = r.xz; out6[3] = r.yy; out6[4] = r.yz; out6[5] = r.zz;
+}
+void hm_sym3_rotate_f(const float* R9, const float* c6, float* out6) {
+  const Sym3<float> c = {c6[0], c6[1], c6[2], c6[3], c6[4], c6[5]};
+  const Sym3<float> r = sym3_rotate(R9, c);
+  out6[0] = r.xx; out6[1] = r.xy; out6[2] = r.xz; out6[3] = r.yy; out6[4] = r.yz; out6[5] = r.zz;
+}
+int hm_is_converged(const double* T16, double rot_eps, double trans_eps) {
+  Pose p;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) p.R[3 * r + c] = T16[4 * r + c];
+    p.t[r] = T16[4 * r + 3];
+  }
+  return is_converged(p, rot_eps, trans_eps) ? 1 : 0;
+}
+float hm_dist2f(const float* q, const float* p) { return dist2f(q[0], q[1], q[2], p[0], p[1], p[2]); }
+}

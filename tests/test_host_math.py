@@ -1,0 +1,115 @@
+"""CPU tests of the PRODUCT's host/device maths header (csrc/devmath.hpp compiled with g++): se3_exp, pivoted LDL^T, the
+symmetric 6x6 SVD solve, covariance regularisation, fp32 3x3 helpers — against SciPy / NumPy / the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hm") / "libhost_math.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           "-o", out, os.path.join(ROOT, "tests", "host_math_harness.cpp")])
+    lib = C.CDLL(out)
+    lib.hm_dist2f.restype = C.c_float
+    lib.hm_is_converged.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_se3_exp(hm):
+    rng = np.random.default_rng(0)
+    for scale in (1e-8, 1e-4, 0.2, 2.0):
+        d = rng.normal(size=6) * scale
+        T = np.empty(16)
+        hm.hm_se3_exp(_p(d), _p(T))
+        A = np.zeros((4, 4))
+        A[:3, :3] = [[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]]
+        A[:3, 3] = d[3:]
+        np.testing.assert_allclose(T.reshape(4, 4), expm(A), atol=1e-12)
+
+
+def test_ldlt6_and_svd6(hm):
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        J = rng.normal(size=(40, 6)) * rng.uniform(0.01, 100, 6)
+        H = np.ascontiguousarray(J.T @ J)
+        b = rng.normal(size=6)
+        x = np.empty(6)
+        assert hm.hm_ldlt6(_p(H), _p(b), _p(x)) == 1
+        np.testing.assert_allclose(x, np.linalg.solve(H, b), rtol=1e-8)
+        hm.hm_svd6(_p(H), _p(b), _p(x))
+        np.testing.assert_allclose(x, np.linalg.solve(H, b), rtol=1e-7)
+    Z = np.zeros((6, 6))
+    x = np.full(6, 7.0)
+    assert hm.hm_ldlt6(_p(Z), _p(np.ones(6)), _p(x)) == 0 and not x.any()  # singular -> zero step, like Eigen's LDLT
+    # indefinite symmetric (NDT Hessians are): the SVD solve is the plain inverse
+    S = rng.normal(size=(6, 6))
+    S = np.ascontiguousarray(S + S.T)
+    b = rng.normal(size=6)
+    hm.hm_svd6(_p(S), _p(b), _p(x))
+    np.testing.assert_allclose(x, np.linalg.solve(S, b), rtol=1e-8)
+
+
+@pytest.mark.parametrize("method,name", [(0, "NONE"), (1, "MIN_EIG"), (2, "NORMALIZED_MIN_EIG"), (3, "PLANE"), (4, "FROBENIUS")])
+def test_regularisation_vs_numpy(hm, method, name):
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        P = rng.normal(size=(20, 3)) * rng.uniform(0.01, 1.0, 3)
+        c = np.cov(P.T, bias=True)
+        c6 = np.array([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
+        out = np.empty(6)
+        hm.hm_regularize(_p(c6), method, _p(out))
+        got = np.array([[out[0], out[1], out[2]], [out[1], out[3], out[4]], [out[2], out[4], out[5]]])
+        if name == "NONE":
+            ref = c
+        elif name == "FROBENIUS":
+            Ci = np.linalg.inv(c + 1e-3 * np.eye(3))
+            ref = np.linalg.inv(Ci / np.linalg.norm(Ci))
+        else:
+            U, s, Vt = np.linalg.svd(c)
+            vals = {"PLANE": np.array([1, 1, 1e-3]), "MIN_EIG": np.maximum(s, 1e-3), "NORMALIZED_MIN_EIG": np.maximum(s / s.max(), 1e-3)}[name]
+            ref = U @ np.diag(vals) @ Vt
+        np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11)
+
+
+def test_fp32_helpers_and_specified_rounding(hm):
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(3, 3)).astype(np.float32)
+    S = a @ a.T + np.eye(3, dtype=np.float32)
+    s6 = np.array([S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]], dtype=np.float32)
+    out = np.empty(6, dtype=np.float32)
+    hm.hm_sym3_inverse_f(_p(s6), _p(out))
+    inv = np.linalg.inv(S.astype(np.float64))
+    np.testing.assert_allclose(out, [inv[0, 0], inv[0, 1], inv[0, 2], inv[1, 1], inv[1, 2], inv[2, 2]], rtol=2e-5)
+    R = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+    hm.hm_sym3_rotate_f(_p(np.ascontiguousarray(R.reshape(9))), _p(s6), _p(out))
+    ref = R.astype(np.float64) @ S.astype(np.float64) @ R.astype(np.float64).T
+    np.testing.assert_allclose(out, [ref[0, 0], ref[0, 1], ref[0, 2], ref[1, 1], ref[1, 2], ref[2, 2]], rtol=2e-5, atol=2e-6)
+    # dist2f is the specified fmaf(dz,dz, fmaf(dy,dy, dx*dx)): bit-equal to the oracle's k-NN distances
+    from oracle import oracle_py as O
+    pts = rng.uniform(-50, 50, (64, 4)).astype(np.float32)
+    q = rng.uniform(-50, 50, (1, 4)).astype(np.float32)
+    idx, d2 = O.knn(pts, q, 64, brute_force=True)
+    mine = np.array([hm.hm_dist2f(_p(np.ascontiguousarray(q[0])), _p(np.ascontiguousarray(pts[j]))) for j in idx[0]], dtype=np.float32)
+    np.testing.assert_array_equal(mine, d2[0])
+
+
+def test_is_converged(hm):
+    T = np.eye(4)
+    T[0, 3] = 0.009
+    assert hm.hm_is_converged(_p(np.ascontiguousarray(T.reshape(16))), 2e-3, 0.01) == 1
+    T[0, 3] = 0.011
+    assert hm.hm_is_converged(_p(np.ascontiguousarray(T.reshape(16))), 2e-3, 0.01) == 0
+    T[0, 3] = 0
+    T[0, 1], T[1, 0] = -0.0025, 0.0025
+    assert hm.hm_is_converged(_p(np.ascontiguousarray(T.reshape(16))), 2e-3, 0.01) == 0
