@@ -234,7 +234,7 @@ struct NextEq {
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_self(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
                                                   const GridMeta* __restrict__ meta, int* __restrict__ nbr, size_t cap, size_t slots_cap, int k, int G,
-                                                  int B) {
+                                                  int B, int need_div) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_knn_self(const float4* __restrict__ pts
   {
     NearestKD<K> nk;
     nk.init(k);
-    grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k), 1);
+    grid_search(g, q.x, q.y, q.z, INFINITY, nk, knn_start_level(g, q.x, q.y, q.z, k, need_div), 1);
     tau2 = nk.kth();
   }
   if (!(tau2 < INFINITY)) {  // fewer than k points in the whole cloud (the API rejects this; keep the lists defined)
@@ -311,7 +311,7 @@ template <int K>
 static void launch_knn_self(hipStream_t s, CloudSet& set, int k) {
   const int G = div_up((long)set.cap, 256);
   hipLaunchKernelGGL(k_knn_self<K>, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p, set.cap,
-                     set.slots_cap, k, G, set.B);
+                     set.slots_cap, k, G, set.B, getenv("MI355_KNN_NEED_DIV") ? atoi(getenv("MI355_KNN_NEED_DIV")) : 2);
 }
 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {

@@ -403,7 +403,7 @@ struct NearestK {
 // the neighbours are recovered afterwards by one ball query with the (exact) k-th distance — see k_knn_self.
 template <int K>
 struct NearestKD {
-  static constexpr int kScanWidth = 2;
+  static constexpr int kScanWidth = 8;
   int k;
   float hint;
   float d2[K];
@@ -442,7 +442,7 @@ struct NearestKD {
 // Collects the indices of the points within a known k-th distance tau2: everything strictly closer, plus as many of the
 // points AT tau2 as are needed to make k, lowest caller index first (the oracle's tie rule).
 struct BallCollector {
-  static constexpr int kScanWidth = 2;
+  static constexpr int kScanWidth = 8;
   const int* orig;
   int* out;       // k slots
   int k;
@@ -503,12 +503,12 @@ struct NearestKQ : NearestK<K> {
 
 // Level at which a k-NN query of a point of the cloud itself should start: the finest level whose own cell already
 // holds about k/3 points (then shells r <= 1 almost always suffice).  Only a speed heuristic — any level is exact.
-__device__ __forceinline__ int knn_start_level(const GridView& g, float qx, float qy, float qz, int k) {
+__device__ __forceinline__ int knn_start_level(const GridView& g, float qx, float qy, float qz, int k, int need_div = 3) {
   const GridMeta& m = g.m;
   const int bx = min(max((int)floorf(cell_coord(qx, m.ox, m.inv_cell)), 0), m.dx - 1);
   const int by = min(max((int)floorf(cell_coord(qy, m.oy, m.inv_cell)), 0), m.dy - 1);
   const int bz = min(max((int)floorf(cell_coord(qz, m.oz, m.inv_cell)), 0), m.dz - 1);
-  const int need = max(1, k / 3);
+  const int need = max(1, k / need_div);
   int l = 0;
   for (; l < m.top_level; l++)
     if (own_cell_count(g, bx, by, bz, l) >= need) break;
