@@ -3,6 +3,7 @@
 #include "engine.hpp"
 #include "grid.hpp"
 #include "primitives.hpp"
+#include "tile.hpp"
 
 namespace mi355 {
 
@@ -234,11 +235,15 @@ struct NextEq {
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_self(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
                                                   const GridMeta* __restrict__ meta, int* __restrict__ nbr, size_t cap, size_t slots_cap, int k, int G,
-                                                  int B, int need_div) {
+                                                  int B, int need_div, const int* __restrict__ queue, const int* __restrict__ queue_n) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
-  const int i = bx * blockDim.x + threadIdx.x;
+  int i = bx * blockDim.x + threadIdx.x;
+  if (queue) {  // only the points the tile search handed over
+    if (i >= queue_n[c]) return;
+    i = queue[(size_t)c * cap + i];
+  }
   if (i >= g.m.n) return;
   const float4 q = g.pts[i];
   int* o = nbr + ((size_t)c * cap + i) * k;
@@ -273,59 +278,402 @@ __global__ __launch_bounds__(256) void k_knn_self(const float4* __restrict__ pts
   for (; filled < k; filled++) o[filled] = -1;
 }
 
-// Step 2: neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation, 2 x float4 per point.
-__global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, const int* __restrict__ nbr,
-                                                      float4* __restrict__ cov, size_t cap, int k, int method, int G, int B) {
-  int c, bx;
-  if (!xcd_item_chunk(G, B, c, bx)) return;
-  const int n = meta[c].n;
-  const int i = bx * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4* p0 = pts + (size_t)c * cap;
-  const int* nb = nbr + ((size_t)c * cap + i) * k;
+#ifdef MI355_TILE_STATS  // debug build only: per-tile counters and a per-wave timeline (benchmarks/_tile_stats.py)
+__device__ unsigned long long g_tile_stats[16];
+extern "C" void mi355_debug_tile_stats(unsigned long long* out) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stats), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stats), z, sizeof(z));
+}
+__device__ unsigned long long g_tile_log[1 << 20];
+__device__ unsigned int g_tile_log_n;
+extern "C" unsigned mi355_debug_tile_log(unsigned long long* out, unsigned max_entries) {
+  unsigned n = 0;
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tile_log_n), sizeof(n));
+  if (n > max_entries) n = max_entries;
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_log), sizeof(unsigned long long) * 4 * max_entries);
+  unsigned z = 0;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_tile_log_n), &z, sizeof(z));
+  return n;
+}
+#define TILE_STAT(i, v) do { if (lane_id() == 0) atomicAdd(&g_tile_stats[i], (unsigned long long)(v)); } while (0)
+#define TILE_STAT_MAX(i, v) do { if (lane_id() == 0) atomicMax(&g_tile_stats[i], (unsigned long long)(v)); } while (0)
+#endif
+
+// Neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation; point(t) returns the t-th neighbour.
+template <typename P>
+__device__ __forceinline__ void covariance_of(int k, int method, float4* o, P&& point) {
   double mx = 0, my = 0, mz = 0;
-  for (int j = 0; j < k; j++) {
-    const int t = nb[j];
-    if (t < 0) continue;
-    const float4 p = p0[t];
+  for (int t = 0; t < k; t++) {
+    const float4 p = point(t);
     mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
   }
   const double invk = 1.0 / (double)k;
   mx *= invk; my *= invk; mz *= invk;
   Sym3<double> cv = {0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < k; j++) {
-    const int t = nb[j];
-    if (t < 0) continue;
-    const float4 p = p0[t];
+  for (int t = 0; t < k; t++) {
+    const float4 p = point(t);
     const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
     cv.xx += x * x; cv.xy += x * y; cv.xz += x * z; cv.yy += y * y; cv.yz += y * z; cv.zz += z * z;
   }
   cv.xx *= invk; cv.xy *= invk; cv.xz *= invk; cv.yy *= invk; cv.yz *= invk; cv.zz *= invk;
   const Sym3<double> r = regularize_covariance(cv, method);
-  float4* o = cov + ((size_t)c * cap + i) * 2;
   o[0] = make_float4((float)r.xx, (float)r.xy, (float)r.xz, (float)r.yy);
   o[1] = make_float4((float)r.yz, (float)r.zz, 0.f, 0.f);
 }
 
+// Steps 1+2, fast path: k-NN and covariance of every point by the wave-cooperative tile search (tile.hpp).  One wave =
+// 64 consecutive points of the Morton-sorted cloud.  The points of the grown tile box are gathered into LDS and walked by
+// every lane through a (k+2)-deep key network; a key is the squared distance with the candidate's list position in the
+// low kOrdBits mantissa bits, so the k smallest keys ARE the neighbour list and the covariance is computed straight from
+// the LDS copies of those points.  The box radius starts from the tile's own point density and grows until it covers the
+// k-th distance of every lane (each round gathers only the shell that is new).
+// A lane's list is exact when (1) the covered radius reaches its k-th distance and (2) its k-th and (k+1)-th keys differ in
+// the distance bits that are left, i.e. truncation cannot have swapped a neighbour with a non-neighbour.  When exactly
+// two candidates share the k-th truncated distance (~1 % of the points) the pair is ranked with the full distances; longer
+// runs, lanes whose neighbourhood does not fit the candidate list and far-field points go to the fallback queue and are
+// done by k_knn_hard + k_cov_from_knn.  A tile whose own box is too large (it straddles a jump of the Morton curve, or lies
+// in the sparse far field) is split into halves, processed one after the other by the whole wave.
+constexpr int kOrdBits = 10;
+constexpr int kTileMaxCand = 1 << kOrdBits;  // candidates per tile segment (list positions)
+constexpr uint32_t kOrdMask = kTileMaxCand - 1;
+constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
+
+// Launch: one-wave blocks, G per cloud (all on the cloud's XCD); a wave takes tiles from the cloud's counter until none
+// is left, so the waves of a cloud finish together whatever the tiles cost.
 template <int K>
-static void launch_knn_self(hipStream_t s, CloudSet& set, int k) {
+__global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
+                                                     const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
+                                                     float4* __restrict__ cov, int* __restrict__ queue, int* __restrict__ queue_n,
+                                                     int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k, int method, int G, int B) {
+  __shared__ float4 cand[kTileMaxCand];  // this wave's candidate list (x, y, z, sorted index)
+  int c, bx;
+  if (!xcd_item_chunk(G, B, c, bx)) return;
+  const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
+  const int n = g.m.n;
+  const int lane = lane_id();
+  for (;;) {
+  int tile = 0;
+  if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
+  const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
+  if (tile0 >= n) return;
+#ifdef MI355_TILE_STATS
+  const unsigned long long t_start = wall_clock64();
+  int n_a = 0, n_rounds = 0, n_segs = 0;
+  unsigned long long t_cells = 0, t_gather = 0, t_rank = 0, t_tmp;
+#endif
+  const int i = tile0 + lane;
+  const bool valid = i < n;
+  const float4 q = g.pts[min(i, n - 1)];
+  const float rcap = 16.f * g.m.cell, rmin = 0.6f * g.m.cell;
+  bool fb = false;  // this lane goes to the fallback queue
+  int seg = 0, len = kWave;
+  while (seg < kWave) {
+    const bool act = valid && lane >= seg && lane < seg + len;
+    const int nact = __popcll(__ballot(act));
+    bool split = false;
+    if (nact > 0) {
+      const TileBox bb = tile_bounds(act, q.x, q.y, q.z);
+      const float eps = tile_eps(bb, rcap);
+      float r, e_max;  // first radius: k-NN radius of a surface with the segment's own point density
+      {
+        const float ex = bb.hx - bb.lx, ey = bb.hy - bb.ly, ez = bb.hz - bb.lz;
+        const float e_min = fminf(fminf(ex, ey), ez);
+        e_max = fmaxf(fmaxf(ex, ey), ez);
+        const float e_mid = ex + ey + ez - e_min - e_max;
+        const float area = fmaxf(e_max * e_mid, 0.16f * g.m.cell * g.m.cell);
+        r = fminf(fmaxf(sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
+      }
+      SmallestKeys<K + 2> keys;
+      keys.init();
+      int n_ord = 0;
+      TileBox ob = bb;
+      bool has_old = false, open = act;
+#ifdef MI355_TILE_STATS
+      n_segs++;
+#endif
+      for (int round = 0;; round++) {
+        const TileBox nb = grow(bb, r);
+#ifdef MI355_TILE_STATS
+        t_tmp = wall_clock64();
+#endif
+        const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
+#ifdef MI355_TILE_STATS
+        t_cells += wall_clock64() - t_tmp; t_tmp = wall_clock64();
+#endif
+        const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
+#ifdef MI355_TILE_STATS
+        t_gather += wall_clock64() - t_tmp; t_tmp = wall_clock64();
+        n_rounds++;
+#endif
+        if (n_new < 0) {  // over a budget: split the segment if nothing has been ranked yet, else hand the open lanes over
+          if (round == 0 && r > rmin && r > 0.5f * e_max) {
+            // clustered points (far field): the density guess overshoots and the radius, not the segment's own extent,
+            // makes the box too big - start smaller, the rounds grow it back where needed
+            r = fmaxf(0.5f * r, rmin);
+            round = -1;
+            continue;
+          }
+          if (round == 0 && len > 8) split = true;
+          else {
+            fb = fb || open;
+#ifdef MI355_TILE_STATS
+            { const int cnt = __popcll(__ballot(open)); TILE_STAT(round == 0 ? 10 : 11, cnt); if (!cells.ok) TILE_STAT(15, cnt); }
+#endif
+          }
+          break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
+#pragma unroll 4
+        for (int o = n_ord; o < n_new; o++) {
+          const float4 p = cand[o];
+          const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+          keys.insert((d & ~kOrdMask) | (uint32_t)o);
+        }
+        n_ord = n_new;
+#ifdef MI355_TILE_STATS
+        t_rank += wall_clock64() - t_tmp;
+#endif
+        const float rs = r * 0.9999f - eps;  // every point within rs of a query of the segment has been seen
+        const uint32_t kk = keys.at(k - 1);
+        const bool full = kk != SmallestKeys<K + 2>::kEmpty;
+        const float ub = __uint_as_float(kk | kOrdMask);  // >= the exact k-th squared distance
+        open = act && !(full && ub <= rs * rs);
+        if (!__any(open)) break;
+        // next radius: what the open lanes ask for; lanes asking for much more wait for a later round
+        const float need = open ? (full ? sqrtf(ub) * 1.001f + 2.f * eps : 2.f * r) : 0.f;
+        const float near = wave_max_all((open && need <= 2.f * r) ? need : 0.f);
+        const float far = wave_min_all((open && need > 2.f * r) ? need : INFINITY);
+        float want = (near > 0.f) ? near : far;
+        want = fminf(fmaxf(want, 1.02f * r), rcap);
+        if (!(want > r) || round >= 4) {
+          fb = fb || open;
+#ifdef MI355_TILE_STATS
+          { const int cnt = __popcll(__ballot(open)); TILE_STAT(round >= 4 ? 12 : 13, cnt); }
+#endif
+          break;
+        }
+        ob = nb;
+        has_old = true;
+        r = uniform_f(want);
+      }
+      if (!split) {
+        // closed lanes: exact unless truncation could have swapped the k-th and (k+1)-th candidates (or they tie exactly)
+        const uint32_t kk = keys.at(k - 1), kn = keys.at(k);
+        const uint32_t tk = kk >> kOrdBits;
+        const bool closed = act && !open && !fb;
+        const bool clear = tk < (kn >> kOrdBits);
+        // exactly two candidates share the k-th truncated distance: rank the pair exactly (ties: lower caller index)
+        const bool pair = closed && !clear && tk < (keys.at(k + 1) >> kOrdBits) && (k < 2 || (keys.at(k - 2) >> kOrdBits) < tk);
+        if (pair) {
+          const float4 a = cand[kk & kOrdMask], b = cand[kn & kOrdMask];
+          const float da = dist2f(q.x, q.y, q.z, a.x, a.y, a.z), db = dist2f(q.x, q.y, q.z, b.x, b.y, b.z);
+          if (db < da || (db == da && g.orig[__float_as_int(b.w)] < g.orig[__float_as_int(a.w)])) {
+#pragma unroll
+            for (int t = 0; t < K; t++)
+              if (t == k - 1) keys.v[t] = kn;
+          }
+        }
+        const bool exact = closed && (clear || pair);
+#ifdef MI355_TILE_STATS
+        { const int cnt = __popcll(__ballot(closed && !exact)); TILE_STAT(14, cnt); }
+#endif
+        fb = fb || (act && !exact);
+        if (exact) covariance_of(k, method, cov + ((size_t)c * cap + i) * 2, [&](int t) { return cand[keys.at(t) & kOrdMask]; });
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the list
+#ifdef MI355_TILE_STATS
+        n_a += n_ord;
+#endif
+      }
+    }
+    if (split) {
+      len >>= 1;
+    } else {
+      seg += len;
+      len = seg & -seg;
+    }
+  }
+#ifdef MI355_TILE_STATS
+  TILE_STAT(0, 1); TILE_STAT(1, n_a); TILE_STAT(2, n_rounds); TILE_STAT(3, n_segs); TILE_STAT_MAX(4, n_a);
+  if (lane == 0) {
+    const unsigned slot = atomicAdd(&g_tile_log_n, 1u);
+    if (slot < (1u << 18)) {
+      g_tile_log[4 * slot] = t_start; g_tile_log[4 * slot + 1] = wall_clock64();
+      g_tile_log[4 * slot + 2] = (t_cells << 42) | (t_gather << 21) | t_rank; g_tile_log[4 * slot + 3] = ((unsigned long long)n_a << 32) | (unsigned)n_rounds;
+    }
+  }
+  const int n_fb_stat = __popcll(__ballot(fb));
+  TILE_STAT(8, n_fb_stat);
+#endif
+  const unsigned long long fm = __ballot(fb);
+  if (fm) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&queue_n[c], __popcll(fm));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (fb) queue[(size_t)c * cap + base + __popcll(fm & ((1ull << lane) - 1ull))] = i;
+  }
+  }  // next tile
+}
+
+// Fallback for the few points the tile kernel hands over (isolated far-field points whose k-th neighbour is tens of
+// metres away, exact distance ties, truncation-ambiguous lists): ONE WAVE PER QUERY, the candidates spread over the lanes.
+// A per-lane search would walk thousands of points serially for such a query (0.7 ms measured, longer than the whole
+// tile kernel); here the wave scans the cells of a box around the query 64 points at a time, every lane keeps the k best of
+// its own share in exact (distance, caller index) order, and the 64 lists are merged by k wave-wide arg-min steps.
+// The box grows until it covers the k-th distance found, so the result is the exact k-NN with the oracle's tie rule.
+template <int K>
+__global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+                                                 const GridMeta* __restrict__ meta, int* __restrict__ nbr, const int* __restrict__ queue,
+                                                 const int* __restrict__ queue_n, size_t cap, size_t slots_cap, int k, int G, int B) {
+  int c, bx;
+  if (!xcd_item_chunk(G, B, c, bx)) return;
+  const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
+  const int n = g.m.n;
+  const int lane = lane_id();
+  const int nq = queue_n[c];
+  for (int t = bx; t < nq; t += G) {
+    const int i = queue[(size_t)c * cap + t];
+    const float4 q = g.pts[i];
+    int* o = nbr + ((size_t)c * cap + i) * k;
+    if (n < k) {  // the API rejects this; keep the list defined
+      for (int u = lane; u < k; u += kWave) o[u] = -1;
+      continue;
+    }
+    const TileBox qb{q.x, q.y, q.z, q.x, q.y, q.z};
+    const float eps = tile_eps(qb, 0.f);
+    float r = 2.f * g.m.cell;
+    NearestK<K> nk;
+#ifdef MI355_TILE_STATS
+    const unsigned long long t_start = wall_clock64();
+    int n_rounds = 0, n_scanned = 0;
+#endif
+    for (;;) {
+#ifdef MI355_TILE_STATS
+      n_rounds++;
+#endif
+      // candidates: the cells of the box q +- r, or the whole cloud once the box outgrows 64 top-level cells
+      const TileCells cells = tile_cells(g, grow(qb, r), 0x7fffffff);
+      const bool whole = !cells.ok;
+      if (!whole && cells.total < k) { r *= 2.f; continue; }
+      nk.init(g.orig, k);
+      if (whole) {
+        for (int j = lane; j < n; j += kWave) {
+          const float4 p = g.pts[j];
+          nk.visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+        }
+      } else {
+        unsigned long long todo = __ballot(cells.ce > cells.cs);
+        while (todo) {
+          const int cl = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int s0 = __builtin_amdgcn_readlane(cells.cs, cl), e0 = __builtin_amdgcn_readlane(cells.ce, cl);
+          for (int j = s0 + lane; j < e0; j += kWave) {
+            const float4 p = g.pts[j];
+            nk.visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+          }
+        }
+      }
+      // merge: k times, the smallest head of the 64 sorted lists (ties: lowest caller index)
+      int head = 0, mine = -1;  // lane u < k ends up holding the u-th neighbour in `mine`
+      float kth = INFINITY;
+      for (int u = 0; u < k; u++) {
+        float hd = INFINITY;
+        int hj = -1;
+#pragma unroll
+        for (int v = 0; v < K; v++)
+          if (v == head) { hd = nk.d2[v]; hj = nk.idx[v]; }
+        const float best = uniform_f(wave_min_all(hd));
+        bool win = (hd == best) && hj >= 0;
+        if (__popcll(__ballot(win)) > 1) {  // several lists offer the same distance: lowest caller index first (rare)
+          const int ho = win ? g.orig[hj] : 0x7fffffff;
+          int bo = ho;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) bo = min(bo, __shfl_xor(bo, off, kWave));
+          win = win && (ho == bo);
+        }
+        if (!__any(win)) break;  // fewer than k points seen
+        const int wj = __builtin_amdgcn_readlane(hj, __builtin_ctzll(__ballot(win)));
+        if (win) head++;
+        if (lane == u) mine = wj;
+        kth = best;
+      }
+      const float rs = r * 0.9999f - eps;
+#ifdef MI355_TILE_STATS
+      n_scanned += whole ? n : cells.total;
+#endif
+      if (whole || kth <= rs * rs) {
+        if (lane < k) o[lane] = mine;
+#ifdef MI355_TILE_STATS
+        if (lane == 0) {
+          const unsigned slot = (1u << 18) - 1 - atomicAdd(&g_tile_stats[9], 1ull);
+          g_tile_log[4 * slot] = t_start; g_tile_log[4 * slot + 1] = wall_clock64();
+          g_tile_log[4 * slot + 2] = ((unsigned long long)c << 32) | (unsigned)t; g_tile_log[4 * slot + 3] = ((unsigned long long)n_scanned << 32) | (unsigned)(n_rounds | (whole ? 256 : 0));
+        }
+#endif
+        break;
+      }
+      r = (kth < INFINITY) ? sqrtf(kth) * 1.001f + 2.f * eps : 2.f * r;
+    }
+  }
+}
+
+// Step 2: neighbourhood covariance from the neighbour lists, 2 x float4 per point (all points, or the queue's).
+__global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, const int* __restrict__ nbr,
+                                                      float4* __restrict__ cov, size_t cap, int k, int method, int G, int B,
+                                                      const int* __restrict__ queue, const int* __restrict__ queue_n) {
+  int c, bx;
+  if (!xcd_item_chunk(G, B, c, bx)) return;
+  const int n = meta[c].n;
+  int i = bx * blockDim.x + threadIdx.x;
+  if (queue) {
+    if (i >= queue_n[c]) return;
+    i = queue[(size_t)c * cap + i];
+  }
+  if (i >= n) return;
+  const float4* p0 = pts + (size_t)c * cap;
+  const int* nb = nbr + ((size_t)c * cap + i) * k;
+  covariance_of(k, method, cov + ((size_t)c * cap + i) * 2, [&](int t) {
+    const int j = nb[t];
+    return j >= 0 ? p0[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  });
+}
+
+template <int K>
+static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   const int G = div_up((long)set.cap, 256);
-  hipLaunchKernelGGL(k_knn_self<K>, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p, set.cap,
-                     set.slots_cap, k, G, set.B, getenv("MI355_KNN_NEED_DIV") ? atoi(getenv("MI355_KNN_NEED_DIV")) : 2);
+  static const int need_div = getenv("MI355_KNN_NEED_DIV") ? atoi(getenv("MI355_KNN_NEED_DIV")) : 2;
+  static const bool tiles = !(getenv("MI355_KNN_TILES") && atoi(getenv("MI355_KNN_TILES")) == 0);
+  if (!tiles) {  // per-lane search for every point
+    hipLaunchKernelGGL(k_knn_self<K>, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p, set.cap,
+                       set.slots_cap, k, G, set.B, need_div, (const int*)nullptr, (const int*)nullptr);
+    hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
+                       set.B, (const int*)nullptr, (const int*)nullptr);
+    return;
+  }
+  set.fbq.ensure((size_t)set.B * set.cap);
+  set.fbn.ensure((size_t)2 * set.B);  // [0, B) fallback queue lengths, [B, 2B) tile counters
+  MI_HIP(hipMemsetAsync(set.fbn.p, 0, sizeof(int) * 2 * set.B, s));
+  // about two resident waves per SIMD over the whole batch, at least 8 and at most one wave per tile of a cloud
+  const int Gt = max(min(8192 / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
+  hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
+                     set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B);
+  // the points the tile kernel handed over: one wave per point, then their covariances from the lists
+  const int Gh = 64;
+  hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p,
+                     (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, Gh, set.B);
+  hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
+                     set.B, (const int*)set.fbq.p, (const int*)set.fbn.p);
 }
 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k_correspondences must be in [1, 64]");
   set.cov.ensure((size_t)set.B * set.cap * 2);
   set.nbr.ensure((size_t)set.B * set.cap * k);
-  if (k == 20) launch_knn_self<20>(s, set, k);
-  else if (k <= 8) launch_knn_self<8>(s, set, k);
-  else if (k <= 16) launch_knn_self<16>(s, set, k);
-  else if (k <= 32) launch_knn_self<32>(s, set, k);
-  else launch_knn_self<64>(s, set, k);
-  const int Gc = div_up((long)set.cap, 256);
-  hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(Gc, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, Gc,
-                     set.B);
+  if (k == 20) launch_covariances<20>(s, set, k, method);
+  else if (k <= 8) launch_covariances<8>(s, set, k, method);
+  else if (k <= 16) launch_covariances<16>(s, set, k, method);
+  else if (k <= 32) launch_covariances<32>(s, set, k, method);
+  else launch_covariances<64>(s, set, k, method);
   MI_LAUNCH_CHECK();
   set.has_cov = true;
 }

@@ -60,6 +60,7 @@ struct CloudSet {
   DevBuf<int> count;
   DevBuf<float4> cov;
   DevBuf<int> nbr;  // [B*cap*k] k-NN lists (sorted indices) between the search and the covariance kernels
+  DevBuf<int> fbq, fbn;  // [B*cap] / [B] points the tile k-NN hands over to the per-lane search
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false;
