@@ -92,13 +92,30 @@ struct mi355_batch {
   mi355_gicp_params gp;
   int n_sources = 0, n_targets = 0;
   size_t cap = 0;
-  Workspace ws;
-  CloudSet src, tgt, sor_set;
+  // Targets and sources are prepared (prefilter, sort, voxel hash, k-NN covariances) on two side streams forked from the
+  // context stream at call time and joined by mi355_batch_align: the two chains are independent, and most of their kernels
+  // are short or end in a thin tail (sort passes, the k-NN stragglers), so run together they fill each other's gaps.
+  struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool pending = false;  // work enqueued since the last join
+    Workspace ws;
+    CloudSet sor_set;
+    DevBuf<int> cnt_in;
+    std::vector<int> h_counts;
+  };
+  Side side[2];  // 0 targets, 1 sources
+  CloudSet src, tgt;
   GicpBatch gb;
-  DevBuf<int> cnt_in;
   DevBuf<float4> host_stage;
-  std::vector<int> h_counts;
   bool has_src = false, has_tgt = false, aligned = false, with_fitness = false;
+  ~mi355_batch() {
+    for (auto& sd : side) {
+      if (sd.stream) { (void)hipStreamSynchronize(sd.stream); (void)hipStreamDestroy(sd.stream); }
+      if (sd.fork) (void)hipEventDestroy(sd.fork);
+      if (sd.join) (void)hipEventDestroy(sd.join);
+    }
+  }
 };
 
 struct CtxExtras {
@@ -602,8 +619,14 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
     b->tgt.alloc(n_targets, capacity);
     gicp_alloc(b->gb, n_sources, capacity, ctx->compute_units);
     b->gb.time_kernels = true;
-    ws_reserve(b->ws, std::max(n_sources, n_targets), capacity);
-    b->cnt_in.ensure(std::max(n_sources, n_targets));
+    for (int k = 0; k < 2; k++) {
+      auto& sd = b->side[k];
+      MI_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+      MI_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+      MI_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+      ws_reserve(sd.ws, k == 0 ? n_targets : n_sources, capacity);
+      sd.cnt_in.ensure(k == 0 ? n_targets : n_sources);
+    }
   });
   if (rc != MI355_OK) {
     delete b;
@@ -619,27 +642,47 @@ extern "C" void mi355_batch_destroy(mi355_batch* b) {
   delete b;
 }
 
-static void batch_set(mi355_batch* b, CloudSet& set, int B, const float4* d_points, const int* counts, const mi355_prefilter_params* pf) {
+static void batch_set(mi355_batch* b, bool targets, const float4* d_points, const int* counts, const mi355_prefilter_params* pf) {
   mi355_ctx* ctx = b->ctx;
   MI_HIP(hipSetDevice(ctx->device));
   if (!d_points || !counts) throw ArgError(MI355_EINVAL, "NULL points / counts");
-  b->h_counts.assign(counts, counts + B);
+  auto& sd = b->side[targets ? 0 : 1];
+  CloudSet& set = targets ? b->tgt : b->src;
+  const int B = targets ? b->n_targets : b->n_sources;
   for (int i = 0; i < B; i++)
     if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
-  MI_HIP(hipMemcpyAsync(b->cnt_in.p, b->h_counts.data(), B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  // fork: everything already enqueued on the context stream (the producer of d_points, the previous align that still reads
+  // this cloud set) comes first
+  MI_HIP(hipEventRecord(sd.fork, ctx->stream));
+  MI_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
+  if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));  // h_counts of a not-yet-joined call may still be read by its copy
+  sd.h_counts.assign(counts, counts + B);
+  hipStream_t s = sd.stream;
+  MI_HIP(hipMemcpyAsync(sd.cnt_in.p, sd.h_counts.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
   const float4* pts = d_points;
-  const int* cnt = b->cnt_in.p;
+  const int* cnt = sd.cnt_in.p;
   if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
-    run_prefilter(ctx->stream, b->ws, b->sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, b->cnt_in.p, b->ws.stage_a, b->ws.stage_b, b->ws.count_a,
-                  b->ws.count_b, &pts, &cnt);
-  build_grid(ctx->stream, b->ws, pts, cnt, set, ctx->grid_cell);
-  compute_covariances(ctx->stream, set, b->gp.k_correspondences, b->gp.regularization_method);
+    run_prefilter(s, sd.ws, sd.sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, sd.cnt_in.p, sd.ws.stage_a, sd.ws.stage_b, sd.ws.count_a,
+                  sd.ws.count_b, &pts, &cnt);
+  build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell);
+  compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
+  MI_HIP(hipEventRecord(sd.join, s));
+  sd.pending = true;
+}
+
+// Make the context stream wait for the side streams' pending work.
+static void batch_join(mi355_batch* b) {
+  for (auto& sd : b->side)
+    if (sd.pending) {
+      MI_HIP(hipStreamWaitEvent(b->ctx->stream, sd.join, 0));
+      sd.pending = false;
+    }
 }
 
 extern "C" int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter) {
   if (!b) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
-    batch_set(b, b->tgt, b->n_targets, (const float4*)d_points, counts, prefilter);
+    batch_set(b, true, (const float4*)d_points, counts, prefilter);
     b->has_tgt = true;
     b->aligned = false;
   });
@@ -648,7 +691,7 @@ extern "C" int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points,
 extern "C" int mi355_batch_set_sources_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter) {
   if (!b) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
-    batch_set(b, b->src, b->n_sources, (const float4*)d_points, counts, prefilter);
+    batch_set(b, false, (const float4*)d_points, counts, prefilter);
     b->has_src = true;
     b->aligned = false;
   });
@@ -662,8 +705,8 @@ static int batch_set_host(mi355_batch* b, bool targets, const float* points, con
     b->host_stage.ensure((size_t)B * b->cap);
     MI_HIP(hipMemcpyAsync(b->host_stage.p, points, (size_t)B * b->cap * sizeof(float4), hipMemcpyHostToDevice, b->ctx->stream));
     MI_HIP(hipStreamSynchronize(b->ctx->stream));
-    batch_set(b, targets ? b->tgt : b->src, B, b->host_stage.p, counts, pf);
-    MI_HIP(hipStreamSynchronize(b->ctx->stream));  // host_stage is reused by the next call
+    batch_set(b, targets, b->host_stage.p, counts, pf);
+    MI_HIP(hipStreamSynchronize(b->side[targets ? 0 : 1].stream));  // host_stage is reused by the next call
     if (targets) b->has_tgt = true; else b->has_src = true;
     b->aligned = false;
   });
@@ -681,6 +724,7 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
     if (!b->has_src || !b->has_tgt) throw ArgError(MI355_ESTATE, "sources / targets not set");
     if (!tgt_of_src && b->n_sources != b->n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
     MI_HIP(hipSetDevice(b->ctx->device));
+    batch_join(b);
     gicp_align(b->ctx->stream, b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
     b->with_fitness = with_fitness != 0;
     if (b->with_fitness) gicp_fitness(b->ctx->stream, b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);

@@ -345,7 +345,7 @@ template <int K>
 __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
                                                      float4* __restrict__ cov, int* __restrict__ queue, int* __restrict__ queue_n,
-                                                     int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k, int method, int G, int B) {
+                                                     int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k, int method, int G, int B, float r_scale) {
   __shared__ float4 cand[kTileMaxCand];  // this wave's candidate list (x, y, z, sorted index)
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         e_max = fmaxf(fmaxf(ex, ey), ez);
         const float e_mid = ex + ey + ez - e_min - e_max;
         const float area = fmaxf(e_max * e_mid, 0.16f * g.m.cell * g.m.cell);
-        r = fminf(fmaxf(sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
+        r = fminf(fmaxf(r_scale * sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
       }
       SmallestKeys<K + 2> keys;
       keys.init();
@@ -654,9 +654,11 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
   set.fbn.ensure((size_t)2 * set.B);  // [0, B) fallback queue lengths, [B, 2B) tile counters
   MI_HIP(hipMemsetAsync(set.fbn.p, 0, sizeof(int) * 2 * set.B, s));
   // about two resident waves per SIMD over the whole batch, at least 8 and at most one wave per tile of a cloud
-  const int Gt = max(min(8192 / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
+  static const int gt_total = getenv("MI355_TILE_WAVES") ? atoi(getenv("MI355_TILE_WAVES")) : 8192;
+  static const float r_scale = getenv("MI355_TILE_RSCALE") ? (float)atof(getenv("MI355_TILE_RSCALE")) : 0.8f;
+  const int Gt = max(min(gt_total / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
   hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                     set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B);
+                     set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, r_scale);
   // the points the tile kernel handed over: one wave per point, then their covariances from the lists
   const int Gh = 64;
   hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p,

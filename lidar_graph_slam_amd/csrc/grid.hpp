@@ -244,7 +244,15 @@ __device__ __forceinline__ float grid_search(const GridView& g, float qx, float 
       }
       return INFINITY;  // the whole grid has been scanned
     }
-    l = min(l + level_step, m.top_level);
+    // next level; never coarser than the first level whose shell 1 is guaranteed to cover max_d2 (cell edge >= the radius):
+    // beyond it the cells only get bigger, not the region that matters
+    int l_next = min(l + level_step, m.top_level);
+    if (max_d2 < INFINITY) {
+      const float rel = sqrtf(max_d2) * m.inv_cell;
+      const int l_cover = (rel <= 1.f) ? 0 : min(m.top_level, (int)ceilf(log2f(rel)));
+      l_next = min(l_next, max(l + 1, l_cover));
+    }
+    l = l_next;
     vis.flush();
     vis.restart();
   }
