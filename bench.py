@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--leaf", type=float, default=0.2)
     ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")
+    ap.add_argument("--inflight", type=int, default=1, help="batch objects in flight, each on its own HIP stream (double buffering)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--host-inputs", action="store_true", help="hand HOST buffers to the C-ABI every step (PCIe-inclusive rate; never the headline value)")
@@ -114,13 +115,34 @@ def main():
     # aligned pose T' satisfies T' = W T_gt W^-1.
 
     params = dict(max_iterations=args.iters, force_iterations=1)
-    batch = BatchRegistration(P, P, cap, ctx=ctx, **params)
+    # --inflight 2: two batch objects on two HIP streams, used alternately (double buffering): while one batch is in its
+    # latency-bound LM iterations the next one is prefiltered and indexed.  Every step still processes one full batch.
+    batches = [BatchRegistration(P, P, cap, ctx=ctx, **params) for _ in range(max(1, args.inflight))]
+    streams = []
+    if len(batches) > 1:
+        streams = [torch.cuda.Stream(device=dev) for _ in batches]
+        for b_, s_ in zip(batches, streams):
+            b_.set_stream(s_.cuda_stream)
     pre = L.prefilter_params(min_distance=1.0, leaf_size=args.leaf, mean_k=0)
+    step_no = [0]
+    pending = [None] * len(batches)
 
     if args.host_inputs:
         src_h, tgt_h = src_d.cpu().numpy(), tgt_d.cpu().numpy()
 
     def step():
+        """One batch through the hot path.  With several batches in flight the results returned are those of the batch
+        that was enqueued len(batches)-1 steps ago (drain() collects the rest)."""
+        k = step_no[0] % len(batches)
+        step_no[0] += 1
+        batch = batches[k]
+        out = None
+        if pending[k]:
+            out = batch.results()  # waits for that batch's stream only
+            ms, nl = batch.kernel_time()
+            lin[0] += ms
+            lin[1] += nl
+            pending[k] = None
         if args.host_inputs:
             batch.set_targets(tgt_h, counts, pre)
             batch.set_sources(src_h, counts, pre)
@@ -132,7 +154,21 @@ def main():
                 batch.set_targets_dev(tgt_d.data_ptr(), counts, pre)
                 batch.set_sources_dev(src_d.data_ptr(), counts, pre)
         batch.align()
-        return batch.results()
+        pending[k] = True
+        return out
+
+    def drain():
+        out = None
+        for k, batch in enumerate(batches):
+            if pending[k]:
+                out = batch.results()
+                ms, nl = batch.kernel_time()
+                lin[0] += ms
+                lin[1] += nl
+                pending[k] = None
+        return out
+
+    lin = [0.0, 0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,15 +177,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
-    lin_ms, lin_launches = 0.0, 0
+    lin[0], lin[1] = 0.0, 0
     t0 = time.perf_counter()
+    res = None
     for _ in range(args.steps):
-        res = step()
-        ms, nl = batch.kernel_time()
-        lin_ms += ms
-        lin_launches += nl
+        r_ = step()
+        res = r_ if r_ is not None else res
+    r_ = drain()
+    res = r_ if r_ is not None else res
     barrier()
+    lin_ms, lin_launches = lin
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed)  # MAX over ranks (RCCL all-reduce of one double)
 

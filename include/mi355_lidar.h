@@ -182,6 +182,12 @@ int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
  * total milliseconds inside the GICP linearise kernel and the number of launches. */
 int mi355_batch_kernel_time(mi355_batch* b, double* linearize_ms, int* linearize_launches);
 
+/* Run this batch on its own HIP stream instead of the context's (use_context_stream != 0 switches back).  Batches on
+ * different streams overlap on the GPU: while one batch is in its (latency-bound) LM iterations the next one can be
+ * prefiltered and indexed - the double buffering a streaming caller (one batch of loop-closure candidates / scan pairs
+ * after the other) wants.  Device pointers handed to mi355_batch_set_*_dev must be valid in THAT stream's order. */
+int mi355_batch_set_stream(mi355_batch* batch, void* hip_stream, int use_context_stream);
+
 #ifdef __cplusplus
 }
 #endif

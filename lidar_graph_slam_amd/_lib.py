@@ -102,7 +102,7 @@ EXPORTS = [
     "mi355_reg_create", "mi355_reg_destroy", "mi355_reg_set_params", "mi355_reg_set_target", "mi355_reg_set_source", "mi355_reg_align",
     "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
-    "mi355_batch_set_sources", "mi355_batch_align", "mi355_batch_results", "mi355_batch_kernel_time",
+    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_kernel_time",
 ]
 # include/mi355_scan_matcher.h
 EXPORTS_SCAN_MATCHER = [
@@ -187,6 +187,7 @@ def lib():
         for name in ("mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets", "mi355_batch_set_sources"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
         L.mi355_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi355_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.mi355_scan_matcher_create.restype = C.c_void_p

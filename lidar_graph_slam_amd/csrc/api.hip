@@ -108,6 +108,9 @@ struct mi355_batch {
   CloudSet src, tgt;
   GicpBatch gb;
   DevBuf<float4> host_stage;
+  hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
+  bool has_own_stream = false;
+  hipStream_t stream() const { return has_own_stream ? own_stream : ctx->stream; }
   bool has_src = false, has_tgt = false, aligned = false, with_fitness = false;
   ~mi355_batch() {
     for (auto& sd : side) {
@@ -638,7 +641,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
 extern "C" void mi355_batch_destroy(mi355_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
-  (void)hipStreamSynchronize(b->ctx->stream);
+  (void)hipStreamSynchronize(b->stream());
   delete b;
 }
 
@@ -653,7 +656,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
   // fork: everything already enqueued on the context stream (the producer of d_points, the previous align that still reads
   // this cloud set) comes first
-  MI_HIP(hipEventRecord(sd.fork, ctx->stream));
+  MI_HIP(hipEventRecord(sd.fork, b->stream()));
   MI_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
   if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));  // h_counts of a not-yet-joined call may still be read by its copy
   sd.h_counts.assign(counts, counts + B);
@@ -674,7 +677,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
 static void batch_join(mi355_batch* b) {
   for (auto& sd : b->side)
     if (sd.pending) {
-      MI_HIP(hipStreamWaitEvent(b->ctx->stream, sd.join, 0));
+      MI_HIP(hipStreamWaitEvent(b->stream(), sd.join, 0));
       sd.pending = false;
     }
 }
@@ -703,8 +706,8 @@ static int batch_set_host(mi355_batch* b, bool targets, const float* points, con
     MI_HIP(hipSetDevice(b->ctx->device));
     const int B = targets ? b->n_targets : b->n_sources;
     b->host_stage.ensure((size_t)B * b->cap);
-    MI_HIP(hipMemcpyAsync(b->host_stage.p, points, (size_t)B * b->cap * sizeof(float4), hipMemcpyHostToDevice, b->ctx->stream));
-    MI_HIP(hipStreamSynchronize(b->ctx->stream));
+    MI_HIP(hipMemcpyAsync(b->host_stage.p, points, (size_t)B * b->cap * sizeof(float4), hipMemcpyHostToDevice, b->stream()));
+    MI_HIP(hipStreamSynchronize(b->stream()));
     batch_set(b, targets, b->host_stage.p, counts, pf);
     MI_HIP(hipStreamSynchronize(b->side[targets ? 0 : 1].stream));  // host_stage is reused by the next call
     if (targets) b->has_tgt = true; else b->has_src = true;
@@ -718,6 +721,18 @@ extern "C" int mi355_batch_set_sources(mi355_batch* b, const float* points, cons
   return batch_set_host(b, false, points, counts, pf);
 }
 
+extern "C" int mi355_batch_set_stream(mi355_batch* b, void* hip_stream, int use_context_stream) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    MI_HIP(hipSetDevice(b->ctx->device));
+    MI_HIP(hipStreamSynchronize(b->stream()));  // nothing of this batch may still be in flight on the old stream
+    for (auto& sd : b->side)
+      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    b->has_own_stream = !use_context_stream;
+    b->own_stream = (hipStream_t)hip_stream;
+  });
+}
+
 extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesses16, int with_fitness) {
   if (!b) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
@@ -725,9 +740,9 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
     if (!tgt_of_src && b->n_sources != b->n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
     MI_HIP(hipSetDevice(b->ctx->device));
     batch_join(b);
-    gicp_align(b->ctx->stream, b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
+    gicp_align(b->stream(), b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
     b->with_fitness = with_fitness != 0;
-    if (b->with_fitness) gicp_fitness(b->ctx->stream, b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
+    if (b->with_fitness) gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
     b->aligned = true;
   });
 }
@@ -738,7 +753,7 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     if (!b->aligned) throw ArgError(MI355_ESTATE, "mi355_batch_align has not been called");
     if (fitness && !b->with_fitness) throw ArgError(MI355_ESTATE, "fitness was not requested in mi355_batch_align");
     MI_HIP(hipSetDevice(b->ctx->device));
-    gicp_results(b->ctx->stream, b->gb, b->src, b->tgt, results, fitness);
+    gicp_results(b->stream(), b->gb, b->src, b->tgt, results, fitness);
   });
 }
 
@@ -746,7 +761,7 @@ extern "C" int mi355_batch_kernel_time(mi355_batch* b, double* linearize_ms, int
   if (!b) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
     MI_HIP(hipSetDevice(b->ctx->device));
-    MI_HIP(hipStreamSynchronize(b->ctx->stream));
+    MI_HIP(hipStreamSynchronize(b->stream()));
     if (b->gb.ev_used) gicp_finish_timing(b->gb);
     if (linearize_ms) *linearize_ms = b->gb.last_linearize_ms;
     if (linearize_launches) *linearize_launches = b->gb.last_linearize_launches;

@@ -67,7 +67,9 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
-  gb.blocks_lin = std::max(1, std::min(16, div_up((long)cap, kGicpBlock * 4)));
+  // few, long-lived blocks: each block streams several tiles (software-pipelined) and pays ONE 29-value fp64 reduction;
+  // about 512 blocks over the batch, at least 4 per pair, never more than the tiles a cloud can have
+  gb.blocks_lin = std::max(1, std::min(std::max(4, std::min(32, 512 / std::max(S, 1))), div_up((long)cap, kGicpBlock * 2)));
   if (const char* e = getenv("MI355_BLOCKS_LIN")) gb.blocks_lin = std::max(1, atoi(e));
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
@@ -295,17 +297,50 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
+  // Software pipeline over the block's tiles: the correspondence index, the source point and its covariance of the NEXT
+  // tile are loaded while the current tile is computed, so the dependent gathers (target point / covariance at corr[i])
+  // of a tile are issued as soon as its loop iteration starts — one exposed memory latency per tile instead of two.
+  struct Pre {
+    int j;
+    float4 p, c0, c1;
+  };
+  auto preload = [&](int base, int u) -> Pre {
+    Pre r;
+    const int i = base + u * kGicpBlock + threadIdx.x;
+    r.j = -1;
+    if (i < n) {
+      r.j = corr[so + i];
+      r.p = spts[so + i];
+      r.c0 = scov[2 * (so + i)];
+      r.c1 = scov[2 * (so + i) + 1];
+    }
+    return r;
+  };
+  Pre nxt[kLinPointsPerThread];
+#pragma unroll
+  for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(bx * kLinTile, u);
   for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
+    Pre cur[kLinPointsPerThread];
+    float4 tq[kLinPointsPerThread], t0[kLinPointsPerThread], t1[kLinPointsPerThread];
+#pragma unroll
+    for (int u = 0; u < kLinPointsPerThread; u++) {
+      cur[u] = nxt[u];
+      const int j = max(cur[u].j, 0);
+      tq[u] = tp[j];
+      t0[u] = tc[2 * (size_t)j];
+      t1[u] = tc[2 * (size_t)j + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(base + G * kLinTile, u);
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
-      if (i >= n) continue;
-      const int j = corr[so + i];
-      if (j < 0) continue;
+      const int j = cur[u].j;
+      if (j < 0) continue;  // past the end, or no correspondence
       if (debug_flags & 8) { acc[28] += 1.0; continue; }
-      const float4 p = spts[so + i];
-      const Sym3<float> CA = load_cov(scov, so + i);
-      const Sym3<float> CB = load_cov(tc, (size_t)j);
+      const float4 p = cur[u].p;
+      const Sym3<float> CA = {cur[u].c0.x, cur[u].c0.y, cur[u].c0.z, cur[u].c0.w, cur[u].c1.x, cur[u].c1.y};
+      const Sym3<float> CB = {t0[u].x, t0[u].y, t0[u].z, t0[u].w, t1[u].x, t1[u].y};
       Sym3<float> RCR = sym3_rotate(Rf, CA);
       RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
       const Sym3<float> M = sym3_inverse(RCR);
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
       mahal[2 * (so + i) + 1] = make_float4(M.yz, M.zz, 0.f, 0.f);
       float ax, ay, az, ex, ey, ez;
       double dex, dey, dez;
-      residual(x0, p, tp[j], ax, ay, az, ex, ey, ez, dex, dey, dez);
+      residual(x0, p, tq[u], ax, ay, az, ex, ey, ez, dex, dey, dez);
       const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
       const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
       const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
@@ -581,7 +616,8 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
 
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P) {
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
-  auto kl = k_gicp_linearize<4>;
+  static const int lin_ppt = getenv("MI355_LIN_PPT") ? atoi(getenv("MI355_LIN_PPT")) : 1;
+  auto kl = lin_ppt == 1 ? k_gicp_linearize<1> : (lin_ppt == 2 ? k_gicp_linearize<2> : k_gicp_linearize<4>);
   hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                      tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
                      gb.debug_flags, gb.stats.p, gb.iter_counter++ % 64, gb.blocks_per_pair, gb.S);

@@ -220,6 +220,13 @@ class BatchRegistration:
         c = self._counts(counts, self.n_sources)
         self.ctx.check(self.ctx._lib.mi355_batch_set_sources(self.handle, p.ctypes.data, c.ctypes.data, C.byref(prefilter) if prefilter else None))
 
+    def set_stream(self, hip_stream: int | None):
+        """Run this batch on its own HIP stream (None: back to the context's); batches on different streams overlap."""
+        if hip_stream is None:
+            self.ctx.check(self.ctx._lib.mi355_batch_set_stream(self.handle, None, 1))
+        else:
+            self.ctx.check(self.ctx._lib.mi355_batch_set_stream(self.handle, C.c_void_p(hip_stream), 0))
+
     def align(self, tgt_of_src=None, guesses=None, with_fitness=False):
         t = None if tgt_of_src is None else np.ascontiguousarray(tgt_of_src, dtype=np.int32)
         g = None if guesses is None else np.ascontiguousarray(guesses, dtype=np.float32).reshape(self.n_sources, 16)
