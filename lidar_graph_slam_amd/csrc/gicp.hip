@@ -501,6 +501,11 @@ __device__ __forceinline__ double point_error(const Pose& x, const float4& p, co
 }
 
 // F5 compute_error for every LM trial pose in one pass (frozen correspondences and Mahalanobis matrices).
+// All LM trial costs in one pass.  Per tile every thread keeps kErrPoints points (source, correspondent, Mahalanobis) in
+// registers and walks the trials in a rolled loop; a trial pose is wave-uniform and comes through scalar loads into SGPRs,
+// so the register budget is the points plus NT accumulators (the first version kept all NT poses in VGPRs: 256 VGPRs +
+// AGPRs, one wave per SIMD, and spent its time waiting on the point loads with nothing to overlap them).
+constexpr int kErrPoints = 4;
 template <int NT>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
@@ -508,25 +513,43 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
                                                            const int* __restrict__ corr, const float4* __restrict__ mahal,
                                                            double* __restrict__ partials, int n_trials) {
   __shared__ double smem[4 * NT];
-  __shared__ Pose sxi[NT];
   const int pair = blockIdx.y;
   const GicpPairState* st = state + pair;
   if (!st->active || !st->need_error) return;
-  if (threadIdx.x < NT) sxi[threadIdx.x] = trials[(size_t)pair * kMaxTrials + min((int)threadIdx.x, n_trials - 1)].xi;
-  __syncthreads();
   const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
+  const LmTrial* tr = trials + (size_t)pair * kMaxTrials;
   const int n = scount[pair];
   const size_t so = (size_t)pair * scap;
+  const int nt = min(n_trials, NT);
   double acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) acc[t] = 0.0;
-  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
-    const int j = corr[so + i];
-    if (j < 0) continue;
-    const float4 p = spts[so + i], q = tp[j], ma = mahal[2 * (so + i)], mb = mahal[2 * (so + i) + 1];
+  constexpr int kTile = kGicpBlock * kErrPoints;
+  for (int base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {
+    float4 p[kErrPoints], q[kErrPoints], ma[kErrPoints], mb[kErrPoints];
+    bool ok[kErrPoints];
 #pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] += point_error(sxi[t], p, q, ma, mb);
+    for (int u = 0; u < kErrPoints; u++) {
+      const int i = base + u * kGicpBlock + threadIdx.x;
+      const int j = (i < n) ? corr[so + i] : -1;
+      ok[u] = j >= 0;
+      const size_t ii = so + min(i, n - 1);
+      p[u] = spts[ii];
+      q[u] = tp[max(j, 0)];
+      ma[u] = mahal[2 * ii];
+      mb[u] = mahal[2 * ii + 1];
+    }
+#pragma unroll 1
+    for (int t = 0; t < nt; t++) {
+      const Pose xi = tr[t].xi;  // wave-uniform: scalar loads
+      double e = 0.0;
+#pragma unroll
+      for (int u = 0; u < kErrPoints; u++) e += ok[u] ? point_error(xi, p[u], q[u], ma[u], mb[u]) : 0.0;
+#pragma unroll
+      for (int k = 0; k < NT; k++) acc[k] += (k == t) ? e : 0.0;
+    }
   }
+  // trials past n_trials repeat the last one (the decision never reads them)
   block_sum<NT, 4>(acc, smem);
   if (threadIdx.x == 0) {
     double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + kTrialSlot;
