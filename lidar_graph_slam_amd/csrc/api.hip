@@ -406,14 +406,14 @@ extern "C" int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, in
     if (fs.set.B != 1 || fs.set.cap != oc.cap()) fs.set.alloc(1, oc.cap());
     build_grid(ctx->stream, fs.ws, fs.a.p, fs.na.p, fs.set, ctx->grid_cell);
     compute_covariances(ctx->stream, fs.set, k, method);
-    std::vector<float4> c(2 * oc.n);
+    std::vector<Cov6> c(oc.n);
     std::vector<int> orig(oc.n);
-    MI_HIP(hipMemcpyAsync(c.data(), fs.set.cov.p, c.size() * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(c.data(), fs.set.cov.p, c.size() * sizeof(Cov6), hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipMemcpyAsync(orig.data(), fs.set.orig.p, oc.n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < oc.n; i++) {  // back to the caller's point order
       float* o = cov6 + 6 * (size_t)orig[i];
-      o[0] = c[2 * i].x; o[1] = c[2 * i].y; o[2] = c[2 * i].z; o[3] = c[2 * i].w; o[4] = c[2 * i + 1].x; o[5] = c[2 * i + 1].y;
+      for (int t = 0; t < 6; t++) o[t] = c[i].v[t];
     }
   });
 }

@@ -302,7 +302,7 @@ extern "C" unsigned mi355_debug_tile_log(unsigned long long* out, unsigned max_e
 
 // Neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation; point(t) returns the t-th neighbour.
 template <typename P>
-__device__ __forceinline__ void covariance_of(int k, int method, float4* o, P&& point) {
+__device__ __forceinline__ void covariance_of(int k, int method, Cov6* o, P&& point) {
   double mx = 0, my = 0, mz = 0;
   for (int t = 0; t < k; t++) {
     const float4 p = point(t);
@@ -318,8 +318,7 @@ __device__ __forceinline__ void covariance_of(int k, int method, float4* o, P&& 
   }
   cv.xx *= invk; cv.xy *= invk; cv.xz *= invk; cv.yy *= invk; cv.yz *= invk; cv.zz *= invk;
   const Sym3<double> r = regularize_covariance(cv, method);
-  o[0] = make_float4((float)r.xx, (float)r.xy, (float)r.xz, (float)r.yy);
-  o[1] = make_float4((float)r.yz, (float)r.zz, 0.f, 0.f);
+  *o = cov6_pack((float)r.xx, (float)r.xy, (float)r.xz, (float)r.yy, (float)r.yz, (float)r.zz);
 }
 
 // Steps 1+2, fast path: k-NN and covariance of every point by the wave-cooperative tile search (tile.hpp).  One wave =
@@ -344,7 +343,7 @@ constexpr int kTileMaxLoad = 8192;           // points in the covering cells per
 template <int K>
 __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
-                                                     float4* __restrict__ cov, int* __restrict__ queue, int* __restrict__ queue_n,
+                                                     Cov6* __restrict__ cov, int* __restrict__ queue, int* __restrict__ queue_n,
                                                      int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k, int method, int G, int B, float r_scale) {
   __shared__ float4 cand[kTileMaxCand];  // this wave's candidate list (x, y, z, sorted index)
   int c, bx;
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         { const int cnt = __popcll(__ballot(closed && !exact)); TILE_STAT(14, cnt); }
 #endif
         fb = fb || (act && !exact);
-        if (exact) covariance_of(k, method, cov + ((size_t)c * cap + i) * 2, [&](int t) { return cand[keys.at(t) & kOrdMask]; });
+        if (exact) covariance_of(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.at(t) & kOrdMask]; });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the list
 #ifdef MI355_TILE_STATS
         n_a += n_ord;
@@ -617,9 +616,9 @@ __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts,
   }
 }
 
-// Step 2: neighbourhood covariance from the neighbour lists, 2 x float4 per point (all points, or the queue's).
+// Step 2: neighbourhood covariance from the neighbour lists, one 24-byte record per point (all points, or the queue's).
 __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, const int* __restrict__ nbr,
-                                                      float4* __restrict__ cov, size_t cap, int k, int method, int G, int B,
+                                                      Cov6* __restrict__ cov, size_t cap, int k, int method, int G, int B,
                                                       const int* __restrict__ queue, const int* __restrict__ queue_n) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
@@ -632,7 +631,7 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
   if (i >= n) return;
   const float4* p0 = pts + (size_t)c * cap;
   const int* nb = nbr + ((size_t)c * cap + i) * k;
-  covariance_of(k, method, cov + ((size_t)c * cap + i) * 2, [&](int t) {
+  covariance_of(k, method, cov + ((size_t)c * cap + i), [&](int t) {
     const int j = nb[t];
     return j >= 0 ? p0[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   });
@@ -669,7 +668,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k_correspondences must be in [1, 64]");
-  set.cov.ensure((size_t)set.B * set.cap * 2);
+  set.cov.ensure((size_t)set.B * set.cap);
   set.nbr.ensure((size_t)set.B * set.cap * k);
   if (k == 20) launch_covariances<20>(s, set, k, method);
   else if (k <= 8) launch_covariances<8>(s, set, k, method);

@@ -26,6 +26,14 @@ struct Sym3 {
   T xx, xy, xz, yy, yz, zz;
 };
 
+// Storage form of a symmetric 3x3 in HBM: the 6 unique floats, 24 bytes per record (no padding: the GICP streaming kernels
+// are HBM-bound and these records are most of their bytes).  A record loads as one dwordx4 + one dwordx2.
+struct Cov6 {
+  float v[6];  // xx xy xz yy yz zz
+};
+MI_HD Cov6 cov6_pack(float xx, float xy, float xz, float yy, float yz, float zz) { return Cov6{{xx, xy, xz, yy, yz, zz}}; }
+MI_HD Sym3<float> cov6_unpack(const Cov6& c) { return Sym3<float>{c.v[0], c.v[1], c.v[2], c.v[3], c.v[4], c.v[5]}; }
+
 template <typename T>
 MI_HD Sym3<T> sym3_inverse(const Sym3<T>& a) {
   // cofactor inverse (what a fixed-size 3x3 inverse evaluates)

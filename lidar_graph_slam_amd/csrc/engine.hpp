@@ -58,7 +58,7 @@ struct CloudSet {
   DevBuf<float4> pts;
   DevBuf<int> orig;
   DevBuf<int> count;
-  DevBuf<float4> cov;
+  DevBuf<Cov6> cov;   // [B*cap] regularised neighbourhood covariances
   DevBuf<int> nbr;  // [B*cap*k] k-NN lists (sorted indices) between the search and the covariance kernels
   DevBuf<int> fbq, fbn;  // [B*cap] / [B] points the tile k-NN hands over to the per-lane search
   DevBuf<GridMeta> meta;
@@ -103,7 +103,7 @@ struct GicpBatch {
   int blocks_lin = 0;        // streaming kernels geometry
   DevBuf<int> tgt_of_src;
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
-  DevBuf<float4> mahal;      // [S*cap*2] Mahalanobis (6 floats + pad)
+  DevBuf<Cov6> mahal;        // [S*cap] Mahalanobis matrices of the current linearisation
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;

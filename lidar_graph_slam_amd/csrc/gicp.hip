@@ -73,7 +73,7 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   if (const char* e = getenv("MI355_BLOCKS_LIN")) gb.blocks_lin = std::max(1, atoi(e));
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
-  gb.mahal.ensure((size_t)S * cap * 2);
+  gb.mahal.ensure((size_t)S * cap);
   gb.qsearch.ensure((size_t)S * cap);
   gb.stats.ensure(64);
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
@@ -104,10 +104,6 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
 }
 
 // ---- per-point pieces ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ Sym3<float> load_cov(const float4* cov, size_t i) {
-  const float4 a = cov[2 * i], b = cov[2 * i + 1];
-  return {a.x, a.y, a.z, a.w, b.x, b.y};
-}
 
 // e^T M e with the residual in fp64 and the stored fp32 Mahalanobis matrix: y0 (linearize) and yi (compute_error) must
 // resolve cost decreases far below fp32 resolution or the LM rho test degenerates into a coin flip near convergence.
@@ -273,11 +269,11 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
 // reads src pt 16 + src cov 24(32) + tgt pt 16 + tgt cov 24(32) B (the 80 algorithmic bytes of SURVEY.md §8d) and the
 // 4-byte correspondence, writes the 24(32)-byte Mahalanobis matrix, and accumulates 21+6+1 terms in fp64 registers.
 template <int kLinPointsPerThread>
-__global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const float4* __restrict__ scov,
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const Cov6* __restrict__ scov,
                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
-                                                               const float4* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
+                                                               const Cov6* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                               float4* __restrict__ mahal, double* __restrict__ partials, int debug_flags, int G,
+                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int debug_flags, int G,
                                                                int S) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ double smem[4 * kNAcc];
@@ -287,7 +283,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
   if (!st->active) return;
   const int t = tgt_of_src[pair];
   const float4* tp = tpts + (size_t)t * tcap;
-  const float4* tc = tcov + (size_t)t * tcap * 2;
+  const Cov6* tc = tcov + (size_t)t * tcap;
   const int n = scount[pair];
   const Pose x0 = st->x0;
   float Rf[9];
@@ -302,7 +298,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
   // of a tile are issued as soon as its loop iteration starts — one exposed memory latency per tile instead of two.
   struct Pre {
     int j;
-    float4 p, c0, c1;
+    float4 p;
+    Cov6 c;
   };
   auto preload = [&](int base, int u) -> Pre {
     Pre r;
@@ -311,8 +308,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
     if (i < n) {
       r.j = corr[so + i];
       r.p = spts[so + i];
-      r.c0 = scov[2 * (so + i)];
-      r.c1 = scov[2 * (so + i) + 1];
+      r.c = scov[so + i];
     }
     return r;
   };
@@ -321,14 +317,14 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
   for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(bx * kLinTile, u);
   for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
     Pre cur[kLinPointsPerThread];
-    float4 tq[kLinPointsPerThread], t0[kLinPointsPerThread], t1[kLinPointsPerThread];
+    float4 tq[kLinPointsPerThread];
+    Cov6 tcv[kLinPointsPerThread];
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       cur[u] = nxt[u];
       const int j = max(cur[u].j, 0);
       tq[u] = tp[j];
-      t0[u] = tc[2 * (size_t)j];
-      t1[u] = tc[2 * (size_t)j + 1];
+      tcv[u] = tc[j];
     }
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(base + G * kLinTile, u);
@@ -339,13 +335,12 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
       if (j < 0) continue;  // past the end, or no correspondence
       if (debug_flags & 8) { acc[28] += 1.0; continue; }
       const float4 p = cur[u].p;
-      const Sym3<float> CA = {cur[u].c0.x, cur[u].c0.y, cur[u].c0.z, cur[u].c0.w, cur[u].c1.x, cur[u].c1.y};
-      const Sym3<float> CB = {t0[u].x, t0[u].y, t0[u].z, t0[u].w, t1[u].x, t1[u].y};
+      const Sym3<float> CA = cov6_unpack(cur[u].c);
+      const Sym3<float> CB = cov6_unpack(tcv[u]);
       Sym3<float> RCR = sym3_rotate(Rf, CA);
       RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
       const Sym3<float> M = sym3_inverse(RCR);
-      mahal[2 * (so + i)] = make_float4(M.xx, M.xy, M.xz, M.yy);
-      mahal[2 * (so + i) + 1] = make_float4(M.yz, M.zz, 0.f, 0.f);
+      mahal[so + i] = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
       float ax, ay, az, ex, ey, ez;
       double dex, dey, dez;
       residual(x0, p, tq[u], ax, ay, az, ex, ey, ez, dex, dey, dez);
@@ -493,11 +488,11 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
   }
 }
 
-__device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const float4& ma, const float4& mb) {
+__device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const Cov6& m) {
   float ax, ay, az, ex, ey, ez;
   double dex, dey, dez;
   residual(x, p, q, ax, ay, az, ex, ey, ez, dex, dey, dez);
-  return cost64(dex, dey, dez, ma.x, ma.y, ma.z, ma.w, mb.x, mb.y);
+  return cost64(dex, dey, dez, m.v[0], m.v[1], m.v[2], m.v[3], m.v[4], m.v[5]);
 }
 
 // F5 compute_error for every LM trial pose in one pass (frozen correspondences and Mahalanobis matrices).
@@ -510,7 +505,7 @@ template <int NT>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
                                                            const GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
-                                                           const int* __restrict__ corr, const float4* __restrict__ mahal,
+                                                           const int* __restrict__ corr, const Cov6* __restrict__ mahal,
                                                            double* __restrict__ partials, int n_trials) {
   __shared__ double smem[4 * NT];
   const int pair = blockIdx.y;
@@ -526,7 +521,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
   for (int t = 0; t < NT; t++) acc[t] = 0.0;
   constexpr int kTile = kGicpBlock * kErrPoints;
   for (int base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {
-    float4 p[kErrPoints], q[kErrPoints], ma[kErrPoints], mb[kErrPoints];
+    float4 p[kErrPoints], q[kErrPoints];
+    Cov6 m[kErrPoints];
     bool ok[kErrPoints];
 #pragma unroll
     for (int u = 0; u < kErrPoints; u++) {
@@ -536,15 +532,14 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
       const size_t ii = so + min(i, n - 1);
       p[u] = spts[ii];
       q[u] = tp[max(j, 0)];
-      ma[u] = mahal[2 * ii];
-      mb[u] = mahal[2 * ii + 1];
+      m[u] = mahal[ii];
     }
 #pragma unroll 1
     for (int t = 0; t < nt; t++) {
       const Pose xi = tr[t].xi;  // wave-uniform: scalar loads
       double e = 0.0;
 #pragma unroll
-      for (int u = 0; u < kErrPoints; u++) e += ok[u] ? point_error(xi, p[u], q[u], ma[u], mb[u]) : 0.0;
+      for (int u = 0; u < kErrPoints; u++) e += ok[u] ? point_error(xi, p[u], q[u], m[u]) : 0.0;
 #pragma unroll
       for (int k = 0; k < NT; k++) acc[k] += (k == t) ? e : 0.0;
     }
