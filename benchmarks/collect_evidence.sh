@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- 'bash benchmarks/collect_evidence.sh r01'): everything profiles/README.md cites, written
+# under gpurun_out/<round>/; benchmarks/summarize_evidence.py then distils it into profiles/.
+# rocprofv3 is given the program directly (no env/bash hop) and PMC passes carry --kernel-trace only.
+R=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$R
+rm -rf "$O"; mkdir -p "$O"
+timeout 600 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python bench.py --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.err"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_fetch.err"
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_write.err"
+timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinputs.json" 2> "$O/bench_hostinputs.err"
+timeout 300 python bench.py --inflight 2 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
+timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.json" 2> "$O/bench_128pairs.err"
+timeout 600 python benchmarks/other_configs.py > "$O/other_configs.txt" 2> "$O/other_configs.err"
+ls -la "$O"

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Distil gpurun_out/<round>/ (written by collect_evidence.sh on the GPU box) into the committed files under profiles/.
+
+usage: python benchmarks/summarize_evidence.py r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(ROOT, "gpurun_out", R)
+DST = os.path.join(ROOT, "profiles")
+
+
+def last_json(path):
+    with open(path) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.startswith("{")]
+    return json.loads(lines[-1])
+
+
+def one(pattern):
+    fs = sorted(glob.glob(os.path.join(SRC, pattern)))
+    if not fs:
+        raise SystemExit(f"missing {pattern} under {SRC}")
+    return fs[-1]
+
+
+def pmc_per_kernel(counter_dir, counter):
+    """mean counter value per launch, per kernel (summed over the per-XCD/SE rows of one dispatch)"""
+    per_dispatch = collections.defaultdict(float)
+    name = {}
+    with open(one(f"{counter_dir}/*/*_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
+            name[r["Dispatch_Id"]] = r["Kernel_Name"]
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for d, v in per_dispatch.items():
+        tot[name[d]] += v
+        cnt[name[d]] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    bench = last_json(os.path.join(SRC, "bench_default.json"))
+    pairs = bench["config"]["pairs_per_gpu_per_step"]
+    for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_128pairs", "bench_under_trace"):
+        p = os.path.join(SRC, name + ".json")
+        if os.path.exists(p):
+            with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:
+                f.write(json.dumps(last_json(p)) + "\n")
+    shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(DST, f"{R}_kernel_stats_bench_default.csv"))
+    oc = os.path.join(SRC, "other_configs.txt")
+    if os.path.exists(oc):
+        shutil.copy(oc, os.path.join(DST, f"{R}_other_configs.txt"))
+    fetch = pmc_per_kernel("pmc_fetch", "FETCH_SIZE")
+    write = pmc_per_kernel("pmc_write", "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[0] + write.get(k, (0, 0))[0])):
+        f_kb, n = fetch.get(k, (0.0, 0))
+        w_kb, _ = write.get(k, (0.0, 0))
+        rows.append((k, n, f_kb, w_kb))
+    with open(os.path.join(DST, f"{R}_pmc_fetch_write.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KB_per_launch_raw", "WRITE_SIZE_KB_per_launch", "HBM_bytes_per_launch_FETCHx2_plus_WRITE"])
+        for k, n, f_kb, w_kb in rows[:40]:
+            w.writerow([k, n, round(f_kb, 1), round(w_kb, 1), int(2 * f_kb * 1024 + w_kb * 1024)])
+    lin = [r for r in rows if "k_gicp_linearize" in r[0]]
+    if lin:
+        k, n, f_kb, w_kb = lin[0]
+        tj = {
+            "kernel": "k_gicp_linearize",
+            "pairs": pairs,
+            "hbm_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024),
+            "fetch_size_kb_raw": round(f_kb, 1),
+            "write_size_kb": round(w_kb, 1),
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --steps 2 "
+                      "--warmup 1 --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 counts the 128-B requests of 16-B/lane streaming reads as "
+                      f"64 B, MI355X_MICROARCH.md §HBM); per-launch average over {n} launches; profiles/{R}_pmc_fetch_write.csv",
+        }
+        with open(os.path.join(DST, f"{R}_traffic.json"), "w") as f:
+            json.dump(tj, f, indent=1)
+            f.write("\n")
+        print("traffic", tj["hbm_bytes_per_launch"], "bytes/launch; algorithmic", bench["roofline"]["algorithmic_bytes_per_launch"])
+    print("bench", bench["value"], bench["unit"], "frac", bench["roofline"]["frac"], "cpu", bench.get("cpu_baseline"))
+
+
+if __name__ == "__main__":
+    main()
