@@ -165,3 +165,52 @@ def test_covariances(F, small_pair, name, mode):
     scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
     err = np.abs(c.astype(np.float64) - ref) / scale
     assert (err.max(axis=(1, 2)) < 2e-6).mean() > 0.999, err.max()
+
+
+def _cov_err(c, ref):
+    scale = np.maximum(np.abs(ref).max(axis=(1, 2), keepdims=True), 1e-12)
+    return (np.abs(c.astype(np.float64) - ref) / scale).max(axis=(1, 2))
+
+
+@pytest.mark.parametrize("k", [5, 12, 31, 40])
+def test_covariances_other_k(F, small_pair, k):
+    """The other template widths of the tile k-NN (8 / 16 / 32 / 64 lanes of the key network), raw covariance (method NONE):
+    a single wrong neighbour shows up as an error orders of magnitude above the fp32 storage tolerance."""
+    s, _, _ = small_pair
+    err = _cov_err(F.covariances(s, k, 0), O.covariances(s, k, 0))
+    assert (err < 2e-6).mean() > 0.999, (k, err.max())
+    assert np.median(err) < 2e-7
+
+
+def _cloud(xyz):
+    return np.concatenate([np.asarray(xyz, np.float32), np.ones((len(xyz), 1), np.float32)], axis=1)
+
+
+def test_covariances_ties_lattice(F):
+    """Integer lattice: almost every k-th distance is tied several ways, so the neighbour set hinges on the tie rule (lower
+    caller index) — the path that goes through the fallback queue and the wave-per-query kernel."""
+    g = np.stack(np.meshgrid(np.arange(14), np.arange(13), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.3
+    rng = np.random.default_rng(5)
+    pts = _cloud(g[rng.permutation(len(g))])  # caller order unrelated to the Morton order
+    for k in (7, 20):
+        err = _cov_err(F.covariances(pts, k, 0), O.covariances(pts, k, 0))
+        assert err.max() < 2e-6, (k, err.max(), int((err >= 2e-6).sum()))
+
+
+def test_covariances_sparse_and_tiny(F):
+    rng = np.random.default_rng(11)
+    # neighbourhoods tens of metres wide: beyond the tile kernel's radius cap, whole-cloud scans in the fallback kernel
+    sparse = _cloud(rng.uniform(-70, 70, size=(400, 3)))
+    err = _cov_err(F.covariances(sparse, 20, 0), O.covariances(sparse, 20, 0))
+    assert err.max() < 2e-6, err.max()
+    # dense cluster + isolated outliers + duplicates of one point
+    cluster = rng.normal(0, 0.4, size=(3000, 3))
+    outliers = rng.uniform(-60, 60, size=(40, 3))
+    dup = np.repeat(np.array([[5.0, 5.0, 0.5]]), 30, axis=0)
+    mix = _cloud(np.concatenate([cluster, outliers, dup])[rng.permutation(3070)])
+    err = _cov_err(F.covariances(mix, 20, 0), O.covariances(mix, 20, 0))
+    assert err.max() < 2e-6, err.max()
+    # exactly k points: every neighbourhood is the whole cloud
+    tiny = _cloud(rng.uniform(-1, 1, size=(20, 3)))
+    err = _cov_err(F.covariances(tiny, 20, 0), O.covariances(tiny, 20, 0))
+    assert err.max() < 2e-6, err.max()
