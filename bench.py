@@ -48,8 +48,8 @@ def base_pairs(rank: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--leaf", type=float, default=0.2)

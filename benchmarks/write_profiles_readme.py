@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 P = os.path.join(ROOT, "profiles")
-STEPS = 12  # bench defaults: 10 timed + 2 warm-up steps per traced run
+STEPS = 25  # bench defaults: 20 timed + 5 warm-up steps per traced run
 
 PROGRESSION = """Progression over the round (1 GPU, pairs/s): 416 first correct path → 2 278 multi-level hash → 3 354 XCD-aware mapping →
 4 229 branch-free median-network k-NN → 4 945 speculative all-trials LM → 6 203 (scene fix, LDS-staged centroids) → 6 786
@@ -40,8 +40,8 @@ def main():
     alg = rf["algorithmic_bytes_per_launch"]
     out = f"""# profiles/ — round 1 (MI355X, gfx950, ROCm 7.2)
 
-All files come from ONE command family on a fresh 1-GPU box, `python bench.py` (defaults: {pairs} pairs/step, 10 steps,
-2 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel 0.2 m, k = 20, exactly 20 LM iterations), run by
+All files come from ONE command family on a fresh 1-GPU box, `python bench.py` (defaults: {pairs} pairs/step, 20 steps,
+5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel 0.2 m, k = 20, exactly 20 LM iterations), run by
 `benchmarks/collect_evidence.sh` and distilled by `benchmarks/summarize_evidence.py` / `write_profiles_readme.py`.
 
 | file | what |
