@@ -179,3 +179,66 @@ def test_batch_matches_single(R, small_pair):
         np.testing.assert_allclose(fit[i], O.fitness(srcs[i, : ns[i]], tgts[tgt_of_src[i], : nt[tgt_of_src[i]]], res[i]["T"]), rtol=1e-9)
     ms, launches = b.kernel_time()
     assert launches == 8 and ms > 0
+
+
+def test_batches_on_their_own_streams(R, small_pair):
+    """mi355_batch_set_stream: two batch objects on two HIP streams, used alternately with device-resident inputs and their
+    results collected late (the double buffering of bench.py --inflight 2) give bit-identical poses to a batch on the context
+    stream — the side streams of the preparation and the per-batch stream only reorder independent work."""
+    import ctypes as C
+
+    s, t, _ = small_pair
+    cap = max(len(s), len(t))
+    n = 3
+    srcs = np.zeros((n, cap, 4), np.float32)
+    tgts = np.zeros((n, cap, 4), np.float32)
+    ns, nt = [], []
+    for i in range(n):
+        si, ti = s[: len(s) - 5 * i], t[: len(t) - 3 * i]
+        srcs[i, : len(si)], tgts[i, : len(ti)] = si, ti
+        ns.append(len(si))
+        nt.append(len(ti))
+    kw = dict(max_iterations=6, force_iterations=1)
+    ref = R.BatchRegistration(n, n, cap, **kw)
+    ref.set_targets(tgts, nt)
+    ref.set_sources(srcs, ns)
+    ref.align()
+    want = [r["T"] for r in ref.results()]
+
+    # device buffers and streams straight from the HIP runtime the library itself uses (no torch in this process: a second
+    # HIP runtime initialised after the first one sees no GPU)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+
+    def to_device(a):
+        ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(ptr), a.nbytes) == 0
+        assert hip.hipMemcpy(ptr, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        return ptr.value
+
+    d_src, d_tgt = to_device(srcs), to_device(tgts)
+    streams = []
+    for _ in range(2):
+        st = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(st)) == 0
+        streams.append(st.value)
+    batches = [R.BatchRegistration(n, n, cap, **kw) for _ in range(2)]
+    for b, st in zip(batches, streams):
+        b.set_stream(st)
+    for rep in range(3):  # A, B, A: the third use re-enters a batch whose previous results were never fetched
+        b = batches[rep % 2]
+        b.set_sources_dev(d_src, ns)
+        b.set_targets_dev(d_tgt, nt)
+        b.align()
+    for b in batches:
+        got = [r["T"] for r in b.results()]
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+    batches[0].set_stream(None)  # back to the context stream
+    batches[0].set_sources_dev(d_src, ns)
+    batches[0].set_targets_dev(d_tgt, nt)
+    batches[0].align()
+    for g, w in zip([r["T"] for r in batches[0].results()], want):
+        np.testing.assert_array_equal(g, w)
