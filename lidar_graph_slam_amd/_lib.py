@@ -109,6 +109,39 @@ EXPORTS_SCAN_MATCHER = [
     "mi355_scan_matcher_create", "mi355_scan_matcher_destroy", "mi355_scan_matcher_last_error", "mi355_scan_matcher_callback_cloud",
     "mi355_scan_matcher_target",
 ]
+# include/mi355_loop_closure.h
+EXPORTS_LOOP_CLOSURE = [
+    "mi355_loop_closure_default_params", "mi355_loop_closure_create", "mi355_loop_closure_destroy", "mi355_loop_closure_last_error",
+    "mi355_loop_closure_add_key_frame", "mi355_loop_closure_set_pose", "mi355_loop_closure_candidate", "mi355_loop_closure_close",
+]
+
+
+class LoopClosureParams(C.Structure):
+    _fields_ = [
+        ("search_key_frame_num", C.c_int),
+        ("score_threshold", C.c_double),
+        ("search_for_candidate_threshold", C.c_double),
+        ("accumulate_distance_threshold", C.c_double),
+        ("submap_leaf", C.c_float),
+        ("max_iteration", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("correspondence_randomness", C.c_int),
+    ]
+
+
+class LoopResult(C.Structure):
+    _fields_ = [
+        ("query_id", C.c_int),
+        ("candidate_id", C.c_int),
+        ("converged", C.c_int),
+        ("accepted", C.c_int),
+        ("iterations", C.c_int),
+        ("fitness", C.c_double),
+        ("transform", C.c_float * 16),
+        ("between", C.c_double * 16),
+        ("target_points", C.c_size_t),
+    ]
 
 
 class ScanMatcherParams(C.Structure):
@@ -190,6 +223,18 @@ def lib():
         L.mi355_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.mi355_loop_closure_default_params.argtypes = [C.POINTER(LoopClosureParams)]
+        L.mi355_loop_closure_default_params.restype = None
+        L.mi355_loop_closure_create.restype = C.c_void_p
+        L.mi355_loop_closure_create.argtypes = [C.c_int, C.POINTER(LoopClosureParams)]
+        L.mi355_loop_closure_destroy.argtypes = [C.c_void_p]
+        L.mi355_loop_closure_destroy.restype = None
+        L.mi355_loop_closure_last_error.restype = C.c_char_p
+        L.mi355_loop_closure_last_error.argtypes = [C.c_void_p]
+        L.mi355_loop_closure_add_key_frame.argtypes = [C.c_void_p, PV, C.c_void_p, C.c_double]
+        L.mi355_loop_closure_set_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mi355_loop_closure_candidate.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.mi355_loop_closure_close.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(LoopResult)]
         L.mi355_scan_matcher_create.restype = C.c_void_p
         L.mi355_scan_matcher_create.argtypes = [C.c_int, C.POINTER(ScanMatcherParams)]
         L.mi355_scan_matcher_destroy.argtypes = [C.c_void_p]

@@ -1,0 +1,278 @@
+// See loop_closure_core.hpp.  Line references are to /root/reference/graph_based_slam/src/graph_based_slam.cpp.
+#include "loop_closure_core.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "../../../include/mi355_loop_closure.h"
+
+namespace mi355 {
+
+int LoopClosureCore::add_key_frame(PointCloud cloud, const Pose& pose, double accum_distance) {
+  KeyFrame kf;
+  kf.cloud = std::move(cloud);
+  kf.pose = pose;
+  kf.accum_distance = accum_distance;
+  kf.id = (long)key_frames_.size();
+  key_frames_.emplace_back(std::move(kf));
+  return (int)key_frames_.size() - 1;
+}
+
+int LoopClosureCore::candidate(int query) const {
+  if (query < 0 || (size_t)query >= key_frames_.size()) throw Error(MI355_EINVAL, "query key frame out of range");
+  const KeyFrame& latest = key_frames_[(size_t)query];
+  double min_dist = std::numeric_limits<double>::max();
+  int min_id = -1;
+  for (int id = 0; id < (int)key_frames_.size(); id++) {  // :264-280 (every key frame is tested, also later ones)
+    const KeyFrame& kf = key_frames_[(size_t)id];
+    if ((latest.accum_distance - kf.accum_distance) < params_.accumulate_distance_threshold) continue;
+    const double dx = latest.pose.px - kf.pose.px, dy = latest.pose.py - kf.pose.py, dz = latest.pose.pz - kf.pose.pz;
+    const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+    if (dist < params_.search_for_candidate_threshold && dist < min_dist) {
+      min_dist = dist;
+      min_id = id;
+    }
+  }
+  return min_id;
+}
+
+void LoopClosureCore::append_transformed(const PointCloud& in, const Matrix4f& T, std::vector<float>& packed) {
+  packed.reserve(packed.size() + 4 * in.size());
+  for (const PointXYZI& p : in) {
+    for (int r = 0; r < 3; r++)
+      packed.push_back(std::fmaf(T[4 * r], p.x, std::fmaf(T[4 * r + 1], p.y, std::fmaf(T[4 * r + 2], p.z, T[4 * r + 3]))));
+    packed.push_back(p.intensity);
+  }
+}
+
+// double-precision rigid transform from a geometry Pose (what gtsam::Pose3(Rot3::Quaternion, Point3) holds)
+static void pose_to_matrix_d(const Pose& p, double M[16]) {
+  const double n = std::sqrt(p.qx * p.qx + p.qy * p.qy + p.qz * p.qz + p.qw * p.qw);
+  const double x = p.qx / n, y = p.qy / n, z = p.qz / n, w = p.qw / n;
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w),     2 * (x * z + y * w),
+                       2 * (x * y + z * w),     1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                       2 * (x * z - y * w),     2 * (y * z + x * w),     1 - 2 * (x * x + y * y)};
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) M[4 * r + c] = R[3 * r + c];
+  }
+  M[3] = p.px; M[7] = p.py; M[11] = p.pz;
+  M[12] = M[13] = M[14] = 0.0;
+  M[15] = 1.0;
+}
+
+std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) {
+  std::vector<LoopResult> out(queries.size());
+  std::vector<int> cand(queries.size()), uniq;  // uniq: candidate ids that need a sub-map
+  for (size_t i = 0; i < queries.size(); i++) {
+    out[i].query_id = queries[i];
+    cand[i] = candidate(queries[i]);
+    out[i].candidate_id = cand[i];
+    if (cand[i] >= 0 && std::find(uniq.begin(), uniq.end(), cand[i]) == uniq.end()) uniq.push_back(cand[i]);
+  }
+  if (uniq.empty()) return out;
+
+  // sub-maps (:297-309): key frames min_id - N .. min_id + N, each moved by its own pose, concatenated in index order
+  const int n_kf = (int)key_frames_.size();
+  std::vector<std::vector<float>> submap(uniq.size());
+  size_t cap = 1;
+  for (size_t u = 0; u < uniq.size(); u++) {
+    for (int idx = -params_.search_key_frame_num; idx <= params_.search_key_frame_num; idx++) {
+      const int k = uniq[u] + idx;
+      if (k < 0 || n_kf <= k) continue;
+      append_transformed(key_frames_[(size_t)k].cloud, geometry_pose_to_matrix(key_frames_[(size_t)k].pose), submap[u]);
+    }
+    cap = std::max(cap, submap[u].size() / 4);
+  }
+  // sources (:248-252): the query key frame moved by its pose
+  std::vector<size_t> src_of;  // rows of `out` that are registered
+  std::vector<std::vector<float>> source;
+  for (size_t i = 0; i < queries.size(); i++) {
+    if (cand[i] < 0) continue;
+    src_of.push_back(i);
+    source.emplace_back();
+    const KeyFrame& kf = key_frames_[(size_t)queries[i]];
+    append_transformed(kf.cloud, geometry_pose_to_matrix(kf.pose), source.back());
+    cap = std::max(cap, source.back().size() / 4);
+  }
+  const int S = (int)source.size(), U = (int)uniq.size();
+
+  if (!ctx_) ctx_.reset(new Context(device_id_));
+  mi355_gicp_params gp;
+  mi355_gicp_default_params(&gp);  // fast_gicp defaults, then the setters of :92-96
+  gp.k_correspondences = params_.correspondence_randomness;
+  gp.max_iterations = params_.max_iteration;
+  gp.transformation_epsilon = params_.transformation_epsilon;
+  gp.max_correspondence_distance = params_.max_correspondence_distance;
+  mi355_batch* b = mi355_batch_create(ctx_->get(), MI355_METHOD_FAST_GICP, &gp, S, U, cap);
+  if (!b) throw Error(MI355_EHIP, mi355_last_error(ctx_->get()));
+  struct Guard {
+    mi355_batch* b;
+    ~Guard() { mi355_batch_destroy(b); }
+  } guard{b};
+
+  std::vector<float> stage((size_t)std::max(S, U) * cap * 4, 0.f);
+  std::vector<int> counts((size_t)std::max(S, U));
+  for (int u = 0; u < U; u++) {
+    std::copy(submap[(size_t)u].begin(), submap[(size_t)u].end(), stage.begin() + (size_t)u * cap * 4);
+    counts[(size_t)u] = (int)(submap[(size_t)u].size() / 4);
+  }
+  mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
+  ctx_->check(mi355_batch_set_targets(b, stage.data(), counts.data(), &pf));
+  for (int s = 0; s < S; s++) {
+    std::copy(source[(size_t)s].begin(), source[(size_t)s].end(), stage.begin() + (size_t)s * cap * 4);
+    counts[(size_t)s] = (int)(source[(size_t)s].size() / 4);
+  }
+  ctx_->check(mi355_batch_set_sources(b, stage.data(), counts.data(), nullptr));
+  std::vector<int> tgt_of_src((size_t)S);
+  for (int s = 0; s < S; s++)
+    tgt_of_src[(size_t)s] = (int)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
+  ctx_->check(mi355_batch_align(b, tgt_of_src.data(), nullptr /* align(*output): identity guess, :318 */, /*with_fitness=*/1));
+  std::vector<mi355_result> res((size_t)S);
+  std::vector<double> fit((size_t)S);
+  ctx_->check(mi355_batch_results(b, res.data(), fit.data()));
+
+  for (int s = 0; s < S; s++) {
+    LoopResult& r = out[src_of[(size_t)s]];
+    const mi355_result& m = res[(size_t)s];
+    std::copy(m.T, m.T + 16, r.transform.begin());
+    r.converged = m.converged != 0;
+    r.iterations = m.iterations;
+    r.fitness = fit[(size_t)s];
+    r.target_points = m.n_target;
+    r.accepted = r.converged && !(params_.score_threshold < r.fitness);  // :328
+    // :331-340  pose_from = transform * pose(query) through geometry_msgs::Pose, pose_to = pose(candidate)
+    const Pose from = convert_matrix_to_pose(matmul(r.transform, geometry_pose_to_matrix(key_frames_[(size_t)r.query_id].pose)));
+    double A[16], B[16];
+    pose_to_matrix_d(from, A);
+    pose_to_matrix_d(key_frames_[(size_t)r.candidate_id].pose, B);
+    // between = A^-1 * B, A rigid
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) {
+        double acc = 0.0;
+        for (int k = 0; k < 3; k++) acc += A[4 * k + i] * B[4 * k + j];
+        r.between[(size_t)(4 * i + j)] = acc;
+      }
+      double acc = 0.0;
+      for (int k = 0; k < 3; k++) acc += A[4 * k + i] * (B[4 * k + 3] - A[4 * k + 3]);
+      r.between[(size_t)(4 * i + 3)] = acc;
+    }
+    r.between[12] = r.between[13] = r.between[14] = 0.0;
+    r.between[15] = 1.0;
+  }
+  return out;
+}
+
+}  // namespace mi355
+
+// ---- C-ABI (include/mi355_loop_closure.h) ----------------------------------------------------------------------------
+struct mi355_loop_closure {
+  std::unique_ptr<mi355::LoopClosureCore> core;
+  std::string err;
+};
+
+template <typename F>
+static int lc_guarded(mi355_loop_closure* h, F&& f) {
+  try {
+    f();
+    return MI355_OK;
+  } catch (const mi355::Error& e) {
+    h->err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return MI355_EINVAL;
+  }
+}
+
+static mi355::Pose pose_from7(const double p[7]) {
+  mi355::Pose q;
+  q.px = p[0]; q.py = p[1]; q.pz = p[2];
+  q.qx = p[3]; q.qy = p[4]; q.qz = p[5]; q.qw = p[6];
+  return q;
+}
+
+extern "C" void mi355_loop_closure_default_params(mi355_loop_closure_params* p) {
+  if (!p) return;
+  const mi355::LoopClosureParams d;
+  p->search_key_frame_num = d.search_key_frame_num;
+  p->score_threshold = d.score_threshold;
+  p->search_for_candidate_threshold = d.search_for_candidate_threshold;
+  p->accumulate_distance_threshold = d.accumulate_distance_threshold;
+  p->submap_leaf = d.submap_leaf;
+  p->max_iteration = d.max_iteration;
+  p->transformation_epsilon = d.transformation_epsilon;
+  p->max_correspondence_distance = d.max_correspondence_distance;
+  p->correspondence_randomness = d.correspondence_randomness;
+}
+
+extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi355_loop_closure_params* p) {
+  if (!p || p->search_key_frame_num < 0 || !(p->submap_leaf >= 0.f)) return nullptr;
+  mi355::LoopClosureParams lp;
+  lp.search_key_frame_num = p->search_key_frame_num;
+  lp.score_threshold = p->score_threshold;
+  lp.search_for_candidate_threshold = p->search_for_candidate_threshold;
+  lp.accumulate_distance_threshold = p->accumulate_distance_threshold;
+  lp.submap_leaf = p->submap_leaf;
+  lp.max_iteration = p->max_iteration;
+  lp.transformation_epsilon = p->transformation_epsilon;
+  lp.max_correspondence_distance = p->max_correspondence_distance;
+  lp.correspondence_randomness = p->correspondence_randomness;
+  auto* h = new mi355_loop_closure();
+  h->core.reset(new mi355::LoopClosureCore(device_id, lp));
+  return h;
+}
+
+extern "C" void mi355_loop_closure_destroy(mi355_loop_closure* h) { delete h; }
+
+extern "C" const char* mi355_loop_closure_last_error(const mi355_loop_closure* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int mi355_loop_closure_add_key_frame(mi355_loop_closure* h, const mi355_cloud_view* cloud, const double pose7[7], double accum_distance) {
+  if (!h || !cloud || !pose7 || (cloud->n && !cloud->data)) return -1;
+  try {
+    mi355::PointCloud in(cloud->n);
+    const char* base = (const char*)cloud->data;
+    for (size_t i = 0; i < cloud->n; i++) {
+      const float* p = (const float*)(base + i * cloud->stride);
+      in[i].x = p[0]; in[i].y = p[1]; in[i].z = p[2]; in[i].w = 1.f;
+      in[i].intensity = *(const float*)(base + i * cloud->stride + cloud->intensity_offset);
+      in[i].pad[0] = in[i].pad[1] = in[i].pad[2] = 0.f;
+    }
+    return h->core->add_key_frame(std::move(in), pose_from7(pose7), accum_distance);
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return -1;
+  }
+}
+
+extern "C" int mi355_loop_closure_set_pose(mi355_loop_closure* h, int key_frame_id, const double pose7[7]) {
+  if (!h || !pose7) return MI355_EINVAL;
+  return lc_guarded(h, [&] {
+    if (key_frame_id < 0 || (size_t)key_frame_id >= h->core->size()) throw mi355::Error(MI355_EINVAL, "key frame id out of range");
+    h->core->set_pose(key_frame_id, pose_from7(pose7));
+  });
+}
+
+extern "C" int mi355_loop_closure_candidate(const mi355_loop_closure* h, int query_id, int* candidate_id) {
+  if (!h || !candidate_id) return MI355_EINVAL;
+  return lc_guarded(const_cast<mi355_loop_closure*>(h), [&] { *candidate_id = h->core->candidate(query_id); });
+}
+
+extern "C" int mi355_loop_closure_close(mi355_loop_closure* h, const int* query_ids, int n_queries, mi355_loop_result* results) {
+  if (!h || n_queries < 0 || (n_queries && (!query_ids || !results))) return MI355_EINVAL;
+  return lc_guarded(h, [&] {
+    const std::vector<mi355::LoopResult> r = h->core->close(std::vector<int>(query_ids, query_ids + n_queries));
+    for (int i = 0; i < n_queries; i++) {
+      mi355_loop_result& o = results[i];
+      o.query_id = r[(size_t)i].query_id;
+      o.candidate_id = r[(size_t)i].candidate_id;
+      o.converged = r[(size_t)i].converged;
+      o.accepted = r[(size_t)i].accepted;
+      o.iterations = r[(size_t)i].iterations;
+      o.fitness = r[(size_t)i].fitness;
+      std::copy(r[(size_t)i].transform.begin(), r[(size_t)i].transform.end(), o.transform);
+      std::copy(r[(size_t)i].between.begin(), r[(size_t)i].between.end(), o.between);
+      o.target_points = r[(size_t)i].target_points;
+    }
+  });
+}

@@ -1,0 +1,57 @@
+// LoopClosureCore — ROS-free restatement of the registration half of GraphBasedSLAM::optimization_callback
+// (/root/reference/graph_based_slam/src/graph_based_slam.cpp:238-328) over plain structs, batched: the reference closes
+// one loop per 1 Hz tick (latest key frame vs the sub-map around ONE candidate); here any number of query key frames are
+// registered against the sub-maps around their candidates in one mi355_batch_* launch sequence (BASELINE config 5).
+// The pose graph (GTSAM iSAM2, :331-349) stays with the caller, which receives the relative pose of the loop factor.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "scan_matcher_core.hpp"
+
+namespace mi355 {
+
+struct LoopClosureParams {  // graph_based_slam.param.yaml:3-23; sub-map leaf hard-coded at graph_based_slam.cpp:61
+  int search_key_frame_num = 20;
+  double score_threshold = 0.3;
+  double search_for_candidate_threshold = 15.0;
+  double accumulate_distance_threshold = 100.0;
+  float submap_leaf = 0.5f;
+  int max_iteration = 100;
+  double transformation_epsilon = 0.01;
+  double max_correspondence_distance = 2.0;
+  int correspondence_randomness = 20;
+};
+
+struct LoopResult {
+  int query_id = -1, candidate_id = -1;
+  bool converged = false, accepted = false;
+  int iterations = 0;
+  double fitness = 0.0;
+  Matrix4f transform = identity4();
+  std::array<double, 16> between{};  // pose_from.between(pose_to), row-major
+  size_t target_points = 0;
+};
+
+class LoopClosureCore {
+ public:
+  LoopClosureCore(int device_id, const LoopClosureParams& p) : device_id_(device_id), params_(p) {}
+  // key_frame_callback's bookkeeping (:354-380): the cloud is in the key frame's own frame
+  int add_key_frame(PointCloud cloud, const Pose& pose, double accum_distance);
+  void set_pose(int id, const Pose& pose) { key_frames_.at((size_t)id).pose = pose; }
+  // :256-280 with `query` in the role of the latest key frame; -1 = no candidate
+  int candidate(int query) const;
+  // :282-341 for every query, one batch
+  std::vector<LoopResult> close(const std::vector<int>& queries);
+  size_t size() const { return key_frames_.size(); }
+
+ private:
+  // pcl::transformPointCloud with the evaluation order the library and the oracle share (devmath.hpp transform_row)
+  static void append_transformed(const PointCloud& in, const Matrix4f& T, std::vector<float>& packed);
+  int device_id_;
+  LoopClosureParams params_;
+  std::vector<KeyFrame> key_frames_;
+  std::unique_ptr<Context> ctx_;  // created by the first close(): the bookkeeping above needs no GPU
+};
+
+}  // namespace mi355

@@ -26,6 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(L.EXPORTS) == syms  # the Python binding lists exactly the header's entry points
     sm = [s for s in _header_symbols("mi355_scan_matcher.h") if s.startswith("mi355_scan_matcher")]
     assert sorted(L.EXPORTS_SCAN_MATCHER) == sm and all(hasattr(lib, s) for s in sm)
+    lc = [s for s in _header_symbols("mi355_loop_closure.h") if s.startswith("mi355_loop_closure")]
+    assert sorted(L.EXPORTS_LOOP_CLOSURE) == lc and all(hasattr(lib, s) for s in lc)
 
 
 def test_default_params_match_reference_yaml():

@@ -1,0 +1,60 @@
+"""GPU parity of the batched loop-closure caller: LoopClosureCore (C++) + the HIP batch registration
+against an independent restatement of graph_based_slam.cpp:238-341 that registers with the oracle."""
+import numpy as np
+import pytest
+
+from lidar_graph_slam_amd import synth
+from oracle import oracle_py as O
+from ref_loop_closure import RefLoopClosure
+from ref_scan_matcher import matrix_to_pose
+
+pytestmark = pytest.mark.gpu
+
+
+def _out_and_back(n_out=16, spacing=2.5):
+    """Key frames along the corridor and back on the other lane: the last ones pass the first ones again after > 60 m."""
+    poses = [synth.se3(spacing * i, 1.0, 0.0, 0.0, 0.0, 0.0) for i in range(n_out)]
+    poses += [synth.se3(spacing * (n_out - 1 - i), -1.0, 0.0, 0.0, 0.0, np.pi) for i in range(n_out)]
+    return poses
+
+
+def test_batched_loop_closure_matches_restatement():
+    from lidar_graph_slam_amd.loop_closure import LoopClosure
+
+    scene = synth.Scene(1234)
+    truth = _out_and_back()
+    kw = dict(search_key_frame_num=2, search_for_candidate_threshold=6.0, accumulate_distance_threshold=50.0, max_iteration=30)
+    lc, ref = LoopClosure(**kw), RefLoopClosure(**kw)
+    accum = 0.0
+    for i, T in enumerate(truth):
+        cloud = synth.cast_scan(scene, T, n_rings=32, n_azimuth=360, noise_sigma=0.01, seed=100 + i)
+        cloud = O.distance_filter(cloud, 1.0)
+        if i:
+            accum += float(np.linalg.norm(truth[i][:3, 3] - truth[i - 1][:3, 3]))
+        # odometry drift on the way back: the pose the back end believes is off by a few decimetres
+        drift = synth.se3(0.25, -0.15, 0.0, 0.0, 0.0, 0.01) if i >= len(truth) // 2 else np.eye(4)
+        p, q = matrix_to_pose((drift @ T).astype(np.float32))
+        assert lc.add_key_frame(cloud, p, q, accum) == ref.add_key_frame(cloud, p, q, accum) == i
+    queries = list(range(len(truth) - 5, len(truth))) + [3]  # the last five key frames, and one without a candidate
+    got = lc.close_loops(queries)
+    assert [g["query_id"] for g in got] == queries
+    n_registered = 0
+    for g in got:
+        w = ref.close_loop(g["query_id"])
+        assert g["candidate_id"] == w["candidate_id"]
+        if w["candidate_id"] < 0:
+            continue
+        n_registered += 1
+        assert g["target_points"] == w["target_points"]  # same sub-map after the 0.5 m VoxelGrid
+        assert g["converged"] == w["converged"] and g["accepted"] == w["accepted"]
+        dt, dr = synth.pose_error(g["T"], w["T"])
+        assert dt < 0.02 and dr < 4e-3, (g["query_id"], dt, dr)  # both stop inside the 0.01 m / 2e-3 rad convergence band
+        # the fitness the GPU reports is the reference's getFitnessScore at the GPU's own pose
+        np.testing.assert_allclose(g["fitness"], O.fitness(w["source"], w["target"], g["T"]), rtol=1e-6)
+        # the correction undoes the drift: the corrected pose is the true one
+        corrected = g["T"].astype(np.float64) @ (synth.se3(0.25, -0.15, 0.0, 0.0, 0.0, 0.01) @ truth[g["query_id"]])
+        dt, dr = synth.pose_error(corrected, truth[g["query_id"]])
+        assert dt < 0.05 and dr < 5e-3, (dt, dr)
+        bt, br = synth.pose_error(g["between"], w["between"])
+        assert bt < 0.03 and br < 5e-3
+    assert n_registered >= 4
