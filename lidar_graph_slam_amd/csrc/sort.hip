@@ -45,16 +45,19 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_hist(const uint32_t* __rest
     for (int d = l; d < 256; d += kWave) hist[((size_t)c * 256 + d) * nsub + sub] = cnt[w][d];
 }
 
-// Exclusive scan of the 256*nsub histogram of each cloud (digit-major), in place.
-__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ hist, int nsub) {
+// Exclusive scan of the histogram of each cloud (digit-major), in place.  Only the sub-tiles the cloud actually fills take
+// part (a 16 k-point cloud in a 64 k-point segment uses 17 of the 64 columns of every digit row).
+__global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ hist, const int* __restrict__ counts, int nsub) {
   __shared__ int wsum[16];
   int* h = hist + (size_t)blockIdx.x * 256 * nsub;
-  const int total = 256 * nsub;
+  const int used = min(nsub, max(1, (counts[blockIdx.x] + kSubTile - 1) / kSubTile));
+  const int total = 256 * used;
   const int per = (total + 1023) / 1024;
-  const int beg = threadIdx.x * per;
+  const int beg = min(threadIdx.x * per, total);
   const int end = min(beg + per, total);
+  auto at = [&](int e) -> int& { return h[(e / used) * nsub + (e % used)]; };
   int s = 0;
-  for (int i = beg; i < end; i++) s += h[i];
+  for (int i = beg; i < end; i++) s += at(i);
   // block exclusive scan of s
   int v = s;
 #pragma unroll
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(1024) void k_sort_scan(int* __restrict__ hist, int 
   }
   __syncthreads();
   int run = wsum[wave_id()] + v - s;
-  for (int i = beg; i < end; i++) { const int t = h[i]; h[i] = run; run += t; }
+  for (int i = beg; i < end; i++) { const int t = at(i); at(i) = run; run += t; }
 }
 
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const uint32_t* __restrict__ keys_in, const int* __restrict__ vals_in,
@@ -125,7 +128,7 @@ void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_co
   for (int p = 0; p < passes; p++) {
     const int shift = 8 * p;
     hipLaunchKernelGGL(k_sort_hist, grid, dim3(kSortBlock), 0, s, ka, d_counts, ws.hist.p, cap, nsub, shift);
-    hipLaunchKernelGGL(k_sort_scan, dim3(B), dim3(1024), 0, s, ws.hist.p, nsub);
+    hipLaunchKernelGGL(k_sort_scan, dim3(B), dim3(1024), 0, s, ws.hist.p, d_counts, nsub);
     hipLaunchKernelGGL(k_sort_scatter, grid, dim3(kSortBlock), 0, s, ka, va, kb, vb, d_counts, ws.hist.p, cap, nsub, shift);
     std::swap(ka, kb);
     std::swap(va, vb);
