@@ -176,7 +176,9 @@ __device__ __forceinline__ void search_point(const GridView& g, float qx, float 
   float margin;
   if (nn.j1 >= 0 && nn.d1 < max_corr_d2) {
     j_out = nn.j1;
-    margin = 0.5f * (sqrtf(fminf(nn.d2nd, explored2)) - sqrtf(nn.d1));
+    // the correspondent stays the nearest while the query moves less than half the gap to the runner-up, and stays in range
+    // while it moves less than its distance to the range limit: one margin covers both, so an unmoved point is never touched
+    margin = fminf(0.5f * (sqrtf(fminf(nn.d2nd, explored2)) - sqrtf(nn.d1)), max_corr - sqrtf(nn.d1));
   } else {
     // nothing within range: stays so until the query has moved by (distance to the nearest thing) - max_corr
     j_out = -1;
@@ -233,14 +235,9 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
       const float4 qs = qsearch[so + i];
       const bool finite_q = isfinite(qx) && isfinite(qy) && isfinite(qz);
       const float moved = sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z));
-      bool need_search = !(moved < qs.w) || (debug_flags & 4);  // NaN margin (never searched) -> search
-      if (!need_search) {
-        const int jprev = corr[so + i];
-        if (jprev >= 0) {
-          const float4 pp = g.pts[jprev];
-          need_search = !(dist2f(qx, qy, qz, pp.x, pp.y, pp.z) < max_corr_d2);  // drifted out of range: re-establish the state
-        }
-      }
+      // NaN margin (never searched) -> search.  The margin also covers "still within max_corr" (search_point), so a point
+      // that passes this test needs neither its correspondence index nor its correspondent: 32 B per point in steady state.
+      const bool need_search = !(moved < qs.w) || (debug_flags & 4);
       if (!finite_q) {
         corr[so + i] = -1;
       } else if (need_search) {
