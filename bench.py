@@ -71,18 +71,25 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DEVICE / BENCH_BACKEND exist so that the multi-rank code path can be exercised on a box with ONE GPU (every rank
+    # on device 0, gloo for the two tiny collectives); the driver's runs use neither.
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        backend = os.environ.get("BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from lidar_graph_slam_amd import _lib as L
     from lidar_graph_slam_amd import sharding, synth
     from lidar_graph_slam_amd.context import Context
     from lidar_graph_slam_amd.registration import BatchRegistration
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.cell > 0:
         ctx.set_grid_cell(args.cell)
