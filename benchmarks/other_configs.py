@@ -41,6 +41,7 @@ def timed(f, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=40)
+    ap.add_argument("--lc-candidates", type=int, default=512, help="loop-closure candidates per batch (config 5: 4096 / 8 GPUs)")
     ap.add_argument("--cpu", action="store_true", help="also time the oracle (CPU) where it is cheap enough")
     args = ap.parse_args()
     out = {}
@@ -140,6 +141,12 @@ def main():
         counts_s.append(len(cm))
         tgt_of_src.append(k)
         truth.append(P @ np.linalg.inv(synth.se3(20.0 * k, 0, 0)))
+    # the per-GPU share of BASELINE config 5 (4096 candidates over 8 GPUs = 512 per GPU): the 64 cast candidates repeated
+    rep = max(1, args.lc_candidates // n_cand)
+    if rep > 1:
+        sr = np.tile(sr, (rep, 1, 1))
+        counts_s, tgt_of_src, truth = counts_s * rep, tgt_of_src * rep, truth * rep
+        n_cand *= rep
     b = BatchRegistration(n_cand, n_sub, cap, max_iterations=64)
     vox = L.prefilter_params(min_distance=0.0, leaf_size=0.5, mean_k=0)  # graph_based_slam.cpp:61,311-313
 
