@@ -656,11 +656,14 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
   // fork: everything already enqueued on the context stream (the producer of d_points, the previous align that still reads
   // this cloud set) comes first
-  MI_HIP(hipEventRecord(sd.fork, b->stream()));
-  MI_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
+  static const bool side_streams = !(getenv("MI355_BATCH_SIDE_STREAMS") && atoi(getenv("MI355_BATCH_SIDE_STREAMS")) == 0);
+  if (side_streams) {
+    MI_HIP(hipEventRecord(sd.fork, b->stream()));
+    MI_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
+  }
   if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));  // h_counts of a not-yet-joined call may still be read by its copy
   sd.h_counts.assign(counts, counts + B);
-  hipStream_t s = sd.stream;
+  hipStream_t s = side_streams ? sd.stream : b->stream();
   MI_HIP(hipMemcpyAsync(sd.cnt_in.p, sd.h_counts.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
   const float4* pts = d_points;
   const int* cnt = sd.cnt_in.p;
@@ -669,8 +672,10 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
                   sd.ws.count_b, &pts, &cnt);
   build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell);
   compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
-  MI_HIP(hipEventRecord(sd.join, s));
-  sd.pending = true;
+  if (side_streams) {
+    MI_HIP(hipEventRecord(sd.join, s));
+    sd.pending = true;
+  }
 }
 
 // Make the context stream wait for the side streams' pending work.

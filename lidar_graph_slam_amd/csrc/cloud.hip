@@ -198,19 +198,6 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   out.has_cov = false;
 }
 
-// Upper bound of the k-th NN distance of sorted point i: the farthest of the k points at sorted positions around i
-// (Morton order keeps them close; they are k distinct real points, the query itself included, so the bound is valid).
-__device__ __forceinline__ float morton_window_hint(const GridView& g, int i, const float4& q, int k) {
-  int lo = i - k / 2;
-  lo = max(0, min(lo, g.m.n - k));
-  float d2max = 0.f;
-  for (int j = lo; j < lo + k; j++) {
-    const float4 p = g.pts[j];
-    d2max = fmaxf(d2max, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
-  }
-  return d2max;
-}
-
 // ---- k-NN covariances (F2) --------------------------------------------------------------------------------------
 // next point at exactly tau2 whose caller index is the smallest one greater than `last` (tie resolution, rare path)
 struct NextEq {

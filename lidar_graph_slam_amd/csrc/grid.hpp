@@ -472,43 +472,6 @@ struct BallCollector {
   }
 };
 
-// NearestK with an LDS staging queue.  The sorted insertion is ~170 instructions; under SIMT a wave executes it for a
-// candidate whenever ANY of its 64 lanes wants that candidate, i.e. for almost every candidate.  Here a lane only appends
-// (d2, j) of candidates that beat its current worst to a small private queue in LDS; the queues are drained together —
-// when one of them fills up and at shell boundaries — so the insertion block runs with most lanes active.  The bound
-// used for pruning between drains is the (looser) bound of the last drain, which is always safe.
-template <int K, int Q>
-struct NearestKQ : NearestK<K> {
-  int2* queue;  // this wave's Q x 64 slots, slot t of lane l at [t * 64 + l]
-  int lane, len;
-  __device__ __forceinline__ void init_queue(int2* wave_queue) {
-    queue = wave_queue;
-    lane = threadIdx.x & 63;
-    len = 0;
-  }
-  __device__ __forceinline__ void flush() {
-    for (int t = 0; t < Q; t++) {
-      if (!__any(t < len)) break;
-      if (t < len) {
-        const int2 c = queue[t * 64 + lane];
-        NearestK<K>::visit(c.y, __int_as_float(c.x));
-      }
-    }
-    len = 0;
-  }
-  __device__ __forceinline__ void restart() {
-    flush();
-    NearestK<K>::restart();
-  }
-  __device__ __forceinline__ void visit(int j, float dd) {
-    if (dd > this->hint) return;
-    if (!this->less(dd, j, this->d2[K - 1], this->idx[K - 1])) return;
-    queue[len * 64 + lane] = make_int2(__float_as_int(dd), j);
-    len++;
-    if (__any(len >= Q)) flush();
-  }
-};
-
 // Level at which a k-NN query of a point of the cloud itself should start: the finest level whose own cell already
 // holds about k/3 points (then shells r <= 1 almost always suffice).  Only a speed heuristic — any level is exact.
 __device__ __forceinline__ int knn_start_level(const GridView& g, float qx, float qy, float qz, int k, int need_div = 3) {

@@ -16,12 +16,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
   return v;  // valid in lane 0
 }
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-  return v;
-}
-
 // Sum NV doubles per thread across a block of NW waves.  Result valid in thread 0 (acc[] overwritten).
 // `smem` must hold NW * NV doubles.
 template <int NV, int NW>
