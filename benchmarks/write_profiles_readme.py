@@ -92,6 +92,16 @@ Targets and sources are prepared on two concurrent streams, so the kernel times 
         out += f"| `{name}` | {t[1]:.0f} | {t[0]:.2f} | {note} |\n"
     by_threads = ", ".join(f"{t}: {v}" for t, v in cpu["pairs_per_s_by_threads"].items())
     out += f"""
+## What bounds the other kernels (`{R}_pmc_valu.csv`, 128 pairs/step, per-launch PMC averages)
+
+| kernel | bound | evidence |
+|---|---|---|
+| `k_knn_cov_tile` | VALU (median network: ~30 instructions per candidate and wave) | VALUBusy 64 %, 626 M VALU instructions per launch, 2 waves/SIMD (177 VGPRs, 16 KB LDS per wave); 26 % of the wave cycles waiting |
+| `k_gicp_correspond` | latency (dependent loads of the per-lane voxel-hash walk) | VALUBusy 19 %, 71 % of the wave cycles waiting; early iterations dominated by the 16 % of points with no neighbour within 1 m |
+| `k_gicp_error` | fp64 VALU + HBM, about balanced | VALUBusy 42 %, 60 B/pt read |
+| `k_gicp_linearize` | HBM (see above) | VALUBusy 34 %, 58 % of the wave cycles waiting on memory |
+| `k_sort_scatter` | HBM, scattered 4-byte writes | VALUBusy 20 %, 67 % waiting |
+
 ## Other measurements of the round
 
 | what | value |
