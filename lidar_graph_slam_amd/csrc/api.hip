@@ -183,6 +183,10 @@ extern "C" mi355_ctx* mi355_create(int device_id) {
     return nullptr;
   }
   ctx->own_stream = true;
+  if (const char* e = getenv("MI355_GRID_CELL")) {  // tuning knob: base cell of the voxel hash (m); results do not depend on it
+    const float c = (float)atof(e);
+    if (c > 0.f) ctx->grid_cell = c;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
     ctx->compute_units = prop.multiProcessorCount;

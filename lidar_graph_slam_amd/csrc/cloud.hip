@@ -646,7 +646,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
   hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                      set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, r_scale);
   // the points the tile kernel handed over: one wave per point, then their covariances from the lists
-  const int Gh = 64;
+  const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
   hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p,
                      (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, Gh, set.B);
   hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
