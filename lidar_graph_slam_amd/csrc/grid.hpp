@@ -307,7 +307,7 @@ __device__ __forceinline__ void grid_ball_search(const GridView& g, float qx, fl
 
 // ---- visitors -----------------------------------------------------------------------------------------------------
 struct Nearest1 {
-  static constexpr int kScanWidth = 2;
+  static constexpr int kScanWidth = 4;
   const int* orig;
   float best_d2;
   int best_j;
@@ -323,7 +323,7 @@ struct Nearest1 {
 // Nearest + distance of the runner-up: what the incremental correspondence update needs (gicp.hip).  The search
 // prunes with the runner-up distance, so both are exact inside the explored region; `limit` caps a ball query.
 struct Nearest2 {
-  static constexpr int kScanWidth = 2;
+  static constexpr int kScanWidth = 4;
   const int* orig;
   float d1;
   int j1;
