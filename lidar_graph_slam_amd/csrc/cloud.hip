@@ -288,20 +288,36 @@ extern "C" unsigned mi355_debug_tile_log(unsigned long long* out, unsigned max_e
 #endif
 
 // Neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation; point(t) returns the t-th neighbour.
-template <typename P>
+// KU > 0: the two passes over the neighbours are unrolled KU times (guarded by t < k), so a caller that keeps the neighbour
+// list in registers indexes it with compile-time constants; KU == 0: plain loops.
+template <int KU, typename P>
 __device__ __forceinline__ void covariance_of(int k, int method, Cov6* o, P&& point) {
   double mx = 0, my = 0, mz = 0;
-  for (int t = 0; t < k; t++) {
+  auto add_mean = [&](int t) {
     const float4 p = point(t);
     mx += (double)p.x; my += (double)p.y; mz += (double)p.z;
+  };
+  if constexpr (KU > 0) {
+#pragma unroll
+    for (int t = 0; t < KU; t++)
+      if (t < k) add_mean(t);
+  } else {
+    for (int t = 0; t < k; t++) add_mean(t);
   }
   const double invk = 1.0 / (double)k;
   mx *= invk; my *= invk; mz *= invk;
   Sym3<double> cv = {0, 0, 0, 0, 0, 0};
-  for (int t = 0; t < k; t++) {
+  auto add_cov = [&](int t) {
     const float4 p = point(t);
     const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
     cv.xx += x * x; cv.xy += x * y; cv.xz += x * z; cv.yy += y * y; cv.yz += y * z; cv.zz += z * z;
+  };
+  if constexpr (KU > 0) {
+#pragma unroll
+    for (int t = 0; t < KU; t++)
+      if (t < k) add_cov(t);
+  } else {
+    for (int t = 0; t < k; t++) add_cov(t);
   }
   cv.xx *= invk; cv.xy *= invk; cv.xz *= invk; cv.yy *= invk; cv.yz *= invk; cv.zz *= invk;
   const Sym3<double> r = regularize_covariance(cv, method);
@@ -465,7 +481,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         { const int cnt = __popcll(__ballot(closed && !exact)); TILE_STAT(14, cnt); }
 #endif
         fb = fb || (act && !exact);
-        if (exact) covariance_of(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.at(t) & kOrdMask]; });
+        if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the list
 #ifdef MI355_TILE_STATS
         n_a += n_ord;
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
   if (i >= n) return;
   const float4* p0 = pts + (size_t)c * cap;
   const int* nb = nbr + ((size_t)c * cap + i) * k;
-  covariance_of(k, method, cov + ((size_t)c * cap + i), [&](int t) {
+  covariance_of<0>(k, method, cov + ((size_t)c * cap + i), [&](int t) {
     const int j = nb[t];
     return j >= 0 ? p0[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   });
