@@ -497,7 +497,7 @@ __device__ __forceinline__ double point_error(const Pose& x, const float4& p, co
 // registers and walks the trials in a rolled loop; a trial pose is wave-uniform and comes through scalar loads into SGPRs,
 // so the register budget is the points plus NT accumulators (the first version kept all NT poses in VGPRs: 256 VGPRs +
 // AGPRs, one wave per SIMD, and spent its time waiting on the point loads with nothing to overlap them).
-constexpr int kErrPoints = 4;
+constexpr int kErrPoints = 2;
 template <int NT>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
