@@ -127,7 +127,7 @@ def main():
     batches = [BatchRegistration(P, P, cap, ctx=ctx, **params) for _ in range(max(1, args.inflight))]
     streams = []
     if len(batches) > 1:
-        streams = [torch.cuda.Stream(device=dev) for _ in batches]
+        streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in batches]  # LM iterations ahead of the (low-priority) indexing chains
         for b_, s_ in zip(batches, streams):
             b_.set_stream(s_.cuda_stream)
     pre = L.prefilter_params(min_distance=1.0, leaf_size=args.leaf, mean_k=0)

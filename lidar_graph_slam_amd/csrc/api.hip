@@ -628,7 +628,11 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
     b->gb.time_kernels = true;
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
-      MI_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+      // the preparation chains run at the lowest priority: when batches overlap (mi355_batch_set_stream), the short,
+      // latency-bound kernels of another batch's LM iterations get the freed wave slots first
+      int prio_lo = 0, prio_hi = 0;
+      MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+      MI_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, prio_lo));
       MI_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
       MI_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
       ws_reserve(sd.ws, k == 0 ? n_targets : n_sources, capacity);
