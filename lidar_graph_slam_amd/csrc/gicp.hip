@@ -444,13 +444,12 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
     sums[l] = s;
   }
   __syncthreads();
-  if (l == 0) {
-    GicpPairState s = *st;
-    unpack_normal_equations(sums, s.H, s.b);
-    s.y0 = sums[27];
-    s.n_inliers = (int)(sums[28] + 0.5);
-    do_trials = 0;
-    if (P.optimizer == MI355_OPT_GN) {
+  if (P.optimizer == MI355_OPT_GN) {
+    if (l == 0) {
+      GicpPairState s = *st;
+      unpack_normal_equations(sums, s.H, s.b);
+      s.y0 = sums[27];
+      s.n_inliers = (int)(sums[28] + 0.5);
       double nb[6];
       for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
       ldlt6_solve(s.H, nb, s.d);
@@ -459,22 +458,31 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
       for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
       s.last_error = s.y0;
       finish_step(s, P, true);
-    } else {
-      if (s.lambda < 0.0) {
-        double mx = 0;
-        for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(s.H[7 * i]));
-        s.lambda = P.lm_init_lambda_factor * mx;
-      }
-      s.need_error = 1;
-      do_trials = 1;
-      for (int i = 0; i < 36; i++) sH[i] = s.H[i];
-      for (int i = 0; i < 6; i++) sb[i] = s.b[i];
-      slambda = s.lambda;
-      sx0 = s.x0;
+      *st = s;
     }
-    *st = s;
+    return;
   }
+  // LM: only the fields that change are touched (a copy of the 1 KB state through one lane's scratch cost 15 of the 30 us)
+  if (l == 0) {
+    unpack_normal_equations(sums, sH, sb);
+    double lam = st->lambda;
+    if (lam < 0.0) {
+      double mx = 0;
+      for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(sH[7 * i]));
+      lam = P.lm_init_lambda_factor * mx;
+      st->lambda = lam;
+    }
+    slambda = lam;
+    st->y0 = sums[27];
+    st->n_inliers = (int)(sums[28] + 0.5);
+    st->need_error = 1;
+    do_trials = 1;
+  }
+  if (l < 9) sx0.R[l] = st->x0.R[l];
+  else if (l < 12) sx0.t[l - 9] = st->x0.t[l - 9];
   __syncthreads();
+  if (l < 36) st->H[l] = sH[l];
+  if (l < 6) st->b[l] = sb[l];
   if (do_trials && l < P.lm_max_iterations) {
     // lambda of trial l: step_lm multiplies by nu = 2, 4, 8, ... after each rejection
     double lam = slambda, nu = 2.0;
