@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
   }
   __syncthreads();
   if (l != 0) return;
-  GicpPairState s = state[pair];
+  GicpPairState& s = state[pair];  // in place: only the fields of the taken branch move (the state is 1 KB)
   bool finished = false;
   double lam_next = s.lambda, nu = 2.0;
   for (int t = 0; t < P.lm_max_iterations && !finished; t++) {
@@ -608,7 +608,6 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
     s.lambda = lam_next;
     finish_step(s, P, false);
   }
-  state[pair] = s;
 }
 
 __global__ void k_count_active(const GicpPairState* __restrict__ st, int S, int* __restrict__ n_active) {
