@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--leaf", type=float, default=0.2)
     ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")

@@ -24,7 +24,8 @@ def last_json(path):
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(SRC, pattern)))
+    # gpurun merges every call's files into the same local directory (rocprofv3 names them by pid): take the newest
+    fs = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
     if not fs:
         raise SystemExit(f"missing {pattern} under {SRC}")
     return fs[-1]

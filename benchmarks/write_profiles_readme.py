@@ -16,7 +16,7 @@ STEPS = 25  # bench defaults: 20 timed + 5 warm-up steps per traced run
 PROGRESSION = """Progression over the round (1 GPU, pairs/s): 416 first correct path → 2 278 multi-level hash → 3 354 XCD-aware mapping →
 4 229 branch-free median-network k-NN → 4 945 speculative all-trials LM → 6 203 (scene fix, LDS-staged centroids) → 6 786
 8-wide candidate loads → 7 416 wave-cooperative tile k-NN fused with the covariance → 7 930 two-stream preparation →
-8 690 long-lived pipelined linearize blocks → 8 920 rolled-trial error kernel → 9 000 24-byte records → 10.3 k at 512 pairs/step → 10.5–10.7 k 4-wide search scans.
+8 690 long-lived pipelined linearize blocks → 8 920 rolled-trial error kernel → 9 000 24-byte records → 10.3 k at 512 pairs/step → 10.6 k 4-wide search scans → 11.5 k at 1 024 pairs/step.
 """
 
 
@@ -106,7 +106,7 @@ Targets and sources are prepared on two concurrent streams, so the kernel times 
 
 | what | value |
 |---|---|
-| `python bench.py` ({pairs} pairs/step) | {b['value']:.0f} pairs/s (over fresh boxes of the pool: 9.2–10.9 k; boxes differ by several per cent) |
+| `python bench.py` ({pairs} pairs/step) | {b['value']:.0f} pairs/s (boxes of the pool differ by several per cent) |
 | `--pairs 128` | {p128['value']:.0f} pairs/s, roofline frac {p128['roofline']['frac']:.3f} |
 | `--inflight 2` | {i2['value']:.0f} pairs/s; `k_gicp_linearize` then shares the GPU with the other batch's indexing: {i2['roofline']['avg_launch_ms'] * 1e3:.0f} µs per launch, frac {i2['roofline']['frac']:.3f} |
 | `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s |
