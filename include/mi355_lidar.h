@@ -97,8 +97,11 @@ typedef struct mi355_result {
   int n_source;             /* source points actually registered (after any prefilter) */
   int n_target;
   int n_inliers;            /* correspondences within max_correspondence_distance at the last linearisation (GICP) */
-  int reserved;
+  int status;               /* batch mode: MI355_PAIR_OK, or why the pair was not registered (T = the guess, converged = 0) */
 } mi355_result;
+#define MI355_PAIR_OK 0
+#define MI355_PAIR_TOO_FEW_POINTS 1 /* source or target holds fewer than k_correspondences points after the prefilter
+                                       (mi355_reg_set_source / _target reject such clouds with MI355_EINVAL) */
 
 void mi355_gicp_default_params(mi355_gicp_params* p);
 void mi355_ndt_default_params(mi355_ndt_params* p);
@@ -108,8 +111,11 @@ void mi355_prefilter_default_params(mi355_prefilter_params* p);
 mi355_ctx* mi355_create(int device_id);
 void mi355_destroy(mi355_ctx* ctx);
 const char* mi355_last_error(const mi355_ctx* ctx);
-/* Run on a caller-owned HIP stream (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
-int mi355_set_stream(mi355_ctx* ctx, void* hip_stream);
+/* own_stream == 0: run on the caller's HIP stream `hip_stream` exactly as given — a NULL handle is the legacy default stream
+ * (torch.cuda.current_stream().cuda_stream is 0 for torch's default stream), so the library's work is ordered with what the
+ * caller enqueued there.  own_stream != 0: the library creates a private non-blocking stream (the state after mi355_create);
+ * inputs handed to the *_dev entry points must then be complete before the call. */
+int mi355_set_stream(mi355_ctx* ctx, void* hip_stream, int own_stream);
 int mi355_synchronize(mi355_ctx* ctx);
 /* NN-grid cell edge in metres for the voxel-hash searches (default 0.5). */
 int mi355_set_grid_cell(mi355_ctx* ctx, float cell);
@@ -178,9 +184,19 @@ int mi355_batch_set_sources(mi355_batch* b, const float* points, const int* coun
 int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesses16, int with_fitness);
 /* Synchronises and copies results (n_sources entries) and optional fitness scores. */
 int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
-/* Dominant-kernel timing of the last mi355_batch_align, measured with HIP events on the context stream:
- * total milliseconds inside the GICP linearise kernel and the number of launches. */
-int mi355_batch_kernel_time(mi355_batch* b, double* linearize_ms, int* linearize_launches);
+/* Per-kernel-family timing for the benchmark's roofline block.  With timing enabled the library records HIP events on the
+ * launching stream around every launch of the hot kernels (k_knn_cov_tile, k_gicp_correspond, k_gicp_linearize, ...; short
+ * kernels that always run back to back, e.g. the 12 launches of one radix sort, share one bracket).
+ * mi355_batch_kernel_times synchronises the batch, returns one entry per family (total milliseconds and number of brackets
+ * since the last call) and resets the counters; *n_out is the number of families that ran (may exceed capacity). */
+typedef struct mi355_kernel_time {
+  char name[64];
+  double total_ms;
+  int launches;
+  int reserved;
+} mi355_kernel_time;
+int mi355_batch_set_timing(mi355_batch* b, int enable);
+int mi355_batch_kernel_times(mi355_batch* b, mi355_kernel_time* out, int capacity, int* n_out);
 
 /* Run this batch on its own HIP stream instead of the context's (use_context_stream != 0 switches back).  Batches on
  * different streams overlap on the GPU: while one batch is in its (latency-bound) LM iterations the next one can be

@@ -65,6 +65,13 @@ class PrefilterParams(C.Structure):
     _fields_ = [("min_distance", C.c_double), ("leaf_size", C.c_double), ("mean_k", C.c_int), ("stddev_mul", C.c_double)]
 
 
+PAIR_OK, PAIR_TOO_FEW_POINTS = 0, 1
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("total_ms", C.c_double), ("launches", C.c_int), ("reserved", C.c_int)]
+
+
 class Result(C.Structure):
     _fields_ = [
         ("T", C.c_float * 16),
@@ -76,7 +83,7 @@ class Result(C.Structure):
         ("n_source", C.c_int),
         ("n_target", C.c_int),
         ("n_inliers", C.c_int),
-        ("reserved", C.c_int),
+        ("status", C.c_int),
     ]
 
     def to_dict(self):
@@ -90,6 +97,7 @@ class Result(C.Structure):
             "n_source": int(self.n_source),
             "n_target": int(self.n_target),
             "n_inliers": int(self.n_inliers),
+            "status": int(self.status),
         }
 
 
@@ -102,7 +110,7 @@ EXPORTS = [
     "mi355_reg_create", "mi355_reg_destroy", "mi355_reg_set_params", "mi355_reg_set_target", "mi355_reg_set_source", "mi355_reg_align",
     "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
-    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_kernel_time",
+    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times",
 ]
 # include/mi355_scan_matcher.h
 EXPORTS_SCAN_MATCHER = [
@@ -188,7 +196,7 @@ def lib():
         L.mi355_destroy.restype = None
         L.mi355_last_error.restype = C.c_char_p
         L.mi355_last_error.argtypes = [C.c_void_p]
-        L.mi355_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_synchronize.argtypes = [C.c_void_p]
         L.mi355_set_grid_cell.argtypes = [C.c_void_p, C.c_float]
         L.mi355_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
@@ -222,7 +230,8 @@ def lib():
         L.mi355_batch_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mi355_batch_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.mi355_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_batch_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
         L.mi355_loop_closure_default_params.argtypes = [C.POINTER(LoopClosureParams)]
         L.mi355_loop_closure_default_params.restype = None
         L.mi355_loop_closure_create.restype = C.c_void_p

@@ -21,8 +21,13 @@ class Context:
             raise L.Mi355Error(rc, self._lib.mi355_last_error(self.handle).decode())
 
     def set_stream(self, hip_stream: int | None):
-        """Run on a caller-owned HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""
-        self.check(self._lib.mi355_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
+        """Run on a caller-owned HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream`` — 0 is torch's (legacy) default
+        stream and is used as such, so device inputs produced by torch kernels on it are ordered with the library's work.
+        ``None`` goes back to a private non-blocking stream of the library."""
+        if hip_stream is None:
+            self.check(self._lib.mi355_set_stream(self.handle, None, 1))
+        else:
+            self.check(self._lib.mi355_set_stream(self.handle, C.c_void_p(int(hip_stream)), 0))
 
     def synchronize(self):
         self.check(self._lib.mi355_synchronize(self.handle))

@@ -8,6 +8,32 @@
 
 using namespace mi355;
 
+namespace mi355 {
+thread_local KernelTimers* g_timers = nullptr;
+const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard+k_cov_from_knn", "k_voxel_centroids", "sort_pairs(k_sort_*)",
+                                                 "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_linearize",
+                                                 "k_gicp_error", "k_gicp_solve+k_gicp_decide", "k_fitness"};
+const Tuning& tuning() {
+  static const Tuning t = [] {
+    Tuning v;
+    auto geti = [](const char* name, int& dst) { if (const char* e = getenv(name)) dst = atoi(e); };
+    auto getf = [](const char* name, float& dst) { if (const char* e = getenv(name)) { const float f = (float)atof(e); if (f > 0.f) dst = f; } };
+    geti("MI355_BLOCKS_PER_PAIR", v.blocks_per_pair);
+    geti("MI355_PPT", v.corr_ppt);
+    geti("MI355_BLOCKS_LIN", v.blocks_lin);
+    geti("MI355_LIN_PPT", v.lin_ppt);
+    geti("MI355_KNN_TILES", v.knn_tiles);
+    geti("MI355_KNN_NEED_DIV", v.knn_need_div);
+    geti("MI355_TILE_WAVES", v.tile_waves);
+    getf("MI355_TILE_RSCALE", v.tile_rscale);
+    geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
+    getf("MI355_GRID_CELL", v.grid_cell);
+    return v;
+  }();
+  return t;
+}
+}  // namespace mi355
+
 namespace {
 
 template <typename F>
@@ -107,6 +133,7 @@ struct mi355_batch {
   Side side[2];  // 0 targets, 1 sources
   CloudSet src, tgt;
   GicpBatch gb;
+  KernelTimers timers;  // mi355_batch_set_timing / mi355_batch_kernel_times
   DevBuf<float4> host_stage;
   hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
   bool has_own_stream = false;
@@ -183,10 +210,7 @@ extern "C" mi355_ctx* mi355_create(int device_id) {
     return nullptr;
   }
   ctx->own_stream = true;
-  if (const char* e = getenv("MI355_GRID_CELL")) {  // tuning knob: base cell of the voxel hash (m); results do not depend on it
-    const float c = (float)atof(e);
-    if (c > 0.f) ctx->grid_cell = c;
-  }
+  ctx->grid_cell = tuning().grid_cell;  // base cell of the voxel hash (m); results do not depend on it
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
     ctx->compute_units = prop.multiProcessorCount;
@@ -213,17 +237,20 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
 
 extern "C" const char* mi355_last_error(const mi355_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context (no HIP device?)"; }
 
-extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
+extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream, int own_stream) {
   if (!ctx) return MI355_EINVAL;
   return guarded(ctx, [&] {
+    MI_HIP(hipSetDevice(ctx->device));
     MI_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream) MI_HIP(hipStreamDestroy(ctx->stream));
-    if (hip_stream) {
-      ctx->stream = (hipStream_t)hip_stream;
-      ctx->own_stream = false;
-    } else {
+    if (own_stream) {
       MI_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
       ctx->own_stream = true;
+    } else {
+      // the caller's stream exactly as given: a NULL handle IS the legacy default stream (what torch's default stream is),
+      // so work enqueued there by the caller is ordered with ours
+      ctx->stream = (hipStream_t)hip_stream;
+      ctx->own_stream = false;
     }
   });
 }
@@ -453,8 +480,17 @@ extern "C" int mi355_reg_set_params(mi355_reg* reg, const void* params) {
     reg->gp = *(const mi355_gicp_params*)params;
     if (old_k != reg->gp.k_correspondences || old_m != reg->gp.regularization_method) { reg->src.has_cov = false; reg->tgt.has_cov = false; }
   } else {
+    // pclomp re-initialises its voxel grid only when the grid itself changes (setResolution and friends), and does so from
+    // the target it already holds: the other setters (iterations, epsilon, step size, threads) leave the target alone
+    const mi355_ndt_params old = reg->np;
     reg->np = *(const mi355_ndt_params*)params;
-    reg->has_tgt = false;  // resolution may have changed: the voxel grid must be rebuilt by the next set_target
+    const bool grid_changed = old.resolution != reg->np.resolution || old.min_points_per_voxel != reg->np.min_points_per_voxel ||
+                              old.min_covar_eigvalue_mult != reg->np.min_covar_eigvalue_mult;
+    if (grid_changed && reg->has_tgt)
+      return guarded(reg->ctx, [&] {
+        MI_HIP(hipSetDevice(reg->ctx->device));
+        ndt_build_target(reg->ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
+      });
   }
   return MI355_OK;
 }
@@ -625,7 +661,6 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
     b->src.alloc(n_sources, capacity);
     b->tgt.alloc(n_targets, capacity);
     gicp_alloc(b->gb, n_sources, capacity, ctx->compute_units);
-    b->gb.time_kernels = true;
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
       // the preparation chains run at the lowest priority: when batches overlap (mi355_batch_set_stream), the short,
@@ -664,7 +699,8 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
   // fork: everything already enqueued on the context stream (the producer of d_points, the previous align that still reads
   // this cloud set) comes first
-  static const bool side_streams = !(getenv("MI355_BATCH_SIDE_STREAMS") && atoi(getenv("MI355_BATCH_SIDE_STREAMS")) == 0);
+  const bool side_streams = tuning().side_streams != 0;
+  TimerScope timing(&b->timers);
   if (side_streams) {
     MI_HIP(hipEventRecord(sd.fork, b->stream()));
     MI_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
@@ -760,6 +796,7 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
     if (!tgt_of_src && b->n_sources != b->n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
     MI_HIP(hipSetDevice(b->ctx->device));
     batch_join(b);
+    TimerScope timing(&b->timers);
     gicp_align(b->stream(), b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
     b->with_fitness = with_fitness != 0;
     if (b->with_fitness) gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
@@ -777,13 +814,32 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
   });
 }
 
-extern "C" int mi355_batch_kernel_time(mi355_batch* b, double* linearize_ms, int* linearize_launches) {
+extern "C" int mi355_batch_set_timing(mi355_batch* b, int enable) {
   if (!b) return MI355_EINVAL;
+  b->timers.enabled = enable != 0;
+  return MI355_OK;
+}
+
+extern "C" int mi355_batch_kernel_times(mi355_batch* b, mi355_kernel_time* out, int capacity, int* n_out) {
+  if (!b || !n_out || (capacity > 0 && !out)) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
     MI_HIP(hipSetDevice(b->ctx->device));
-    MI_HIP(hipStreamSynchronize(b->stream()));
-    if (b->gb.ev_used) gicp_finish_timing(b->gb);
-    if (linearize_ms) *linearize_ms = b->gb.last_linearize_ms;
-    if (linearize_launches) *linearize_launches = b->gb.last_linearize_launches;
+    MI_HIP(hipStreamSynchronize(b->stream()));  // the batch stream has joined the side streams: every recorded event is complete
+    for (auto& sd : b->side)
+      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    b->timers.collect();
+    int n = 0;
+    for (int f = 0; f < KF_COUNT; f++) {
+      if (!b->timers.brackets[f]) continue;
+      if (n < capacity) {
+        snprintf(out[n].name, sizeof(out[n].name), "%s", kKernelFamilyName[f]);
+        out[n].total_ms = b->timers.ms[f];
+        out[n].launches = b->timers.brackets[f];
+        out[n].reserved = 0;
+      }
+      n++;
+    }
+    *n_out = n;
+    b->timers.reset();
   });
 }

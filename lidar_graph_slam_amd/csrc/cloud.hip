@@ -79,8 +79,7 @@ static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const
 }
 
 // ---- NN voxel-hash build ----------------------------------------------------------------------------------------
-__global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __restrict__ counts, GridMeta* __restrict__ meta, int B, float cell,
-                            uint32_t slots_cap) {
+__global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __restrict__ counts, GridMeta* __restrict__ meta, int B, float cell) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= B) return;
   GridMeta m;
@@ -107,11 +106,11 @@ __global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __re
   int top = 0;
   while (top < kMaxLevel && (((max(dx, max(dy, dz)) - 1) >> top) > 0)) top++;
   m.top_level = top;
-  m.pad[0] = m.pad[1] = m.pad[2] = 0;
-  uint32_t slots = 16, lg = 4;
-  while (slots < 8u * (uint32_t)max(n, 1) && slots < slots_cap) { slots <<= 1; lg++; }
-  m.hshift = 32 - lg;
-  m.hmask = slots - 1;
+  m.n_cells = 0;
+  m.pad[0] = m.pad[1] = 0;
+  // the hash size is set by k_grid_hash_size once the occupied cells have been counted (after the sort)
+  m.hshift = 28;
+  m.hmask = 15;
   meta[c] = m;
 }
 
@@ -131,6 +130,34 @@ __global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pt
   const float4 p = pts[(size_t)c * cap + i];
   keys[(size_t)c * cap + i] = cell_key(m, p.x, p.y, p.z);
   vals[(size_t)c * cap + i] = i;
+}
+
+// Occupied cells over all levels of a cloud = entries the hash will hold: one per run of equal (key >> 3l) in the sorted keys.
+// The table is then sized to the entries (load factor 0.25 - 0.5), not to the worst case of 5 entries per point: a 16 k-point
+// cloud has ~6 k occupied cells — a 256 KB table that stays in the XCD's L2 while the cloud is searched, instead of 4 MB
+// (the clears alone moved 3.2 GB per 1 024-cloud launch).
+__global__ __launch_bounds__(256) void k_count_cells(const uint32_t* __restrict__ keys, GridMeta* __restrict__ meta, size_t cap) {
+  const int c = blockIdx.y;
+  const int n = meta[c].n, top = meta[c].top_level;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int cnt = 0;
+  if (i < n) {
+    const size_t o = (size_t)c * cap;
+    const uint32_t key = keys[o + i], kprev = (i > 0) ? keys[o + i - 1] : 0u;
+    for (int l = 0; l <= top; l++) cnt += ((i == 0) || ((kprev >> (3 * l)) != (key >> (3 * l)))) ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
+  if (lane_id() == 0 && cnt > 0) atomicAdd(&meta[c].n_cells, cnt);
+}
+
+__global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t slots_cap) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B) return;
+  uint32_t slots = 16, lg = 4;
+  while (slots < 2u * (uint32_t)max(meta[c].n_cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  meta[c].hshift = 32 - lg;
+  meta[c].hmask = slots - 1;
 }
 
 __global__ __launch_bounds__(256) void k_table_clear(HashSlot* __restrict__ table, const GridMeta* __restrict__ meta, size_t slots_cap) {
@@ -184,12 +211,15 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   const size_t cap = out.cap;
   ws_reserve(ws, B, cap);
   compute_bounds(s, ws, in, cnt_in, B, cap);
-  hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, out.meta.p, B, cell, (uint32_t)out.slots_cap);
+  hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, out.meta.p, B, cell);
   hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
   const dim3 grid(div_up((long)cap, 256), B);
   hipLaunchKernelGGL(k_cell_keys, grid, dim3(256), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
   sort_pairs(s, ws, B, cap, cnt_in, 4);
-  hipLaunchKernelGGL(k_table_clear, dim3(std::max(1, std::min(256, (int)(out.slots_cap / 1024))), B), dim3(256), 0, s, out.table.p, out.meta.p,
+  TimedLaunch tl(KF_HASH_BUILD, s);
+  hipLaunchKernelGGL(k_count_cells, grid, dim3(256), 0, s, ws.keys_a.p, out.meta.p, cap);
+  hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap);
+  hipLaunchKernelGGL(k_table_clear, dim3(std::max(1, std::min(32, (int)(out.slots_cap / 8192))), B), dim3(256), 0, s, out.table.p, out.meta.p,
                      out.slots_cap);
   hipLaunchKernelGGL(k_gather_insert, grid, dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p, out.table.p, cap,
                      out.slots_cap);
@@ -265,28 +295,6 @@ __global__ __launch_bounds__(256) void k_knn_self(const float4* __restrict__ pts
   for (; filled < k; filled++) o[filled] = -1;
 }
 
-#ifdef MI355_TILE_STATS  // debug build only: per-tile counters and a per-wave timeline (benchmarks/_tile_stats.py)
-__device__ unsigned long long g_tile_stats[16];
-extern "C" void mi355_debug_tile_stats(unsigned long long* out) {
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stats), sizeof(unsigned long long) * 16);
-  unsigned long long z[16] = {0};
-  hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stats), z, sizeof(z));
-}
-__device__ unsigned long long g_tile_log[1 << 20];
-__device__ unsigned int g_tile_log_n;
-extern "C" unsigned mi355_debug_tile_log(unsigned long long* out, unsigned max_entries) {
-  unsigned n = 0;
-  hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tile_log_n), sizeof(n));
-  if (n > max_entries) n = max_entries;
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_log), sizeof(unsigned long long) * 4 * max_entries);
-  unsigned z = 0;
-  hipMemcpyToSymbol(HIP_SYMBOL(g_tile_log_n), &z, sizeof(z));
-  return n;
-}
-#define TILE_STAT(i, v) do { if (lane_id() == 0) atomicAdd(&g_tile_stats[i], (unsigned long long)(v)); } while (0)
-#define TILE_STAT_MAX(i, v) do { if (lane_id() == 0) atomicMax(&g_tile_stats[i], (unsigned long long)(v)); } while (0)
-#endif
-
 // Neighbourhood covariance in fp64 (divide by k, not k-1) + regularisation; point(t) returns the t-th neighbour.
 // KU > 0: the two passes over the neighbours are unrolled KU times (guarded by t < k), so a caller that keeps the neighbour
 // list in registers indexes it with compile-time constants; KU == 0: plain loops.
@@ -325,21 +333,41 @@ __device__ __forceinline__ void covariance_of(int k, int method, Cov6* o, P&& po
 }
 
 // Steps 1+2, fast path: k-NN and covariance of every point by the wave-cooperative tile search (tile.hpp).  One wave =
-// 64 consecutive points of the Morton-sorted cloud.  The points of the grown tile box are gathered into LDS and walked by
-// every lane through a (k+2)-deep key network; a key is the squared distance with the candidate's list position in the
-// low kOrdBits mantissa bits, so the k smallest keys ARE the neighbour list and the covariance is computed straight from
-// the LDS copies of those points.  The box radius starts from the tile's own point density and grows until it covers the
-// k-th distance of every lane (each round gathers only the shell that is new).
-// A lane's list is exact when (1) the covered radius reaches its k-th distance and (2) its k-th and (k+1)-th keys differ in
-// the distance bits that are left, i.e. truncation cannot have swapped a neighbour with a non-neighbour.  When exactly
-// two candidates share the k-th truncated distance (~1 % of the points) the pair is ranked with the full distances; longer
-// runs, lanes whose neighbourhood does not fit the candidate list and far-field points go to the fallback queue and are
-// done by k_knn_hard + k_cov_from_knn.  A tile whose own box is too large (it straddles a jump of the Morton curve, or lies
-// in the sparse far field) is split into halves, processed one after the other by the whole wave.
+// 64 consecutive points of the Morton-sorted cloud.  The points of the grown tile box are gathered into LDS once; every
+// group of kSubQ consecutive lanes (a SUB-TILE: 8 points that are neighbours on the Morton curve) then gets its own list of
+// the candidates inside ITS grown bounding box, and a lane ranks only its sub-tile's list through a (k+2)-deep key network
+// — about 110 candidates for k = 20 instead of the ~385 of the whole tile, which is what bounded the first version of
+// this kernel (VALU-bound on 64 lanes x 385 candidates x 23 v_med3).  A key is the squared distance with the candidate's
+// position in the tile list in the low kOrdBits mantissa bits, so the k smallest keys ARE the neighbour list and the
+// covariance is computed straight from the LDS copies of those points.  The box radius starts from the tile's own point
+// density and grows until it covers the k-th distance of every lane; a later round gathers only the new shell of the tile
+// box and appends to each open sub-list what entered its own grown box.
+// A lane's list is exact when (1) the radius covered around its sub-tile reaches its k-th distance and (2) its k-th and
+// (k+1)-th keys differ in the distance bits that are left, i.e. truncation cannot have swapped a neighbour with a
+// non-neighbour.  When exactly two candidates share the k-th truncated distance (~1 % of the points) the pair is ranked
+// with the full distances; longer runs, lanes whose neighbourhood does not fit the lists and far-field points go to the
+// fallback queue and are done by k_knn_hard + k_cov_from_knn.  A tile whose own box is too large (it straddles a jump of
+// the Morton curve, or lies in the sparse far field) is split into halves, processed one after the other by the whole wave.
 constexpr int kOrdBits = 10;
 constexpr int kTileMaxCand = 1 << kOrdBits;  // candidates per tile segment (list positions)
 constexpr uint32_t kOrdMask = kTileMaxCand - 1;
 constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
+constexpr int kSubQ = 8;                     // lanes (queries) per sub-tile
+constexpr int kNSub = kWave / kSubQ;
+constexpr int kSubCap = 220;                 // candidates per sub-tile list (16 KB tile list + 3.5 KB of lists per wave: 8 waves per CU)
+constexpr int kSubRow = kSubCap + 4;         // row pitch: the 4-way unrolled rank loop may read (and ignore) up to 3 entries past the end
+
+// min / max over the aligned group of kSubQ lanes a lane belongs to (same value in all lanes of the group)
+__device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+  for (int off = 1; off < kSubQ; off <<= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int off = 1; off < kSubQ; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
 
 // Launch: one-wave blocks, G per cloud (all on the cloud's XCD); a wave takes tiles from the cloud's counter until none
 // is left, so the waves of a cloud finish together whatever the tiles cost.
@@ -348,22 +376,20 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
                                                      Cov6* __restrict__ cov, int* __restrict__ queue, int* __restrict__ queue_n,
                                                      int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k, int method, int G, int B, float r_scale) {
-  __shared__ float4 cand[kTileMaxCand];  // this wave's candidate list (x, y, z, sorted index)
+  __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
+  __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
   const int n = g.m.n;
   const int lane = lane_id();
+  const int mysub = lane / kSubQ, sublane = lane % kSubQ;
+  const unsigned long long below = (1ull << lane) - 1ull;
   for (;;) {
   int tile = 0;
   if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
   const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
   if (tile0 >= n) return;
-#ifdef MI355_TILE_STATS
-  const unsigned long long t_start = wall_clock64();
-  int n_a = 0, n_rounds = 0, n_segs = 0;
-  unsigned long long t_cells = 0, t_gather = 0, t_rank = 0, t_tmp;
-#endif
   const int i = tile0 + lane;
   const bool valid = i < n;
   const float4 q = g.pts[min(i, n - 1)];
@@ -386,28 +412,31 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         const float area = fmaxf(e_max * e_mid, 0.16f * g.m.cell * g.m.cell);
         r = fminf(fmaxf(r_scale * sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
       }
+      // a segment that is a single sub-tile ranks the tile list directly (no sub-list, no 224-entry limit)
+      const bool direct = len <= kSubQ;
+      // this lane's sub-tile box as centre + half extent (the same in the kSubQ lanes of a sub-tile).  The half extent is
+      // padded by eps, so that rounding of centre / extent can only ADD candidates; a sub-tile without active lanes matches
+      // nothing (half extent -inf).
+      float scx, scy, scz, shx, shy, shz;
+      {
+        const float lx = group_min(act ? q.x : INFINITY), ly = group_min(act ? q.y : INFINITY), lz = group_min(act ? q.z : INFINITY);
+        const float hx = group_max(act ? q.x : -INFINITY), hy = group_max(act ? q.y : -INFINITY), hz = group_max(act ? q.z : -INFINITY);
+        const bool some = lx <= hx;
+        scx = some ? 0.5f * (lx + hx) : 0.f; scy = some ? 0.5f * (ly + hy) : 0.f; scz = some ? 0.5f * (lz + hz) : 0.f;
+        shx = some ? 0.5f * (hx - lx) + eps : -INFINITY; shy = some ? 0.5f * (hy - ly) + eps : -INFINITY;
+        shz = some ? 0.5f * (hz - lz) + eps : -INFINITY;
+      }
+      int slen = 0, sdone = 0;  // this lane's sub-list: entries appended / ranked so far (the same in the lanes of a sub-tile)
       SmallestKeys<K + 2> keys;
       keys.init();
       int n_ord = 0;
       TileBox ob = bb;
-      bool has_old = false, open = act;
-#ifdef MI355_TILE_STATS
-      n_segs++;
-#endif
+      float r_old = -INFINITY;
+      bool has_old = false, open = act, ovf = false;
       for (int round = 0;; round++) {
         const TileBox nb = grow(bb, r);
-#ifdef MI355_TILE_STATS
-        t_tmp = wall_clock64();
-#endif
         const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
-#ifdef MI355_TILE_STATS
-        t_cells += wall_clock64() - t_tmp; t_tmp = wall_clock64();
-#endif
         const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
-#ifdef MI355_TILE_STATS
-        t_gather += wall_clock64() - t_tmp; t_tmp = wall_clock64();
-        n_rounds++;
-#endif
         if (n_new < 0) {  // over a budget: split the segment if nothing has been ranked yet, else hand the open lanes over
           if (round == 0 && r > rmin && r > 0.5f * e_max) {
             // clustered points (far field): the density guess overshoots and the radius, not the segment's own extent,
@@ -417,31 +446,58 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
             continue;
           }
           if (round == 0 && len > 8) split = true;
-          else {
-            fb = fb || open;
-#ifdef MI355_TILE_STATS
-            { const int cnt = __popcll(__ballot(open)); TILE_STAT(round == 0 ? 10 : 11, cnt); if (!cells.ok) TILE_STAT(15, cnt); }
-#endif
-          }
+          else fb = fb || open;
           break;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
+        if (direct) {
 #pragma unroll 4
-        for (int o = n_ord; o < n_new; o++) {
-          const float4 p = cand[o];
-          const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
-          keys.insert((d & ~kOrdMask) | (uint32_t)o);
+          for (int o = n_ord; o < n_new; o++) {
+            const float4 p = cand[o];
+            const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+            keys.insert((d & ~kOrdMask) | (uint32_t)o);
+          }
+        } else {
+          // ---- sub-lists: every candidate of the tile list (old and new) that enters a sub-tile's grown box this round,
+          // i.e. lies inside (sub-box + r) but not inside (sub-box + r_old).  One step tests kSubQ candidates against all
+          // kNSub boxes: lane (s, j) tests candidate base + j against the box of ITS sub-tile s, one ballot gives every
+          // sub-tile its 8 hit bits, and the hits are appended to the sub-tile's list in candidate order.
+          for (int base = 0; base < n_new; base += kSubQ) {
+            const int o = base + sublane;
+            const float4 p = cand[min(o, kTileMaxCand - 1)];
+            // Chebyshev distance of p to the sub-box (<= 0 inside)
+            const float m = fmaxf(fmaxf(fabsf(p.x - scx) - shx, fabsf(p.y - scy) - shy), fabsf(p.z - scz) - shz);
+            const bool in = (o < n_new) && (m <= r) && !(m <= r_old);
+            const unsigned long long mask = __ballot(in);
+            const uint32_t hits = (uint32_t)(mask >> (mysub * kSubQ)) & ((1u << kSubQ) - 1u);
+            const int at = slen + __popc(hits & ((1u << sublane) - 1u));
+            if (in && at < kSubCap) sub[mysub][at] = (uint16_t)o;
+            slen += __popc(hits);  // may run past kSubCap: the sub-tile's lanes are then handed over (ovf)
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          // ---- rank: every lane walks the new part of ITS sub-tile's list
+          const int from = sdone, to = min(slen, kSubCap);
+          ovf = ovf || (slen > kSubCap);
+          sdone = to;
+          const int trip = wave_max_all_i(to - from);
+          const uint16_t* mine = sub[mysub] + from;
+#pragma unroll 4
+          for (int t = 0; t < trip; t++) {
+            const uint32_t o = (uint32_t)mine[t] & kOrdMask;  // rows are padded: reading past `to` stays inside the array
+            const float4 p = cand[o];
+            const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+            keys.insert((from + t < to) ? ((d & ~kOrdMask) | o) : SmallestKeys<K + 2>::kEmpty);
+          }
         }
         n_ord = n_new;
-#ifdef MI355_TILE_STATS
-        t_rank += wall_clock64() - t_tmp;
-#endif
-        const float rs = r * 0.9999f - eps;  // every point within rs of a query of the segment has been seen
+        const float rs = r * 0.9999f - eps;  // every point within rs of a query of the segment has been seen by its lane
         const uint32_t kk = keys.at(k - 1);
         const bool full = kk != SmallestKeys<K + 2>::kEmpty;
         const float ub = __uint_as_float(kk | kOrdMask);  // >= the exact k-th squared distance
-        open = act && !(full && ub <= rs * rs);
-        if (!__any(open)) break;
+        fb = fb || (act && ovf);
+        open = act && !ovf && !(full && ub <= rs * rs);
+        const unsigned long long om = __ballot(open);
+        if (!om) break;
         // next radius: what the open lanes ask for; lanes asking for much more wait for a later round
         const float need = open ? (full ? sqrtf(ub) * 1.001f + 2.f * eps : 2.f * r) : 0.f;
         const float near = wave_max_all((open && need <= 2.f * r) ? need : 0.f);
@@ -450,13 +506,13 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         want = fminf(fmaxf(want, 1.02f * r), rcap);
         if (!(want > r) || round >= 4) {
           fb = fb || open;
-#ifdef MI355_TILE_STATS
-          { const int cnt = __popcll(__ballot(open)); TILE_STAT(round >= 4 ? 12 : 13, cnt); }
-#endif
           break;
         }
+        // sub-tiles whose lanes are all done take no more candidates
+        if (((om >> (mysub * kSubQ)) & ((1ull << kSubQ) - 1ull)) == 0ull) shx = -INFINITY;
         ob = nb;
         has_old = true;
+        r_old = r;
         r = uniform_f(want);
       }
       if (!split) {
@@ -477,15 +533,9 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           }
         }
         const bool exact = closed && (clear || pair);
-#ifdef MI355_TILE_STATS
-        { const int cnt = __popcll(__ballot(closed && !exact)); TILE_STAT(14, cnt); }
-#endif
         fb = fb || (act && !exact);
         if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the list
-#ifdef MI355_TILE_STATS
-        n_a += n_ord;
-#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the lists
       }
     }
     if (split) {
@@ -495,24 +545,12 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
       len = seg & -seg;
     }
   }
-#ifdef MI355_TILE_STATS
-  TILE_STAT(0, 1); TILE_STAT(1, n_a); TILE_STAT(2, n_rounds); TILE_STAT(3, n_segs); TILE_STAT_MAX(4, n_a);
-  if (lane == 0) {
-    const unsigned slot = atomicAdd(&g_tile_log_n, 1u);
-    if (slot < (1u << 18)) {
-      g_tile_log[4 * slot] = t_start; g_tile_log[4 * slot + 1] = wall_clock64();
-      g_tile_log[4 * slot + 2] = (t_cells << 42) | (t_gather << 21) | t_rank; g_tile_log[4 * slot + 3] = ((unsigned long long)n_a << 32) | (unsigned)n_rounds;
-    }
-  }
-  const int n_fb_stat = __popcll(__ballot(fb));
-  TILE_STAT(8, n_fb_stat);
-#endif
   const unsigned long long fm = __ballot(fb);
   if (fm) {
     int base = 0;
     if (lane == 0) base = atomicAdd(&queue_n[c], __popcll(fm));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (fb) queue[(size_t)c * cap + base + __popcll(fm & ((1ull << lane) - 1ull))] = i;
+    if (fb) queue[(size_t)c * cap + base + __popcll(fm & below)] = i;
   }
   }  // next tile
 }
@@ -545,14 +583,7 @@ __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts,
     const float eps = tile_eps(qb, 0.f);
     float r = 2.f * g.m.cell;
     NearestK<K> nk;
-#ifdef MI355_TILE_STATS
-    const unsigned long long t_start = wall_clock64();
-    int n_rounds = 0, n_scanned = 0;
-#endif
     for (;;) {
-#ifdef MI355_TILE_STATS
-      n_rounds++;
-#endif
       // candidates: the cells of the box q +- r, or the whole cloud once the box outgrows 64 top-level cells
       const TileCells cells = tile_cells(g, grow(qb, r), 0x7fffffff);
       const bool whole = !cells.ok;
@@ -600,18 +631,8 @@ __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts,
         kth = best;
       }
       const float rs = r * 0.9999f - eps;
-#ifdef MI355_TILE_STATS
-      n_scanned += whole ? n : cells.total;
-#endif
       if (whole || kth <= rs * rs) {
         if (lane < k) o[lane] = mine;
-#ifdef MI355_TILE_STATS
-        if (lane == 0) {
-          const unsigned slot = (1u << 18) - 1 - atomicAdd(&g_tile_stats[9], 1ull);
-          g_tile_log[4 * slot] = t_start; g_tile_log[4 * slot + 1] = wall_clock64();
-          g_tile_log[4 * slot + 2] = ((unsigned long long)c << 32) | (unsigned)t; g_tile_log[4 * slot + 3] = ((unsigned long long)n_scanned << 32) | (unsigned)(n_rounds | (whole ? 256 : 0));
-        }
-#endif
         break;
       }
       r = (kth < INFINITY) ? sqrtf(kth) * 1.001f + 2.f * eps : 2.f * r;
@@ -643,11 +664,10 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
 template <int K>
 static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   const int G = div_up((long)set.cap, 256);
-  static const int need_div = getenv("MI355_KNN_NEED_DIV") ? atoi(getenv("MI355_KNN_NEED_DIV")) : 2;
-  static const bool tiles = !(getenv("MI355_KNN_TILES") && atoi(getenv("MI355_KNN_TILES")) == 0);
-  if (!tiles) {  // per-lane search for every point
+  const Tuning& tn = tuning();
+  if (!tn.knn_tiles) {  // per-lane search for every point
     hipLaunchKernelGGL(k_knn_self<K>, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p, set.cap,
-                       set.slots_cap, k, G, set.B, need_div, (const int*)nullptr, (const int*)nullptr);
+                       set.slots_cap, k, G, set.B, tn.knn_need_div, (const int*)nullptr, (const int*)nullptr);
     hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
                        set.B, (const int*)nullptr, (const int*)nullptr);
     return;
@@ -656,13 +676,15 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
   set.fbn.ensure((size_t)2 * set.B);  // [0, B) fallback queue lengths, [B, 2B) tile counters
   MI_HIP(hipMemsetAsync(set.fbn.p, 0, sizeof(int) * 2 * set.B, s));
   // about two resident waves per SIMD over the whole batch, at least 8 and at most one wave per tile of a cloud
-  static const int gt_total = getenv("MI355_TILE_WAVES") ? atoi(getenv("MI355_TILE_WAVES")) : 8192;
-  static const float r_scale = getenv("MI355_TILE_RSCALE") ? (float)atof(getenv("MI355_TILE_RSCALE")) : 0.8f;
-  const int Gt = max(min(gt_total / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
-  hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                     set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, r_scale);
+  const int Gt = max(min(tn.tile_waves / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
+  {
+    TimedLaunch tl(KF_KNN_COV_TILE, s);
+    hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
+                       set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
+  }
   // the points the tile kernel handed over: one wave per point, then their covariances from the lists
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
+  TimedLaunch tl(KF_KNN_HARD, s);
   hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p,
                      (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, Gh, set.B);
   hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
@@ -795,7 +817,8 @@ __global__ void k_voxel_meta(const uint32_t* __restrict__ bounds, const int* __r
   m.cell = leaf;
   m.hshift = 0; m.hmask = 0;
   m.top_level = 0;
-  m.pad[0] = m.pad[1] = m.pad[2] = 0;
+  m.n_cells = 0;
+  m.pad[0] = m.pad[1] = 0;
   vmeta[c] = m;
 }
 
@@ -832,60 +855,47 @@ __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict_
   flags[o + i] = f;
 }
 
-constexpr int kCentroidBlock = 1024;
-__global__ __launch_bounds__(kCentroidBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
-                                                                    const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
-                                                                    const int* __restrict__ flags, const int* __restrict__ local,
-                                                                    const int* __restrict__ blockoff, const int* __restrict__ totals,
-                                                                    float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G,
-                                                                    int B) {
-  // Every thread gathers ITS point (fully parallel) into LDS; the head thread of a voxel then adds its run in ascending
-  // index order — the oracle's order, so the fp32 sums are bit-equal — reading from LDS.  Only the part of a run that
-  // continues past the end of this block's 1 024 points is read from memory (eight gathers in flight).
-  __shared__ float4 spt[kCentroidBlock];
-  __shared__ uint32_t skey[kCentroidBlock];
+// One thread per sorted point; the thread at the head of a voxel's run adds the run in ascending point-index order (the
+// stable sort's order — the same as the oracle's, so the fp32 sums are bit-equal), gathering the points straight from
+// memory, four in flight per step.  No barrier and no LDS staging: the first version staged 1 024-point tiles through LDS
+// behind a block barrier and took 5.7 ms per 1 024-cloud launch for 2.2 GB of traffic; a run is ~4 points on average (up
+// to ~100 in the voxels next to the sensor), and a lane that is not a head simply retires.
+__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
+                                                         const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
+                                                         const int* __restrict__ flags, const int* __restrict__ local,
+                                                         const int* __restrict__ blockoff, const int* __restrict__ totals,
+                                                         float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G, int B) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = vmeta[c];
-  const int i = bx * kCentroidBlock + threadIdx.x;
+  const int i = bx * blockDim.x + threadIdx.x;
   if (i == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
-  if (bx * kCentroidBlock >= m.n) return;  // whole block past the end (uniform)
+  if (i >= m.n) return;
   const size_t o = (size_t)c * cap;
   if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input
-    if (i < m.n) out[o + i] = in[o + i];
+    out[o + i] = in[o + i];
     return;
   }
-  const bool valid = i < m.n;
-  uint32_t k = kEmptyKey;
-  if (valid) {
-    k = keys[o + i];
-    spt[threadIdx.x] = in[o + vals[o + i]];
-  }
-  skey[threadIdx.x] = valid ? k : kEmptyKey;
-  __syncthreads();
-  if (!valid || !flags[o + i]) return;
-  float4 a = spt[threadIdx.x];
+  if (!flags[o + i]) return;
+  const uint32_t k = keys[o + i];
+  float4 a = in[o + vals[o + i]];
   int cnt = 1;
-  int t = threadIdx.x + 1;
-  for (; t < kCentroidBlock && skey[t] == k; t++) {
-    const float4 p = spt[t];
-    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-    cnt++;
-  }
-  if (t == kCentroidBlock) {  // the run may continue in the next block's points
-    int j = i + cnt;
-    while (j < m.n && keys[o + j] == k) {
-      int len = 1;
-      while (len < 8 && j + len < m.n && keys[o + j + len] == k) len++;
-      float4 p[8];
+  for (int j = i + 1; j < m.n; j += 4) {
+    uint32_t kk[4];
+    float4 p[4];
 #pragma unroll
-      for (int u = 0; u < 8; u++) p[u] = in[o + vals[o + min(j + u, j + len - 1)]];
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (u < len) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; }
-      cnt += len;
-      j += len;
+    for (int u = 0; u < 4; u++) {
+      const int jj = min(j + u, m.n - 1);
+      kk[u] = (j + u < m.n) ? keys[o + jj] : ~k;
+      p[u] = in[o + vals[o + jj]];
     }
+    bool more = true;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      more = more && (kk[u] == k);
+      if (more) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; cnt++; }
+    }
+    if (!more) break;
   }
   const float fc = (float)cnt;
   out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc);
@@ -900,8 +910,9 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   sort_pairs(s, ws, B, cap, cnt_in, 4);
   hipLaunchKernelGGL(k_voxel_heads, grid, dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap);
   scan_flags(s, ws, B, cap, cnt_in);
-  const int Gv = div_up((long)cap, kCentroidBlock);
-  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kCentroidBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
+  const int Gv = div_up((long)cap, 256);
+  TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
+  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
                      ws.scan_block.p, ws.totals.p, out, cnt_out, cap, div_up((long)cap, kScanTile), Gv, B);
   MI_LAUNCH_CHECK();
 }

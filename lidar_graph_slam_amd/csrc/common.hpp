@@ -72,6 +72,80 @@ struct PinnedBuf {
 
 inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- tuning knobs ------------------------------------------------------------------------------------------------
+// Launch-geometry knobs, read ONCE per process from MI355_* environment variables (api.hip).  Results never depend on them.
+struct Tuning {
+  int blocks_per_pair = 64;   // MI355_BLOCKS_PER_PAIR   k_gicp_correspond blocks per pair
+  int corr_ppt = 1;           // MI355_PPT               points per thread and pass in k_gicp_correspond (1 or 4)
+  int blocks_lin = 0;         // MI355_BLOCKS_LIN        blocks per pair of the streaming kernels (0 = from the batch size)
+  int lin_ppt = 1;            // MI355_LIN_PPT           points per thread and tile in k_gicp_linearize (1, 2, 4)
+  int knn_tiles = 1;          // MI355_KNN_TILES         0 = per-lane k-NN search for every point (k_knn_self)
+  int knn_need_div = 2;       // MI355_KNN_NEED_DIV      start level heuristic of the per-lane search
+  int tile_waves = 8192;      // MI355_TILE_WAVES        resident one-wave blocks of k_knn_cov_tile over the batch
+  float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
+  int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream
+  float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
+};
+const Tuning& tuning();
+
+// ---- per-kernel-family timing (bench.py's roofline block) ----------------------------------------------------------
+// HIP events recorded on the LAUNCHING stream around the launches of a family, only while a batch has timing enabled
+// (mi355_batch_set_timing).  The durations are read after the streams have been synchronised (mi355_batch_kernel_times).
+enum KernelFamily : int {
+  KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_LINEARIZE, KF_ERROR, KF_SOLVE_DECIDE,
+  KF_FITNESS, KF_COUNT
+};
+extern const char* const kKernelFamilyName[KF_COUNT];
+struct KernelTimers {
+  struct Rec { int fam; hipEvent_t e0, e1; };
+  bool enabled = false;
+  std::vector<Rec> recs;
+  size_t used = 0;
+  double ms[KF_COUNT] = {0};
+  int brackets[KF_COUNT] = {0};
+  ~KernelTimers() {
+    for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  }
+  Rec* open(int fam, hipStream_t s) {
+    if (used == recs.size()) {
+      Rec r{fam, nullptr, nullptr};
+      if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return nullptr;
+      recs.push_back(r);
+    }
+    Rec* r = &recs[used++];
+    r->fam = fam;
+    (void)hipEventRecord(r->e0, s);
+    return r;
+  }
+  // every recorded event must have completed (callers synchronise the streams first)
+  void collect() {
+    for (size_t i = 0; i < used; i++) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, recs[i].e0, recs[i].e1) == hipSuccess) { ms[recs[i].fam] += t; brackets[recs[i].fam]++; }
+    }
+    used = 0;
+  }
+  void reset() {
+    for (int f = 0; f < KF_COUNT; f++) { ms[f] = 0; brackets[f] = 0; }
+  }
+};
+extern thread_local KernelTimers* g_timers;  // set by the batch entry points while they enqueue work (api.hip)
+struct TimedLaunch {  // RAII bracket around the launches of one family on stream s
+  KernelTimers::Rec* r = nullptr;
+  hipStream_t s;
+  TimedLaunch(int fam, hipStream_t s_) : s(s_) {
+    if (g_timers && g_timers->enabled) r = g_timers->open(fam, s);
+  }
+  ~TimedLaunch() {
+    if (r) (void)hipEventRecord(r->e1, s);
+  }
+};
+struct TimerScope {
+  KernelTimers* prev;
+  explicit TimerScope(KernelTimers* t) : prev(g_timers) { g_timers = t; }
+  ~TimerScope() { g_timers = prev; }
+};
+
 }  // namespace mi355
 
 struct mi355_ctx {

@@ -117,6 +117,80 @@ MI_HD void sort3_desc(const double w[3], int o[3]) {
 
 enum RegularizationMethod { REG_NONE = 0, REG_MIN_EIG = 1, REG_NORMALIZED_MIN_EIG = 2, REG_PLANE = 3, REG_FROBENIUS = 4 };
 
+// Unit eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite 3x3, in fp64, without the sweeps of
+// the Jacobi iteration (which cost the covariance kernel more than the neighbour search itself: 5-6 sweeps x 3 rotations
+// x 2 sqrt + 2 div in fp64, and a data-dependent trip count under SIMT).  PLANE regularisation needs nothing else:
+// U diag(1, 1, 1e-3) U^T = I - (1 - 1e-3) n n^T.
+//   1. the eigenvalue that is best separated from the other two (the smallest for a plane-like neighbourhood, the largest
+//      for a line-like one; the sign of det(A - tr/3 I) tells which) is a simple, well-conditioned root of the
+//      characteristic polynomial: Newton from outside the spectrum (0 or the trace) converges to it monotonically;
+//   2. its eigenvector is the largest cross product of two rows of A - lambda I (error ~ eps / gap, like Jacobi's);
+//   3. the other two eigenpairs live in the orthogonal complement: ONE exact Jacobi rotation of the projected 2x2.
+// Returns false when the input is (numerically) degenerate — isotropic, rank <= 1, or the two smallest eigenvalues closer
+// than 1e-9 of the trace — so that the caller takes the Jacobi path and degenerate inputs resolve exactly as before.
+MI_HD bool smallest_eigenvector_sym3(const Sym3<double>& cv, double n[3]) {
+  const double tr = cv.xx + cv.yy + cv.zz;
+  if (!(tr > 0.0) || !(tr < 1.0e300)) return false;
+  const double sc = 1.0 / tr;
+  const double axx = cv.xx * sc, axy = cv.xy * sc, axz = cv.xz * sc, ayy = cv.yy * sc, ayz = cv.yz * sc, azz = cv.zz * sc;
+  // characteristic polynomial of the trace-1 matrix:  p(l) = l^3 - l^2 + m l - d
+  const double m = (axx * ayy - axy * axy) + (axx * azz - axz * axz) + (ayy * azz - ayz * ayz);
+  const double d = axx * (ayy * azz - ayz * ayz) - axy * (axy * azz - ayz * axz) + axz * (axy * ayz - ayy * axz);
+  // det(A - I/3) = -p(1/3): negative -> two eigenvalues above the mean, one below: the smallest is the separated one
+  const double third = 1.0 / 3.0;
+  const double pm = ((third - 1.0) * third + m) * third - d;
+  const bool small_sep = pm > 0.0;
+  double l = small_sep ? 0.0 : 1.0;
+  for (int it = 0; it < 24; it++) {
+    const double p = ((l - 1.0) * l + m) * l - d;
+    const double dp = (3.0 * l - 2.0) * l + m;
+    if (dp == 0.0) break;
+    const double step = p / dp;
+    l -= step;
+    if (fabs(step) <= 2.0e-17) break;
+  }
+  // eigenvector of l: rows of B = A - l I are orthogonal to it
+  const double bxx = axx - l, byy = ayy - l, bzz = azz - l;
+  const double c0x = axy * ayz - axz * byy, c0y = axz * axy - bxx * ayz, c0z = bxx * byy - axy * axy;  // r0 x r1
+  const double c1x = axy * bzz - axz * ayz, c1y = axz * axz - bxx * bzz, c1z = bxx * ayz - axy * axz;  // r0 x r2
+  const double c2x = byy * bzz - ayz * ayz, c2y = ayz * axz - axy * bzz, c2z = axy * ayz - byy * axz;  // r1 x r2
+  const double n0 = c0x * c0x + c0y * c0y + c0z * c0z, n1 = c1x * c1x + c1y * c1y + c1z * c1z, n2 = c2x * c2x + c2y * c2y + c2z * c2z;
+  double vx = c0x, vy = c0y, vz = c0z, nn = n0;
+  if (n1 > nn) { vx = c1x; vy = c1y; vz = c1z; nn = n1; }
+  if (n2 > nn) { vx = c2x; vy = c2y; vz = c2z; nn = n2; }
+  // |cross| ~ (gap to the 2nd) * (gap to the 3rd) of the trace-1 matrix: below 1e-8 the root was not a separated one
+  if (!(nn > 1.0e-16)) return false;
+  const double inv = 1.0 / sqrt(nn);
+  vx *= inv; vy *= inv; vz *= inv;
+  if (small_sep) { n[0] = vx; n[1] = vy; n[2] = vz; return true; }
+  // orthonormal basis (u, w) of the complement of v: u = v x e_i for the axis where |v_i| is smallest
+  const double ax = fabs(vx), ay = fabs(vy), az = fabs(vz);
+  double ux, uy, uz;
+  if (ax <= ay && ax <= az) { ux = 0.0; uy = vz; uz = -vy; }
+  else if (ay <= az) { ux = -vz; uy = 0.0; uz = vx; }
+  else { ux = vy; uy = -vx; uz = 0.0; }
+  const double iu = 1.0 / sqrt(ux * ux + uy * uy + uz * uz);
+  ux *= iu; uy *= iu; uz *= iu;
+  const double wx = vy * uz - vz * uy, wy = vz * ux - vx * uz, wz = vx * uy - vy * ux;
+  // projected 2x2: [uAu uAw; uAw wAw]
+  const double Aux = axx * ux + axy * uy + axz * uz, Auy = axy * ux + ayy * uy + ayz * uz, Auz = axz * ux + ayz * uy + azz * uz;
+  const double Awx = axx * wx + axy * wy + axz * wz, Awy = axy * wx + ayy * wy + ayz * wz, Awz = axz * wx + ayz * wy + azz * wz;
+  const double app = ux * Aux + uy * Auy + uz * Auz, aqq = wx * Awx + wy * Awy + wz * Awz, apq = ux * Awx + uy * Awy + uz * Awz;
+  // one Jacobi rotation diagonalises it: eigenvalues app - t apq (vector c u - s w) and aqq + t apq (vector s u + c w)
+  double c = 1.0, s = 0.0, t = 0.0;
+  if (apq != 0.0) {
+    const double tau = (aqq - app) / (2.0 * apq);
+    t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    c = 1.0 / sqrt(1.0 + t * t);
+    s = t * c;
+  }
+  const double e1 = app - t * apq, e2 = aqq + t * apq;
+  if (!(fabs(e1 - e2) > 1.0e-9)) return false;  // the two smallest eigenvalues (nearly) coincide: no defined normal
+  if (e1 < e2) { n[0] = c * ux - s * wx; n[1] = c * uy - s * wy; n[2] = c * uz - s * wz; }
+  else { n[0] = s * ux + c * wx; n[1] = s * uy + c * wy; n[2] = s * uz + c * wz; }
+  return true;
+}
+
 // fast_gicp covariance regularisation (row F2).  Input: raw neighbourhood covariance (divided by k).
 MI_HD Sym3<double> regularize_covariance(const Sym3<double>& cov, int method) {
   if (method == REG_NONE) return cov;
@@ -129,6 +203,13 @@ MI_HD Sym3<double> regularize_covariance(const Sym3<double>& cov, int method) {
     const double s = 1.0 / fro;
     const Sym3<double> Cn = {Ci.xx * s, Ci.xy * s, Ci.xz * s, Ci.yy * s, Ci.yz * s, Ci.zz * s};
     return sym3_inverse(Cn);
+  }
+  if (method == REG_PLANE) {
+    double n[3];
+    if (smallest_eigenvector_sym3(cov, n)) {
+      const double f = 1.0 - 1e-3;
+      return {1.0 - f * n[0] * n[0], -f * n[0] * n[1], -f * n[0] * n[2], 1.0 - f * n[1] * n[1], -f * n[1] * n[2], 1.0 - f * n[2] * n[2]};
+    }
   }
   double w[3], V[9];
   jacobi_eigen_sym3(cov, w, V);

@@ -34,7 +34,8 @@ struct GridMeta {
   int n;              // points in this cloud
   int overflow;       // VoxelGrid index overflow flag (pass-through)
   int top_level;      // coarsest level of the multi-level voxel hash (cell edge = cell * 2^level)
-  int pad[3];
+  int n_cells;        // occupied cells over all levels = entries of the hash
+  int pad[2];
 };
 constexpr int kMaxLevel = 4;
 
@@ -115,18 +116,7 @@ struct GicpBatch {
   DevBuf<float> guesses, fit_T;        // device staging that must outlive the enqueued kernels
   std::vector<int> h_map;
   std::vector<float> h_guess, h_fit_T;
-  // dominant-kernel timing (HIP events on the context stream)
-  std::vector<hipEvent_t> ev;
-  int ev_used = 0;
-  bool time_kernels = false;
-  int debug_flags = 0;      // MI355_DEBUG_FLAGS: timing ablations (never set in production)
-  int blocks_override = 0;  // MI355_BLOCKS_PER_PAIR
-  int ppt = 1;              // points per thread and pass in correspond/linearize (MI355_PPT)
-  DevBuf<unsigned long long> stats;
-  int iter_counter = 0;
-  double last_linearize_ms = 0;
-  int last_linearize_launches = 0;
-  ~GicpBatch();
+  int ppt = 1;              // points per thread and pass in k_gicp_correspond (Tuning::corr_ppt)
 };
 void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units);
 // Enqueue the full LM optimisation of every pair.  guesses_host: S x 16 floats or nullptr.
@@ -138,7 +128,6 @@ void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
 // single linearisation at a given pose (parity tests), pair 0 only
 void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T16,
                          double* H36, double* b6, double* err, int* corr_caller_order);
-void gicp_finish_timing(GicpBatch& gb);
 
 // ---- ndt.hip -------------------------------------------------------------------------------------------------
 struct NdtTarget;

@@ -23,7 +23,7 @@ struct GicpPairState {
   double y0, yi, lambda, nu;
   double final_H[36];
   double last_error;
-  int iter, trial, active, converged, n_inliers, lm_failed, need_error, pad;
+  int iter, trial, active, converged, n_inliers, lm_failed, need_error, status;
   double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
 };
 
@@ -49,33 +49,26 @@ constexpr int kTrialSlot = 32;
 constexpr int kGicpBlock = 256;
 constexpr int kMaxTrials = 16;  // lm_max_iterations is capped here (fast_gicp default 10)
 
-GicpBatch::~GicpBatch() {
-  for (auto e : ev) (void)hipEventDestroy(e);
-}
-
 void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
-  if (const char* e = getenv("MI355_DEBUG_FLAGS")) gb.debug_flags = atoi(e);
-  if (const char* e = getenv("MI355_BLOCKS_PER_PAIR")) gb.blocks_override = atoi(e);
-  if (const char* e = getenv("MI355_PPT")) gb.ppt = atoi(e) == 1 ? 1 : 4;
+  const Tuning& tn = tuning();
+  gb.ppt = tn.corr_ppt == 1 ? 1 : 4;
   gb.S = S;
   gb.cap = cap;
   // One pair is worked on by (up to) 64 blocks of 256 threads that all land on one XCD (primitives.hpp): enough waves to
   // fill that XCD's 32 CUs while only ~2 pairs' working sets compete for its 4 MB L2.
   (void)compute_units;
-  int G = 64;
-  if (gb.blocks_override > 0) G = gb.blocks_override;
+  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : 64;
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
   // few, long-lived blocks: each block streams several tiles (software-pipelined) and pays ONE 29-value fp64 reduction;
   // about 512 blocks over the batch, at least 4 per pair, never more than the tiles a cloud can have
   gb.blocks_lin = std::max(1, std::min(std::max(4, std::min(32, 512 / std::max(S, 1))), div_up((long)cap, kGicpBlock * 2)));
-  if (const char* e = getenv("MI355_BLOCKS_LIN")) gb.blocks_lin = std::max(1, atoi(e));
+  if (tn.blocks_lin > 0) gb.blocks_lin = tn.blocks_lin;
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
   gb.mahal.ensure((size_t)S * cap);
   gb.qsearch.ensure((size_t)S * cap);
-  gb.stats.ensure(64);
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
   gb.trials.ensure((size_t)S * kMaxTrials * sizeof(LmTrial));
@@ -85,7 +78,10 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.fitness.ensure((size_t)S * 2);
 }
 
-__global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses, int S, int has_guess) {
+// scount / tcount (optional): a pair whose clouds hold fewer than k_min points after the prefilter is not registered —
+// its covariances would be built from missing neighbours — and reports MI355_PAIR_TOO_FEW_POINTS instead.
+__global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses, int S, int has_guess, const int* __restrict__ scount,
+                            const int* __restrict__ tcount, const int* __restrict__ tgt_of_src, int k_min) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= S) return;
   GicpPairState s;
@@ -98,7 +94,8 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   s.lambda = -1.0;
   s.nu = 2.0;
   s.last_error = 0;
-  s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.pad = 0;
+  s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.status = MI355_PAIR_OK;
+  if (scount && (scount[p] < k_min || tcount[tgt_of_src[p]] < k_min)) { s.active = 0; s.status = MI355_PAIR_TOO_FEW_POINTS; }
   s.last_step = 1.0e9;
   st[p] = s;
 }
@@ -128,15 +125,15 @@ __device__ __forceinline__ void residual(const Pose& x, const float4& p, const f
 
 // Full (re-)search of one source point: exact nearest neighbour in the target + how far the query may move before the
 // answer can change.  Seeded with the previous correspondent when there is one.
-__device__ __forceinline__ void search_point(const GridView& g, float qx, float qy, float qz, int jprev, float max_corr_d2, int debug_flags,
-                                             bool track_margin, int& j_out, float& margin_out) {
+__device__ __forceinline__ void search_point(const GridView& g, float qx, float qy, float qz, int jprev, float max_corr_d2, bool track_margin,
+                                             int& j_out, float& margin_out) {
   const float max_corr = sqrtf(max_corr_d2);
   if (!track_margin) {
     // The pose is still moving by more than any margin could absorb: plain exact 1-NN (prunes with the best distance, not
     // the runner-up), seeded with the previous correspondent and started at the level whose cell is about that far.
     Nearest1 nn{g.orig, INFINITY, -1};
     int level0 = 0;
-    if (jprev >= 0 && jprev < g.m.n && !(debug_flags & 2)) {
+    if (jprev >= 0 && jprev < g.m.n) {
       const float4 pp = g.pts[jprev];
       nn.best_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
       nn.best_j = jprev;
@@ -150,7 +147,7 @@ __device__ __forceinline__ void search_point(const GridView& g, float qx, float 
   }
   Nearest2 nn{g.orig, INFINITY, -1, INFINITY, INFINITY};
   float explored2;
-  if (jprev >= 0 && jprev < g.m.n && !(debug_flags & 2)) {
+  if (jprev >= 0 && jprev < g.m.n) {
     const float4 pp = g.pts[jprev];
     nn.d1 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
     nn.j1 = jprev;
@@ -195,8 +192,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
                                                                 const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
-                                                               float4* __restrict__ qsearch, float max_corr_d2, int debug_flags,
-                                                                unsigned long long* __restrict__ stats, int iter, int G, int S) {
+                                                                float4* __restrict__ qsearch, float max_corr_d2, int G, int S) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ int queue[kLinTile];
   __shared__ int qcount;
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
   const int n = scount[pair];
   const Pose x0 = st->x0;
   // margins only pay once the updates are small enough to stay inside them (cm); before that use the cheap 1-NN search
-  const bool track_margin = (st->last_step < 0.03) || (debug_flags & 128);
+  const bool track_margin = st->last_step < 0.03;
   float Tf[12];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -237,7 +233,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
       const float moved = sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z));
       // NaN margin (never searched) -> search.  The margin also covers "still within max_corr" (search_point), so a point
       // that passes this test needs neither its correspondence index nor its correspondent: 32 B per point in steady state.
-      const bool need_search = !(moved < qs.w) || (debug_flags & 4);
+      const bool need_search = !(moved < qs.w);
       if (!finite_q) {
         corr[so + i] = -1;
       } else if (need_search) {
@@ -247,14 +243,13 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
     __syncthreads();
     // ---- phase 2: dense search of the queued points
     const int nq = qcount;
-    if ((debug_flags & 64) && threadIdx.x == 0) atomicAdd(&stats[iter], (unsigned long long)nq);
     for (int tq = threadIdx.x; tq < nq; tq += kGicpBlock) {
       const int i = queue[tq];
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
       int j;
       float margin;
-      search_point(g, qx, qy, qz, corr[so + i], max_corr_d2, debug_flags, track_margin, j, margin);
+      search_point(g, qx, qy, qz, corr[so + i], max_corr_d2, track_margin, j, margin);
       corr[so + i] = j;
       qsearch[so + i] = make_float4(qx, qy, qz, margin);
     }
@@ -270,8 +265,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
                                                                const Cov6* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int debug_flags, int G,
-                                                               int S) {
+                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ double smem[4 * kNAcc];
   int pair, bx;
@@ -330,7 +324,6 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
       const int i = base + u * kGicpBlock + threadIdx.x;
       const int j = cur[u].j;
       if (j < 0) continue;  // past the end, or no correspondence
-      if (debug_flags & 8) { acc[28] += 1.0; continue; }
       const float4 p = cur[u].p;
       const Sym3<float> CA = cov6_unpack(cur[u].c);
       const Sym3<float> CB = cov6_unpack(tcv[u]);
@@ -638,38 +631,17 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
 
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P) {
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
-  static const int lin_ppt = getenv("MI355_LIN_PPT") ? atoi(getenv("MI355_LIN_PPT")) : 1;
+  const int lin_ppt = tuning().lin_ppt;
   auto kl = lin_ppt == 1 ? k_gicp_linearize<1> : (lin_ppt == 2 ? k_gicp_linearize<2> : k_gicp_linearize<4>);
-  hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
-                     tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                     gb.debug_flags, gb.stats.p, gb.iter_counter++ % 64, gb.blocks_per_pair, gb.S);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (gb.time_kernels) {
-    while ((int)gb.ev.size() < gb.ev_used + 2) {
-      hipEvent_t e;
-      MI_HIP(hipEventCreate(&e));
-      gb.ev.push_back(e);
-    }
-    e0 = gb.ev[gb.ev_used];
-    e1 = gb.ev[gb.ev_used + 1];
-    gb.ev_used += 2;
-    MI_HIP(hipEventRecord(e0, s));
+  {
+    TimedLaunch tl(KF_CORRESPOND, s);
+    hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
+                       tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
+                       gb.blocks_per_pair, gb.S);
   }
+  TimedLaunch tl(KF_LINEARIZE, s);
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
-                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.debug_flags,
-                     gb.blocks_lin, gb.S);
-  if (gb.time_kernels) MI_HIP(hipEventRecord(e1, s));
-}
-
-void gicp_finish_timing(GicpBatch& gb) {
-  double ms = 0;
-  for (int i = 0; i + 1 < gb.ev_used; i += 2) {
-    float t = 0;
-    if (hipEventElapsedTime(&t, gb.ev[i], gb.ev[i + 1]) == hipSuccess) ms += t;
-  }
-  gb.last_linearize_ms = ms;
-  gb.last_linearize_launches = gb.ev_used / 2;
-  gb.ev_used = 0;
+                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.blocks_lin, gb.S);
 }
 
 void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
@@ -687,22 +659,27 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     gb.guesses.ensure((size_t)S * 16);
     MI_HIP(hipMemcpyAsync(gb.guesses.p, gb.h_guess.data(), (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   }
-  hipLaunchKernelGGL(k_gicp_init, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, (const float*)gb.guesses.p, S, guesses_host ? 1 : 0);
+  hipLaunchKernelGGL(k_gicp_init, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, (const float*)gb.guesses.p, S, guesses_host ? 1 : 0,
+                     (const int*)src.count.p, (const int*)tgt.count.p, (const int*)gb.tgt_of_src.p, std::max(p.k_correspondences, 1));
   MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, (size_t)S * gb.cap * sizeof(int), s));        // no previous correspondences yet
   MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, (size_t)S * gb.cap * sizeof(float4), s));  // NaN margins: first pass searches
   const GicpDevParams P = dev_params(p);
   const int G = gb.blocks_lin;
-  gb.iter_counter = 0;
-  MI_HIP(hipMemsetAsync(gb.stats.p, 0, 64 * sizeof(unsigned long long), s));
-  gb.ev_used = 0;
   const int check_every = p.force_iterations ? 0 : 4;
   for (int it = 0; it < p.max_iterations; it++) {
     launch_linearize(s, gb, src, tgt, P);
-    hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P);
+    {
+      TimedLaunch tl(KF_SOLVE_DECIDE, s);
+      hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P);
+    }
     if (p.optimizer == MI355_OPT_LM) {
       auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
-      hipLaunchKernelGGL(ke, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                         gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, P.lm_max_iterations);
+      {
+        TimedLaunch tl(KF_ERROR, s);
+        hipLaunchKernelGGL(ke, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
+                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, P.lm_max_iterations);
+      }
+      TimedLaunch tl(KF_SOLVE_DECIDE, s);
       hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P);
     }
     if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
@@ -772,6 +749,7 @@ void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
     dTp = gb.fit_T.p;
   }
   const float search_d2 = (max_range >= 3.0e38) ? INFINITY : (float)(max_range * (1.0 + 1e-6)) + 1e-30f;
+  TimedLaunch tl(KF_FITNESS, s);
   hipLaunchKernelGGL(k_fitness, dim3(gb.blocks_lin, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                      tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, dTp, gb.fit_partials.p, search_d2, max_range);
   hipLaunchKernelGGL(k_fitness_final, dim3(div_up(gb.S, 64)), dim3(64), 0, s, gb.fit_partials.p, gb.fitness.p, gb.S, gb.blocks_lin);
@@ -792,14 +770,6 @@ void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
     MI_HIP(hipMemcpyAsync(fit.data(), gb.fitness.p, fit.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   MI_HIP(hipStreamSynchronize(s));
-  if (gb.debug_flags & 64) {
-    unsigned long long st64[64];
-    MI_HIP(hipMemcpy(st64, gb.stats.p, sizeof(st64), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[mi355] searched points per iteration:");
-    for (int i = 0; i < 24; i++) fprintf(stderr, " %llu", st64[i]);
-    fprintf(stderr, "\n");
-  }
-  if (gb.time_kernels) gicp_finish_timing(gb);
   for (int p = 0; p < S; p++) {
     mi355_result& r = out[p];
     memset(&r, 0, sizeof(r));
@@ -811,6 +781,7 @@ void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
     r.n_source = ns[p];
     r.n_target = nt[map[p]];
     r.n_inliers = st[p].n_inliers;
+    r.status = st[p].status;
     if (fitness_out) fitness_out[p] = fit[2 * p + 1] > 0 ? fit[2 * p] / fit[2 * p + 1] : 1.7976931348623157e308;
   }
 }
@@ -828,7 +799,8 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   const int zero = 0;
   MI_HIP(hipMemcpyAsync(gb.tgt_of_src.p, &zero, sizeof(int), hipMemcpyHostToDevice, s));
   MI_HIP(hipStreamSynchronize(s));
-  hipLaunchKernelGGL(k_gicp_init, dim3(1), dim3(64), 0, s, gb.state.p, (const float*)nullptr, 1, 0);
+  hipLaunchKernelGGL(k_gicp_init, dim3(1), dim3(64), 0, s, gb.state.p, (const float*)nullptr, 1, 0, (const int*)nullptr, (const int*)nullptr,
+                     (const int*)nullptr, 0);
   Pose x;
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) x.R[3 * r + c] = T16[4 * r + c];
@@ -839,10 +811,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
   GicpDevParams P = dev_params(p);
   P.optimizer = MI355_OPT_LM;
-  const bool tk = gb.time_kernels;
-  gb.time_kernels = false;
   launch_linearize(s, gb, src, tgt, P);
-  gb.time_kernels = tk;
   hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P);
   MI_LAUNCH_CHECK();
   GicpPairState st;

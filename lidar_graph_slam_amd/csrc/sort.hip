@@ -125,6 +125,7 @@ void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_co
   const dim3 grid(div_up((long)cap, kBlockTile), B);
   uint32_t* ka = ws.keys_a.p; uint32_t* kb = ws.keys_b.p;
   int* va = ws.vals_a.p; int* vb = ws.vals_b.p;
+  TimedLaunch tl(KF_SORT, s);
   for (int p = 0; p < passes; p++) {
     const int shift = 8 * p;
     hipLaunchKernelGGL(k_sort_hist, grid, dim3(kSortBlock), 0, s, ka, d_counts, ws.hist.p, cap, nsub, shift);

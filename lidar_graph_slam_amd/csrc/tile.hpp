@@ -46,6 +46,11 @@ __device__ __forceinline__ int wave_sum_all_i(int v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
   return __builtin_amdgcn_readfirstlane(v);
 }
+__device__ __forceinline__ int wave_max_all_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
+  return __builtin_amdgcn_readfirstlane(v);
+}
 __device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 

@@ -240,11 +240,16 @@ class BatchRegistration:
         out = [r.to_dict() for r in res]
         return (out, fit) if with_fitness else out
 
-    def kernel_time(self):
-        ms = C.c_double(0)
+    def set_timing(self, enable: bool = True):
+        """Record HIP events around the hot kernels of this batch (bench.py's roofline block)."""
+        self.ctx.check(self.ctx._lib.mi355_batch_set_timing(self.handle, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{kernel family: (total ms, launches)} since the last call; synchronises the batch."""
+        buf = (L.KernelTime * 16)()
         n = C.c_int(0)
-        self.ctx.check(self.ctx._lib.mi355_batch_kernel_time(self.handle, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        self.ctx.check(self.ctx._lib.mi355_batch_kernel_times(self.handle, buf, 16, C.byref(n)))
+        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(min(n.value, 16))}
 
     def close(self):
         if getattr(self, "handle", None):

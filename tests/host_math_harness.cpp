@@ -21,6 +21,27 @@ void hm_regularize(const double* cov6, int method, double* out6) {
   const Sym3<double> r = regularize_covariance(c, method);
   out6[0] = r.xx; out6[1] = r.xy; out6[2] = r.xz; out6[3] = r.yy; out6[4] = r.yz; out6[5] = r.zz;
 }
+// the smallest-eigenvector shortcut of the PLANE regularisation: returns 1 and n[3], or 0 when it defers to the Jacobi path
+int hm_smallest_eigvec(const double* cov6, double* n3) {
+  const Sym3<double> c = {cov6[0], cov6[1], cov6[2], cov6[3], cov6[4], cov6[5]};
+  return smallest_eigenvector_sym3(c, n3) ? 1 : 0;
+}
+// PLANE regularisation through the Jacobi eigen-decomposition only (what the shortcut must reproduce)
+void hm_plane_jacobi(const double* cov6, double* out6) {
+  const Sym3<double> c = {cov6[0], cov6[1], cov6[2], cov6[3], cov6[4], cov6[5]};
+  double w[3], V[9];
+  jacobi_eigen_sym3(c, w, V);
+  int o[3];
+  sort3_desc(w, o);
+  const double values[3] = {1.0, 1.0, 1e-3};
+  double out[6] = {0, 0, 0, 0, 0, 0};
+  for (int d = 0; d < 3; d++) {
+    const double ux = V[0 + o[d]], uy = V[3 + o[d]], uz = V[6 + o[d]], v = values[d];
+    out[0] += ux * v * ux; out[1] += ux * v * uy; out[2] += ux * v * uz;
+    out[3] += uy * v * uy; out[4] += uy * v * uz; out[5] += uz * v * uz;
+  }
+  for (int i = 0; i < 6; i++) out6[i] = out[i];
+}
 void hm_sym3_inverse_f(const float* a6, float* out6) {
   const Sym3<float> a = {a6[0], a6[1], a6[2], a6[3], a6[4], a6[5]};
   const Sym3<float> r = sym3_inverse(a);

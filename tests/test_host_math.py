@@ -82,6 +82,53 @@ def test_regularisation_vs_numpy(hm, method, name):
         np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-11)
 
 
+def _cov6(c):
+    return np.array([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
+
+
+def test_plane_shortcut_matches_jacobi(hm):
+    """PLANE = I - 0.999 n n^T with n from smallest_eigenvector_sym3 (Newton on the separated root + cross products + one
+    2x2 rotation) against the full Jacobi path, over the neighbourhood shapes a LiDAR cloud has: planes, lines (one ring),
+    blobs, tiny and huge scales, rank-deficient inputs.  Degenerate inputs must defer (return 0) so they resolve as before."""
+    rng = np.random.default_rng(7)
+    n_fast = 0
+    worst = 0.0
+    shapes = [(1.0, 1.0, 0.01), (1.0, 0.02, 0.01), (1.0, 0.5, 0.2), (1.0, 1.0, 1e-4), (1.0, 1e-3, 5e-4), (1.0, 0.3, 0.29), (1.0, 0.99, 0.5),
+              (1.0, 0.05, 0.049)]
+    for sx, sy, sz in shapes:
+        for scale in (1e-3, 1.0, 50.0):
+            for _ in range(40):
+                Q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+                P = (rng.normal(size=(20, 3)) * np.array([sx, sy, sz]) * scale) @ Q.T + rng.uniform(-80, 80, 3)
+                c6 = _cov6(np.cov(P.T, bias=True))
+                n = np.empty(3)
+                ok = hm.hm_smallest_eigvec(_p(c6), _p(n))
+                ref = np.empty(6)
+                hm.hm_plane_jacobi(_p(c6), _p(ref))
+                got = np.empty(6)
+                hm.hm_regularize(_p(c6), 3, _p(got))
+                worst = max(worst, float(np.abs(got - ref).max()))
+                np.testing.assert_allclose(got, ref, atol=2e-9)
+                if ok:
+                    n_fast += 1
+                    assert abs(np.linalg.norm(n) - 1) < 1e-12
+                    w, V = np.linalg.eigh(np.cov(P.T, bias=True))
+                    assert abs(abs(n @ V[:, 0]) - 1) < 1e-9 / max((w[1] - w[0]) / w[2], 1e-6) * 1e-3 + 1e-12
+    assert n_fast > 0.95 * len(shapes) * 3 * 40, n_fast
+    # degenerate inputs defer to the Jacobi path: zero matrix, isotropic, exactly collinear (rank 1), duplicated point
+    for c6 in (np.zeros(6), _cov6(np.eye(3)), _cov6(np.outer([1, 2, 3], [1, 2, 3]).astype(float)), _cov6(1e-30 * np.eye(3))):
+        assert hm.hm_smallest_eigvec(_p(c6), _p(np.empty(3))) == 0
+        ref, got = np.empty(6), np.empty(6)
+        hm.hm_plane_jacobi(_p(c6), _p(ref))
+        hm.hm_regularize(_p(c6), 3, _p(got))
+        np.testing.assert_array_equal(got, ref)
+    # exactly planar (rank 2, smallest eigenvalue 0): the shortcut applies and the normal is exact
+    P = np.c_[rng.normal(size=(20, 2)), np.zeros(20)]
+    n = np.empty(3)
+    assert hm.hm_smallest_eigvec(_p(_cov6(np.cov(P.T, bias=True))), _p(n)) == 1
+    np.testing.assert_allclose(np.abs(n), [0, 0, 1], atol=1e-15)
+
+
 def test_fp32_helpers_and_specified_rounding(hm):
     rng = np.random.default_rng(3)
     a = rng.normal(size=(3, 3)).astype(np.float32)
