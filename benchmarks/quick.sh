@@ -1,21 +1,29 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: GPU test suite + a short bench line with the per-kernel table.  Usage: gpurun -- 'bash benchmarks/quick.sh <tag> [pytest args]'
+# Runs ON THE GPU BOX: GPU test suite + a short bench line with the per-kernel table (+ optional kernel trace).
+# Usage: gpurun -- 'bash benchmarks/quick.sh <tag> [notest] [trace] [-- pytest args]'
 TAG=${1:-quick}; shift
+NOTEST=0; TRACE=0
+while [ $# -gt 0 ]; do case "$1" in notest) NOTEST=1;; trace) TRACE=1;; --) shift; break;; *) break;; esac; shift; done
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
-timeout 900 python -m pytest tests -m gpu -x -q "$@" > "$O/pytest.txt" 2>&1; echo "pytest exit $?" >> "$O/pytest.txt"
-tail -15 "$O/pytest.txt"
+if [ $NOTEST = 0 ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q "$@" > "$O/pytest.txt" 2>&1; echo "pytest exit $?" >> "$O/pytest.txt"
+  tail -12 "$O/pytest.txt"
+fi
+MI355_KNN_STATS=1 timeout 300 python bench.py --no-cpu-baseline --steps 1 --warmup 0 --pairs 128 2>&1 | grep "k-NN tiles" | head -4
 timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 3 > "$O/bench.json" 2> "$O/bench.err"; echo "bench exit $?"
 tail -3 "$O/bench.err"
-python - "$O/bench.json" <<'PY'
-import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-except Exception as e:
-    print("no bench json", e); sys.exit(0)
-print("pairs/s", d["value"], "ms/step", d["ms_per_step"], "e2e frac", d["roofline"]["end_to_end"]["frac"], "acc", d["accuracy"])
-for k,v in d["roofline"]["by_kernel"].items():
-    print(f'  {k[:40]:40s} {v["total_ms_per_step"]:8.3f} ms/step  n={v["launches_per_step"]:5.1f} avg={v["avg_launch_ms"]:8.4f} frac={v.get("frac_of_hbm_peak")}')
+python benchmarks/show_bench.py "$O/bench.json"
+if [ $TRACE = 1 ]; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > "$O/bench_trace.json" 2> "$O/trace.err"
+  f=$(ls $O/trace/*/*_kernel_stats.csv | tail -1); cp "$f" "$O/kernel_stats.csv"
+  python - "$f" <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:16]:
+    print(f"{r['Name'][:60]:60s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:10.1f} share={100*float(r['TotalDurationNs'])/tot:5.1f}%")
 PY
+fi

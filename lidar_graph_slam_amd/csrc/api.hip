@@ -28,6 +28,7 @@ const Tuning& tuning() {
     getf("MI355_TILE_RSCALE", v.tile_rscale);
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
     getf("MI355_GRID_CELL", v.grid_cell);
+    geti("MI355_KNN_STATS", v.knn_stats);
     return v;
   }();
   return t;

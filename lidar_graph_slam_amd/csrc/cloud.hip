@@ -403,81 +403,105 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
     if (nact > 0) {
       const TileBox bb = tile_bounds(act, q.x, q.y, q.z);
       const float eps = tile_eps(bb, rcap);
-      float r, e_max;  // first radius: k-NN radius of a surface with the segment's own point density
+      float r0, e_max;  // first radius: k-NN radius of a surface with the segment's own point density
       {
         const float ex = bb.hx - bb.lx, ey = bb.hy - bb.ly, ez = bb.hz - bb.lz;
         const float e_min = fminf(fminf(ex, ey), ez);
         e_max = fmaxf(fmaxf(ex, ey), ez);
         const float e_mid = ex + ey + ez - e_min - e_max;
         const float area = fmaxf(e_max * e_mid, 0.16f * g.m.cell * g.m.cell);
-        r = fminf(fmaxf(r_scale * sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
+        r0 = fminf(fmaxf(r_scale * sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
       }
-      // a segment that is a single sub-tile ranks the tile list directly (no sub-list, no 224-entry limit)
+      // a segment that is a single sub-tile ranks the tile list directly (no sub-list, no kSubCap limit)
       const bool direct = len <= kSubQ;
       // this lane's sub-tile box as centre + half extent (the same in the kSubQ lanes of a sub-tile).  The half extent is
       // padded by eps, so that rounding of centre / extent can only ADD candidates; a sub-tile without active lanes matches
       // nothing (half extent -inf).
       float scx, scy, scz, shx, shy, shz;
+      bool take;  // this sub-tile appends candidates in the next build pass
       {
         const float lx = group_min(act ? q.x : INFINITY), ly = group_min(act ? q.y : INFINITY), lz = group_min(act ? q.z : INFINITY);
         const float hx = group_max(act ? q.x : -INFINITY), hy = group_max(act ? q.y : -INFINITY), hz = group_max(act ? q.z : -INFINITY);
-        const bool some = lx <= hx;
-        scx = some ? 0.5f * (lx + hx) : 0.f; scy = some ? 0.5f * (ly + hy) : 0.f; scz = some ? 0.5f * (lz + hz) : 0.f;
-        shx = some ? 0.5f * (hx - lx) + eps : -INFINITY; shy = some ? 0.5f * (hy - ly) + eps : -INFINITY;
-        shz = some ? 0.5f * (hz - lz) + eps : -INFINITY;
+        take = lx <= hx;
+        scx = take ? 0.5f * (lx + hx) : 0.f; scy = take ? 0.5f * (ly + hy) : 0.f; scz = take ? 0.5f * (lz + hz) : 0.f;
+        shx = take ? 0.5f * (hx - lx) + eps : -INFINITY; shy = take ? 0.5f * (hy - ly) + eps : -INFINITY;
+        shz = take ? 0.5f * (hz - lz) + eps : -INFINITY;
       }
+      // Every sub-tile has its OWN radius: rs is what its list covers after the next build pass, rs_old what it covers now.
+      // The tile list always covers the largest of them (R).
+      float rs = r0, rs_old = -INFINITY;
       int slen = 0, sdone = 0;  // this lane's sub-list: entries appended / ranked so far (the same in the lanes of a sub-tile)
       SmallestKeys<K + 2> keys;
       keys.init();
-      int n_ord = 0;
+      int n_ord = 0, n_done = 0;  // tile list: gathered / ranked directly (direct mode)
       TileBox ob = bb;
-      float r_old = -INFINITY;
-      bool has_old = false, open = act, ovf = false;
+      float R = -1.f;
+      bool has_old = false, open = act;
       for (int round = 0;; round++) {
-        const TileBox nb = grow(bb, r);
-        const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
-        const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
-        if (n_new < 0) {  // over a budget: split the segment if nothing has been ranked yet, else hand the open lanes over
-          if (round == 0 && r > rmin && r > 0.5f * e_max) {
-            // clustered points (far field): the density guess overshoots and the radius, not the segment's own extent,
-            // makes the box too big - start smaller, the rounds grow it back where needed
-            r = fmaxf(0.5f * r, rmin);
-            round = -1;
-            continue;
+        // ---- tile list: grow the gathered box to the largest radius a working sub-tile asks for
+        const float Rn = uniform_f(wave_max_all(take ? rs : 0.f));
+        if (Rn > R) {
+          const TileBox nb = grow(bb, Rn);
+          const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
+          const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
+          if (n_new < 0) {  // over a budget: split the segment if nothing has been gathered yet, else hand the open lanes over
+            if (!has_old && Rn > rmin && Rn > 0.5f * e_max) {
+              // clustered points (far field): the density guess overshoots and the radius, not the segment's own extent,
+              // makes the box too big - start smaller, the rounds grow it back where needed
+              rs = fmaxf(0.5f * rs, rmin);
+              round = -1;
+              continue;
+            }
+            if (!has_old && len > 8) split = true;
+            else fb = fb || open;
+            break;
           }
-          if (round == 0 && len > 8) split = true;
-          else fb = fb || open;
-          break;
+          ob = nb;
+          has_old = true;
+          R = Rn;
+          n_ord = n_new;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
+        bool redo = false;
         if (direct) {
 #pragma unroll 4
-          for (int o = n_ord; o < n_new; o++) {
+          for (int o = n_done; o < n_ord; o++) {
             const float4 p = cand[o];
             const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
             keys.insert((d & ~kOrdMask) | (uint32_t)o);
           }
+          n_done = n_ord;
         } else {
-          // ---- sub-lists: every candidate of the tile list (old and new) that enters a sub-tile's grown box this round,
-          // i.e. lies inside (sub-box + r) but not inside (sub-box + r_old).  One step tests kSubQ candidates against all
-          // kNSub boxes: lane (s, j) tests candidate base + j against the box of ITS sub-tile s, one ballot gives every
+          // ---- sub-lists: every candidate of the tile list (old and new) that enters a working sub-tile's grown box this
+          // round, i.e. lies inside (sub-box + rs) but not inside (sub-box + rs_old).  One step tests kSubQ candidates against
+          // all kNSub boxes: lane (s, j) tests candidate base + j against the box of ITS sub-tile s, one ballot gives every
           // sub-tile its 8 hit bits, and the hits are appended to the sub-tile's list in candidate order.
-          for (int base = 0; base < n_new; base += kSubQ) {
+          for (int base = 0; base < n_ord; base += kSubQ) {
             const int o = base + sublane;
             const float4 p = cand[min(o, kTileMaxCand - 1)];
             // Chebyshev distance of p to the sub-box (<= 0 inside)
             const float m = fmaxf(fmaxf(fabsf(p.x - scx) - shx, fabsf(p.y - scy) - shy), fabsf(p.z - scz) - shz);
-            const bool in = (o < n_new) && (m <= r) && !(m <= r_old);
+            const bool in = take && (o < n_ord) && (m <= rs) && !(m <= rs_old);
             const unsigned long long mask = __ballot(in);
             const uint32_t hits = (uint32_t)(mask >> (mysub * kSubQ)) & ((1u << kSubQ) - 1u);
             const int at = slen + __popc(hits & ((1u << sublane) - 1u));
             if (in && at < kSubCap) sub[mysub][at] = (uint16_t)o;
-            slen += __popc(hits);  // may run past kSubCap: the sub-tile's lanes are then handed over (ovf)
+            slen += __popc(hits);  // may run past kSubCap
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          // a FIRST list that does not fit is rebuilt with half the radius (the growth rounds bring back what a lane needs);
+          // a list that overflows while growing hands its open lanes over
+          const bool over = slen > kSubCap;
+          redo = over && sdone == 0 && rs > rmin;
+          if (redo) {
+            slen = 0;
+            rs = fmaxf(0.5f * rs, rmin);
+          } else if (over) {
+            fb = fb || open;
+            slen = kSubCap;
+          }
           // ---- rank: every lane walks the new part of ITS sub-tile's list
-          const int from = sdone, to = min(slen, kSubCap);
-          ovf = ovf || (slen > kSubCap);
+          const int from = sdone, to = slen;
           sdone = to;
           const int trip = wave_max_all_i(to - from);
           const uint16_t* mine = sub[mysub] + from;
@@ -489,31 +513,39 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
             keys.insert((from + t < to) ? ((d & ~kOrdMask) | o) : SmallestKeys<K + 2>::kEmpty);
           }
         }
-        n_ord = n_new;
-        const float rs = r * 0.9999f - eps;  // every point within rs of a query of the segment has been seen by its lane
+        // ---- which lanes are done?  every point within rsafe of a query of the sub-tile has been seen by its lanes
+        const float rsafe = redo ? 0.f : rs * 0.9999f - eps;
         const uint32_t kk = keys.at(k - 1);
         const bool full = kk != SmallestKeys<K + 2>::kEmpty;
         const float ub = __uint_as_float(kk | kOrdMask);  // >= the exact k-th squared distance
-        fb = fb || (act && ovf);
-        open = act && !ovf && !(full && ub <= rs * rs);
+        open = act && !fb && !(full && ub <= rsafe * rsafe);
         const unsigned long long om = __ballot(open);
         if (!om) break;
-        // next radius: what the open lanes ask for; lanes asking for much more wait for a later round
-        const float need = open ? (full ? sqrtf(ub) * 1.001f + 2.f * eps : 2.f * r) : 0.f;
-        const float near = wave_max_all((open && need <= 2.f * r) ? need : 0.f);
-        const float far = wave_min_all((open && need > 2.f * r) ? need : INFINITY);
-        float want = (near > 0.f) ? near : far;
-        want = fminf(fmaxf(want, 1.02f * r), rcap);
-        if (!(want > r) || round >= 4) {
+        if (round >= 6) {
           fb = fb || open;
           break;
         }
-        // sub-tiles whose lanes are all done take no more candidates
-        if (((om >> (mysub * kSubQ)) & ((1ull << kSubQ) - 1ull)) == 0ull) shx = -INFINITY;
-        ob = nb;
-        has_old = true;
-        r_old = r;
-        r = uniform_f(want);
+        // ---- next radius of every sub-tile that still has open lanes: what they ask for; lanes asking for much more wait
+        // for a later round
+        take = ((om >> (mysub * kSubQ)) & ((1ull << kSubQ) - 1ull)) != 0ull;
+        if (take && !redo) {
+          const float need = open ? (full ? sqrtf(ub) * 1.001f + 2.f * eps : 2.f * rs) : 0.f;
+          const float near = group_max((open && need <= 2.f * rs) ? need : 0.f);
+          const float far = group_min((open && need > 2.f * rs) ? need : INFINITY);
+          float want = (near > 0.f) ? near : far;
+          want = fminf(fmaxf(want, 1.02f * rs), rcap);
+          if (!(want > rs)) {  // at the radius cap: the open lanes of this sub-tile are handed over
+            fb = fb || open;
+            take = false;
+          } else {
+            rs_old = rs;
+            rs = want;
+          }
+        }
+        if (!__any(take)) {  // only lanes that have just been handed over were open
+          open = open && !fb;
+          break;
+        }
       }
       if (!split) {
         // closed lanes: exact unless truncation could have swapped the k-th and (k+1)-th candidates (or they tie exactly)
@@ -689,6 +721,16 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
                      (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, Gh, set.B);
   hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
                      set.B, (const int*)set.fbq.p, (const int*)set.fbn.p);
+  if (tn.knn_stats) {  // tuning aid: how much of the work the tile kernel handed over
+    std::vector<int> fbn(set.B), cnt(set.B);
+    MI_HIP(hipStreamSynchronize(s));
+    MI_HIP(hipMemcpy(fbn.data(), set.fbn.p, sizeof(int) * set.B, hipMemcpyDeviceToHost));
+    MI_HIP(hipMemcpy(cnt.data(), set.count.p, sizeof(int) * set.B, hipMemcpyDeviceToHost));
+    long nf = 0, np = 0;
+    int worst = 0;
+    for (int c = 0; c < set.B; c++) { nf += fbn[c]; np += cnt[c]; worst = std::max(worst, fbn[c]); }
+    fprintf(stderr, "[mi355] k-NN tiles: %ld of %ld points handed over to k_knn_hard (%.3f %%), worst cloud %d\n", nf, np, 100.0 * nf / std::max(np, 1L), worst);
+  }
 }
 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {

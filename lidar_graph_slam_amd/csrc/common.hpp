@@ -85,6 +85,8 @@ struct Tuning {
   float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
   int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
+  int knn_stats = 0;          // MI355_KNN_STATS         1 = after every covariance launch, synchronise and print to stderr how many
+                              //                         points the tile kernel handed over to k_knn_hard (tuning aid, host side only)
 };
 const Tuning& tuning();
 

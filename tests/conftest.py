@@ -19,6 +19,16 @@ if os.path.join(ROOT, "tests") not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
+    # torch bundles its own ROCm runtime; once libmi355_lidar.so has pulled /opt/rocm's libamdhip64 into the process torch can no
+    # longer initialise its GPU context ("No HIP GPUs are available").  Tests that hand torch tensors to the C-ABI need both, so
+    # torch goes first (a no-op on the CPU-only container).  INTEGRATION.md states the same load order for callers.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # torch is plumbing for a few tests only
+        pass
 
 
 @pytest.fixture(scope="session")
