@@ -10,7 +10,7 @@ using namespace mi355;
 
 namespace mi355 {
 thread_local KernelTimers* g_timers = nullptr;
-const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard+k_cov_from_knn", "k_voxel_centroids", "sort_pairs(k_sort_*)",
+const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
                                                  "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_linearize",
                                                  "k_gicp_error", "k_gicp_solve+k_gicp_decide", "k_fitness"};
 const Tuning& tuning() {

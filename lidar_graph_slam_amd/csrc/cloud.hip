@@ -369,6 +369,50 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
+// Bitonic sort of the wave's lanes by one coordinate of (x, y, z), ascending inside every aligned segment of S lanes; the
+// coordinate (axis 0 / 1 / 2) is the same for all lanes of a segment.  (x, y, z, i) travel together.
+template <int S>
+__device__ __forceinline__ void segment_sort_lanes(float& x, float& y, float& z, int& i, int axis) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= S; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float px = __shfl_xor(x, j, kWave), py = __shfl_xor(y, j, kWave), pz = __shfl_xor(z, j, kWave);
+      const int pi = __shfl_xor(i, j, kWave);
+      const float mine = (axis == 0) ? x : ((axis == 1) ? y : z), theirs = (axis == 0) ? px : ((axis == 1) ? py : pz);
+      const bool up = ((lane & k) == 0) || (k == S);  // the last merge is ascending in every segment
+      const bool lower = (lane & j) == 0;
+      // the lower lane of a pair keeps the smaller key in an ascending block; equal keys stay where they are
+      const bool take = (lower == up) ? (theirs < mine) : (theirs > mine);
+      x = take ? px : x; y = take ? py : y; z = take ? pz : z; i = take ? pi : i;
+    }
+  }
+}
+// Longest axis of the bounding box of the aligned segment of S lanes a lane belongs to (lanes with x = +inf do not count).
+template <int S>
+__device__ __forceinline__ int segment_longest_axis(float x, float y, float z) {
+  const bool ok = x < INFINITY;
+  float lx = ok ? x : INFINITY, ly = ok ? y : INFINITY, lz = ok ? z : INFINITY;
+  float hx = ok ? x : -INFINITY, hy = ok ? y : -INFINITY, hz = ok ? z : -INFINITY;
+#pragma unroll
+  for (int off = 1; off < S; off <<= 1) {
+    lx = fminf(lx, __shfl_xor(lx, off, kWave)); ly = fminf(ly, __shfl_xor(ly, off, kWave)); lz = fminf(lz, __shfl_xor(lz, off, kWave));
+    hx = fmaxf(hx, __shfl_xor(hx, off, kWave)); hy = fmaxf(hy, __shfl_xor(hy, off, kWave)); hz = fmaxf(hz, __shfl_xor(hz, off, kWave));
+  }
+  const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
+  return (ex >= ey && ex >= ez) ? 0 : ((ey >= ez) ? 1 : 2);
+}
+// kd order of the 64 queries of a tile: split at the median along the longest axis, three levels deep, so that every aligned
+// group of 8 lanes (a sub-tile) and every aligned half / quarter (what a tile is split into when its box is too big) is
+// spatially compact.  64 consecutive points of the Morton curve are NOT: the curve jumps, and one ragged group of 8 sets
+// the trip count of the whole wave's ranking loop (measured: mean sub-list 77 candidates, longest 182).
+__device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int& i) {
+  segment_sort_lanes<64>(x, y, z, i, segment_longest_axis<64>(x, y, z));
+  segment_sort_lanes<32>(x, y, z, i, segment_longest_axis<32>(x, y, z));
+  segment_sort_lanes<16>(x, y, z, i, segment_longest_axis<16>(x, y, z));
+}
+
 // Launch: one-wave blocks, G per cloud (all on the cloud's XCD); a wave takes tiles from the cloud's counter until none
 // is left, so the waves of a cloud finish together whatever the tiles cost.
 template <int K>
@@ -390,9 +434,11 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
   const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
   if (tile0 >= n) return;
-  const int i = tile0 + lane;
+  int i = tile0 + lane;
+  float4 q = g.pts[min(i, n - 1)];
+  if (i >= n) q.x = q.y = q.z = INFINITY;  // past the end of the cloud: sorts to the last lanes, never active
+  kd_order_tile(q.x, q.y, q.z, i);
   const bool valid = i < n;
-  const float4 q = g.pts[min(i, n - 1)];
   const float rcap = 16.f * g.m.cell, rmin = 0.6f * g.m.cell;
   bool fb = false;  // this lane goes to the fallback queue
   int seg = 0, len = kWave;
@@ -485,7 +531,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
             const unsigned long long mask = __ballot(in);
             const uint32_t hits = (uint32_t)(mask >> (mysub * kSubQ)) & ((1u << kSubQ) - 1u);
             const int at = slen + __popc(hits & ((1u << sublane) - 1u));
-            if (in && at < kSubCap) sub[mysub][at] = (uint16_t)o;
+            if (in && at < kSubCap) sub[mysub][at] = (uint16_t)(o << 4);  // byte offset of the candidate in cand[]
             slen += __popc(hits);  // may run past kSubCap
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -505,12 +551,14 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           sdone = to;
           const int trip = wave_max_all_i(to - from);
           const uint16_t* mine = sub[mysub] + from;
+          const int cnt = to - from;
 #pragma unroll 4
           for (int t = 0; t < trip; t++) {
-            const uint32_t o = (uint32_t)mine[t] & kOrdMask;  // rows are padded: reading past `to` stays inside the array
-            const float4 p = cand[o];
+            // rows are padded: reading past `to` stays inside the array, and a stale offset stays inside cand[]
+            const uint32_t off = (uint32_t)mine[t] & (uint32_t)((kTileMaxCand - 1) << 4);
+            const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + off);
             const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
-            keys.insert((from + t < to) ? ((d & ~kOrdMask) | o) : SmallestKeys<K + 2>::kEmpty);
+            keys.insert((t < cnt) ? ((d & ~kOrdMask) | (off >> 4)) : SmallestKeys<K + 2>::kEmpty);
           }
         }
         // ---- which lanes are done?  every point within rsafe of a query of the sub-tile has been seen by its lanes
@@ -587,89 +635,194 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   }  // next tile
 }
 
-// Fallback for the few points the tile kernel hands over (isolated far-field points whose k-th neighbour is tens of
-// metres away, exact distance ties, truncation-ambiguous lists): ONE WAVE PER QUERY, the candidates spread over the lanes.
-// A per-lane search would walk thousands of points serially for such a query (0.7 ms measured, longer than the whole
-// tile kernel); here the wave scans the cells of a box around the query 64 points at a time, every lane keeps the k best of
-// its own share in exact (distance, caller index) order, and the 64 lists are merged by k wave-wide arg-min steps.
-// The box grows until it covers the k-th distance found, so the result is the exact k-NN with the oracle's tie rule.
+// Fallback for the points the tile kernel hands over (wide or sparse neighbourhoods: far-field points whose k-th neighbour
+// is metres away, boxes that outgrow the tile list, exact distance ties): ONE WAVE PER QUERY, the candidates spread over
+// the lanes, exact (distance, caller index) order.  Per round of the growing box around the query:
+//   A  every lane runs its share of the candidates through a branch-free (k+1)-deep network of FULL 32-bit distances
+//      (v_med3 per position; the first version inserted into a sorted (distance, index) list under a branch: ~170
+//      instructions whenever any lane wanted a candidate — 4.9 k instructions per query against 0.27 k in the tile kernel);
+//   B  the 64 sorted lists, parked as columns in LDS, are merged by popping the smallest head (all equal heads at once)
+//      until k values are out: that is the exact k-th distance tau, with the number of candidates below and at it;
+//   C  a second pass over the same candidates collects everything below tau by ballot, and of the candidates AT tau as many as
+//      are still needed, lowest caller index first (the oracle's tie rule).
+// The covariance is fused: the k neighbours sit in k lanes, mean and covariance are wave reductions in fp64, and the raw
+// matrices of up to 64 queries are parked in LDS so that the regularisation (the expensive part) runs lane-parallel.
 template <int K>
 __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
-                                                 const GridMeta* __restrict__ meta, int* __restrict__ nbr, const int* __restrict__ queue,
-                                                 const int* __restrict__ queue_n, size_t cap, size_t slots_cap, int k, int G, int B) {
+                                                 const GridMeta* __restrict__ meta, Cov6* __restrict__ cov, const int* __restrict__ queue,
+                                                 const int* __restrict__ queue_n, size_t cap, size_t slots_cap, int k, int method, int G, int B) {
+  __shared__ uint32_t col[K + 1][kWave];  // per-lane sorted distance lists (column = lane)
+  __shared__ double raw[kWave][6];        // raw covariances awaiting regularisation
+  __shared__ int raw_i[kWave];
+  __shared__ int tie_j[kWave];            // candidates at the k-th distance (tie resolution)
+  __shared__ int out_j[kWave];            // the neighbours below the k-th distance, then the chosen ones at it
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
   const int n = g.m.n;
   const int lane = lane_id();
+  const unsigned long long below = (1ull << lane) - 1ull;
   const int nq = queue_n[c];
+  int n_raw = 0;
+  auto flush = [&]() {  // regularise the parked covariances, one per lane
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < n_raw) {
+      const Sym3<double> cv = {raw[lane][0], raw[lane][1], raw[lane][2], raw[lane][3], raw[lane][4], raw[lane][5]};
+      const Sym3<double> r = regularize_covariance(cv, method);
+      cov[(size_t)c * cap + raw_i[lane]] = cov6_pack((float)r.xx, (float)r.xy, (float)r.xz, (float)r.yy, (float)r.yz, (float)r.zz);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    n_raw = 0;
+  };
   for (int t = bx; t < nq; t += G) {
     const int i = queue[(size_t)c * cap + t];
     const float4 q = g.pts[i];
-    int* o = nbr + ((size_t)c * cap + i) * k;
-    if (n < k) {  // the API rejects this; keep the list defined
-      for (int u = lane; u < k; u += kWave) o[u] = -1;
-      continue;
-    }
     const TileBox qb{q.x, q.y, q.z, q.x, q.y, q.z};
     const float eps = tile_eps(qb, 0.f);
     float r = 2.f * g.m.cell;
-    NearestK<K> nk;
+    int mine = -1;  // lane u < k ends up holding the u-th neighbour (sorted index); fewer than k points in the cloud: -1
     for (;;) {
       // candidates: the cells of the box q +- r, or the whole cloud once the box outgrows 64 top-level cells
       const TileCells cells = tile_cells(g, grow(qb, r), 0x7fffffff);
       const bool whole = !cells.ok;
-      if (!whole && cells.total < k) { r *= 2.f; continue; }
-      nk.init(g.orig, k);
-      if (whole) {
-        for (int j = lane; j < n; j += kWave) {
-          const float4 p = g.pts[j];
-          nk.visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
-        }
-      } else {
-        unsigned long long todo = __ballot(cells.ce > cells.cs);
-        while (todo) {
-          const int cl = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const int s0 = __builtin_amdgcn_readlane(cells.cs, cl), e0 = __builtin_amdgcn_readlane(cells.ce, cl);
-          for (int j = s0 + lane; j < e0; j += kWave) {
+      if (!whole && cells.total < k && cells.total < n) { r *= 2.f; continue; }
+      const unsigned long long cellmask = __ballot(cells.ce > cells.cs);
+      // visit(j, d2) for every candidate of this lane's share
+      auto scan = [&](auto&& visit) {
+        if (whole) {
+          for (int j = lane; j < n; j += kWave) {
             const float4 p = g.pts[j];
-            nk.visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+            visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+          }
+        } else {
+          unsigned long long todo = cellmask;
+          while (todo) {
+            const int cl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int s0 = __builtin_amdgcn_readlane(cells.cs, cl), e0 = __builtin_amdgcn_readlane(cells.ce, cl);
+            for (int j = s0 + lane; j < e0; j += kWave) {
+              const float4 p = g.pts[j];
+              visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+            }
+          }
+        }
+      };
+      // ---- A: per-lane network of distances (positive floats order like unsigned integers)
+      SmallestKeys<K + 1> nk;
+      nk.init();
+      scan([&](int, float d2) { nk.insert(__float_as_uint(d2)); });
+#pragma unroll
+      for (int u = 0; u < K + 1; u++) col[u][lane] = nk.v[u];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // ---- B: pop the smallest head (every lane holding it pops) until k values are out
+      int head = 0, n_lt = 0, n_eq = 0;
+      uint32_t tau = SmallestKeys<K + 1>::kEmpty;
+      while (n_lt + n_eq < k) {
+        const uint32_t hd = (head <= K) ? col[min(head, K)][lane] : SmallestKeys<K + 1>::kEmpty;
+        uint32_t best = hd;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, kWave));
+        best = (uint32_t)__builtin_amdgcn_readfirstlane((int)best);
+        if (best == SmallestKeys<K + 1>::kEmpty) break;  // fewer than k candidates
+        // a lane may hold the value several times (distinct points at the same distance): pop them all
+        int pops = 0;
+        if (hd == best) {
+          pops = 1;
+          while (head + pops <= K && col[head + pops][lane] == best) pops++;
+          head += pops;
+        }
+        int total = pops;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, kWave);
+        n_lt += n_eq;
+        n_eq = __builtin_amdgcn_readfirstlane(total);
+        tau = best;
+      }
+      const bool enough = n_lt + n_eq >= k;
+      const float tau_f = __uint_as_float(tau);
+      const float rs = r * 0.9999f - eps;
+      if (!(whole || (enough && tau_f <= rs * rs))) {  // the box does not cover the k-th distance yet
+        r = enough ? sqrtf(tau_f) * 1.001f + 2.f * eps : 2.f * r;
+        continue;
+      }
+      // ---- C: collect.  Everything below tau is a neighbour; of the n_eq candidates AT tau, k - n_lt are needed
+      const int want_eq = enough ? (k - n_lt) : n_eq;
+      int n_out = 0, n_tie = 0;
+      mine = -1;
+      // the collection needs wave-wide ballots per step, so it walks the candidates in lock step instead of through scan()
+      {
+        auto step = [&](int j, bool in_range) {
+          float d2 = INFINITY;
+          if (in_range) {
+            const float4 p = g.pts[j];
+            d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
+          }
+          const uint32_t key = __float_as_uint(d2);
+          const bool lt = in_range && key < tau, eq = in_range && key == tau;
+          const unsigned long long ml = __ballot(lt), me = __ballot(eq);
+          if (ml) {  // output slots n_out ... in candidate order
+            if (lt) out_j[n_out + __popcll(ml & below)] = j;  // n_lt < k <= 64 slots in all
+            n_out += __popcll(ml);
+          }
+          if (me) {
+            if (eq) {
+              const int at = n_tie + __popcll(me & below);
+              if (at < kWave) tie_j[at] = j;
+            }
+            n_tie += __popcll(me);
+          }
+        };
+        if (whole) {
+          for (int j0 = 0; j0 < n; j0 += kWave) step(j0 + lane, j0 + lane < n);
+        } else {
+          unsigned long long todo = cellmask;
+          while (todo) {
+            const int cl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int s0 = __builtin_amdgcn_readlane(cells.cs, cl), e0 = __builtin_amdgcn_readlane(cells.ce, cl);
+            for (int j0 = s0; j0 < e0; j0 += kWave) step(j0 + lane, j0 + lane < e0);
           }
         }
       }
-      // merge: k times, the smallest head of the 64 sorted lists (ties: lowest caller index)
-      int head = 0, mine = -1;  // lane u < k ends up holding the u-th neighbour in `mine`
-      float kth = INFINITY;
-      for (int u = 0; u < k; u++) {
-        float hd = INFINITY;
-        int hj = -1;
-#pragma unroll
-        for (int v = 0; v < K; v++)
-          if (v == head) { hd = nk.d2[v]; hj = nk.idx[v]; }
-        const float best = uniform_f(wave_min_all(hd));
-        bool win = (hd == best) && hj >= 0;
-        if (__popcll(__ballot(win)) > 1) {  // several lists offer the same distance: lowest caller index first (rare)
-          const int ho = win ? g.orig[hj] : 0x7fffffff;
-          int bo = ho;
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) bo = min(bo, __shfl_xor(bo, off, kWave));
-          win = win && (ho == bo);
-        }
-        if (!__any(win)) break;  // fewer than k points seen
-        const int wj = __builtin_amdgcn_readlane(hj, __builtin_ctzll(__ballot(win)));
-        if (win) head++;
-        if (lane == u) mine = wj;
-        kth = best;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // ties at tau: the want_eq lowest caller indices (n_tie == n_eq; more than 64 candidates at one distance do not occur
+      // in point clouds — the list is cut there)
+      {
+        const int nt = min(n_tie, kWave);
+        const int tj = (lane < nt) ? tie_j[lane] : -1;
+        const int to = (lane < nt) ? g.orig[tj] : 0x7fffffff;
+        int rank = 0;  // number of tied candidates with a lower caller index
+        for (int u = 0; u < nt; u++) rank += (__shfl(to, u, kWave) < to) ? 1 : 0;
+        if (lane < nt && rank < want_eq && n_out + rank < kWave) out_j[n_out + rank] = tj;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int n_nb = min(n_out + min(want_eq, nt), k);
+        mine = (lane < n_nb) ? out_j[lane] : -1;
       }
-      const float rs = r * 0.9999f - eps;
-      if (whole || kth <= rs * rs) {
-        if (lane < k) o[lane] = mine;
-        break;
+      break;
+    }
+    // ---- covariance: lanes 0..k-1 hold the neighbours
+    {
+      const bool has = lane < k;
+      const float4 p = (has && mine >= 0) ? g.pts[mine] : make_float4(0.f, 0.f, 0.f, 0.f);
+      auto wsum = [&](double v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+        return v;
+      };
+      const double invk = 1.0 / (double)k;
+      const double mx = wsum(has ? (double)p.x : 0.0) * invk, my = wsum(has ? (double)p.y : 0.0) * invk, mz = wsum(has ? (double)p.z : 0.0) * invk;
+      const double x = has ? (double)p.x - mx : 0.0, y = has ? (double)p.y - my : 0.0, z = has ? (double)p.z - mz : 0.0;
+      const double cxx = wsum(x * x) * invk, cxy = wsum(x * y) * invk, cxz = wsum(x * z) * invk, cyy = wsum(y * y) * invk, cyz = wsum(y * z) * invk,
+                   czz = wsum(z * z) * invk;
+      if (lane == 0) {
+        raw[n_raw][0] = cxx; raw[n_raw][1] = cxy; raw[n_raw][2] = cxz; raw[n_raw][3] = cyy; raw[n_raw][4] = cyz; raw[n_raw][5] = czz;
+        raw_i[n_raw] = i;
       }
-      r = (kth < INFINITY) ? sqrtf(kth) * 1.001f + 2.f * eps : 2.f * r;
+      n_raw++;
+      if (n_raw == kWave) flush();
     }
   }
+  if (n_raw) flush();
 }
 
 // Step 2: neighbourhood covariance from the neighbour lists, one 24-byte record per point (all points, or the queue's).
@@ -714,13 +867,11 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
     hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                        set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
   }
-  // the points the tile kernel handed over: one wave per point, then their covariances from the lists
+  // the points the tile kernel handed over: one wave per point, covariance included
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
   TimedLaunch tl(KF_KNN_HARD, s);
-  hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p,
-                     (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, Gh, set.B);
-  hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
-                     set.B, (const int*)set.fbq.p, (const int*)set.fbn.p);
+  hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
+                     (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, method, Gh, set.B);
   if (tn.knn_stats) {  // tuning aid: how much of the work the tile kernel handed over
     std::vector<int> fbn(set.B), cnt(set.B);
     MI_HIP(hipStreamSynchronize(s));

@@ -52,7 +52,9 @@ def pose_error(T_est: np.ndarray, T_ref: np.ndarray):
 class Scene:
     """Axis-aligned boxes + ground plane."""
 
-    def __init__(self, seed: int = 1234, n_boxes: int = 60, x_extent: float = 400.0):
+    def __init__(self, seed: int = 1234, n_boxes: int = 60, x_extent: float = 400.0, box_x_range=(-60.0, 60.0)):
+        """``box_x_range``: where along the street the parked cars / poles stand.  The default (+-60 m, 60 boxes) is the scene
+        of the pair tests and golden fixtures; a long odometry stream needs them along its whole path (``street()``)."""
         rng = np.random.default_rng(seed)
         boxes = []
         # walls: 5 m flush / 5 m recessed by 1.0 m, alternating along x
@@ -67,7 +69,7 @@ class Scene:
                 x += 5.0
                 k += 1
         for i in range(n_boxes):
-            cx = rng.uniform(-60.0, 60.0)
+            cx = rng.uniform(box_x_range[0], box_x_range[1])
             # parked at the kerbs: the driving lane |y| < 2.6 m stays free, so no sensor pose on the path sits inside or
             # against an object (a scan with 14 k returns inside 1 m is not a LiDAR scan)
             cy = rng.uniform(3.6, 7.0) if rng.uniform() < 0.45 else rng.uniform(-9.0, -3.6)
@@ -110,6 +112,13 @@ class Scene:
         return t_hit
 
 
+def street(length: float, seed: int = 1234, boxes_per_metre: float = 0.5) -> Scene:
+    """A street scene with parked cars / poles along ``length`` metres (x from -20 m), for odometry streams (BASELINE config 4:
+    1000 scans at 0.8 m = 800 m of path; the default Scene has objects within +-60 m only, beyond which translation along
+    the street is observable from the 5 m wall recesses alone)."""
+    return Scene(seed, n_boxes=int(boxes_per_metre * (length + 40.0)), x_extent=length + 120.0, box_x_range=(-20.0, length + 20.0))
+
+
 def sensor_dirs(n_rings: int = 64, n_azimuth: int = 1024) -> np.ndarray:
     elev = np.deg2rad(np.linspace(2.0, -24.8, n_rings))
     az = np.linspace(0.0, 2.0 * np.pi, n_azimuth, endpoint=False)
@@ -119,10 +128,13 @@ def sensor_dirs(n_rings: int = 64, n_azimuth: int = 1024) -> np.ndarray:
 
 
 def cast_scan(scene: Scene, T_world_sensor: np.ndarray, *, n_rings: int = 64, n_azimuth: int = 1024,
-              noise_sigma: float = 0.02, seed: int = 1, jitter_sigma: float = 0.002) -> np.ndarray:
+              noise_sigma: float = 0.02, seed: int = 1, jitter_sigma: float = 0.002, ground_max_range: float | None = None) -> np.ndarray:
     """One scan in the SENSOR frame, float32 [n_rings*n_azimuth, 4].  ``noise_sigma`` acts along the ray; ``jitter_sigma``
     is a small isotropic 3-D jitter (beam divergence / angular encoder noise) so that the returns of one azimuth column
-    are not EXACTLY coplanar — exactly singular neighbourhoods make eigenvalue-sign tests implementation-defined."""
+    are not EXACTLY coplanar — exactly singular neighbourhoods make eigenvalue-sign tests implementation-defined.
+    ``ground_max_range``: ground returns beyond this range are dropped (no-return rays).  A real road does not return at the
+    grazing angles the far rings hit it with; a perfectly flat, perfectly reflective ground out to 80 m lays concentric rings
+    around EVERY sensor pose, and matching ring to ring pulls NDT (and, weakly, GICP) towards the identity."""
     T = np.asarray(T_world_sensor, dtype=np.float64)
     d_s = sensor_dirs(n_rings, n_azimuth)
     d_w = d_s @ T[:3, :3].T
@@ -131,6 +143,9 @@ def cast_scan(scene: Scene, T_world_sensor: np.ndarray, *, n_rings: int = 64, n_
     if noise_sigma > 0:
         rng_ = np.where(rng_ >= MAX_RANGE, rng_, rng_ + rng.normal(0.0, noise_sigma, size=rng_.shape))
     no_return = rng_ >= MAX_RANGE
+    if ground_max_range is not None:
+        hit_z = T[2, 3] + d_w[:, 2] * rng_
+        no_return = no_return | ((np.abs(hit_z - GROUND_Z) < 0.05) & (rng_ > ground_max_range))
     pts = d_s * rng_[:, None]
     if jitter_sigma > 0:
         pts = pts + rng.normal(0.0, jitter_sigma, size=pts.shape)

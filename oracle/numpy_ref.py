@@ -262,3 +262,97 @@ def ndt_score(src, cells, min_b, div_b, resolution, p6, outlier_ratio=0.55, froz
                 continue
             score += -d1 * e
     return score, assign
+
+
+class NdtModel:
+    """Vectorised, float64, and written independently of oracle_ndt.cpp: the NDT score of Magnusson 2009 eq. 6.9 over DIRECT7
+    neighbourhoods, and a Newton optimiser that takes its gradient and Hessian from FINITE DIFFERENCES of that score (no
+    analytic derivative code is shared with the oracle or the HIP path).  Used to tell an optimiser bug from a property of
+    the scene (tests/test_oracle_ndt.py::test_ring_trap_*)."""
+
+    def __init__(self, tgt, resolution=2.0, outlier_ratio=0.55, min_points=6, eig_mult=0.01):
+        cells, self.min_b, self.div_b = ndt_cells(tgt, resolution, min_points, eig_mult)
+        self.res = float(resolution)
+        self.keys = np.array(sorted(cells), dtype=np.int64)
+        self.mean = np.array([cells[k][1] for k in self.keys]).reshape(-1, 3)
+        self.icov = np.array([cells[k][3] for k in self.keys]).reshape(-1, 3, 3)
+        c1 = 10 * (1 - outlier_ratio)
+        c2 = outlier_ratio / resolution ** 3
+        d3 = -np.log(c2)
+        self.d1 = -np.log(c1 + c2) - d3
+        self.d2 = -2 * np.log((-np.log(c1 * np.exp(-0.5) + c2) - d3) / self.d1)
+        self.disp = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+
+    def _transform(self, src, p6):
+        return src[:, :3].astype(np.float64) @ rot_xyz(*p6[3:]).T + np.asarray(p6[:3], dtype=np.float64)
+
+    def assign(self, src, p6):
+        """[n, 7] indices into the cell arrays (-1: no usable cell there)."""
+        x = self._transform(src, p6)
+        ijk = np.floor(x.astype(np.float32) * np.float32(1.0 / self.res)).astype(np.int64)
+        c = ijk[:, None, :] + self.disp[None, :, :] - self.min_b[None, None, :]
+        ok = np.all((c >= 0) & (c < self.div_b[None, None, :]), axis=2)
+        key = c[..., 0] + c[..., 1] * self.div_b[0] + c[..., 2] * self.div_b[0] * self.div_b[1]
+        pos = np.searchsorted(self.keys, key)
+        pos = np.minimum(pos, len(self.keys) - 1)
+        ok &= self.keys[pos] == key
+        return np.where(ok, pos, -1)
+
+    def score(self, src, p6, assign=None):
+        a = self.assign(src, p6) if assign is None else assign
+        x = self._transform(src, p6)
+        ok = a >= 0
+        idx = np.where(ok, a, 0)
+        xt = x[:, None, :] - self.mean[idx]
+        q = np.einsum("nki,nkij,nkj->nk", xt, self.icov[idx], xt)
+        e = np.exp(-self.d2 * q / 2)
+        ok &= ~((self.d2 * e > 1) | (self.d2 * e < 0) | np.isnan(e))
+        return float(np.sum(np.where(ok, -self.d1 * e, 0.0)))
+
+    def derivatives(self, src, p6, h_t=1e-4, h_r=1e-5):
+        """(score, gradient, Hessian) at p6 by central differences with the neighbourhood assignment held fixed."""
+        p6 = np.asarray(p6, dtype=np.float64)
+        a = self.assign(src, p6)
+        h = np.array([h_t] * 3 + [h_r] * 3)
+        f0 = self.score(src, p6, a)
+        g = np.zeros(6)
+        H = np.zeros((6, 6))
+        fp, fm = np.zeros(6), np.zeros(6)
+        for i in range(6):
+            e = np.zeros(6)
+            e[i] = h[i]
+            fp[i], fm[i] = self.score(src, p6 + e, a), self.score(src, p6 - e, a)
+            g[i] = (fp[i] - fm[i]) / (2 * h[i])
+            H[i, i] = (fp[i] - 2 * f0 + fm[i]) / h[i] ** 2
+        for i in range(6):
+            for j in range(i + 1, 6):
+                ei, ej = np.zeros(6), np.zeros(6)
+                ei[i], ej[j] = h[i], h[j]
+                v = (self.score(src, p6 + ei + ej, a) - self.score(src, p6 + ei - ej, a) - self.score(src, p6 - ei + ej, a)
+                     + self.score(src, p6 - ei - ej, a)) / (4 * h[i] * h[j])
+                H[i, j] = H[j, i] = v
+        return f0, g, H
+
+    def align(self, src, p0, step_size=0.1, transformation_epsilon=0.01, max_iterations=64):
+        """Newton iterations as NDT's computeTransformation specifies them: direction = solve(H, -g),
+        normalised, reversed when it does not increase the score, step length = the Newton step clamped to
+        [transformation_epsilon / 2, step_size] (the line search of the ndt_omp lineage never iterates — row N4, legacy
+        variant); converged when the step falls below transformation_epsilon.  Returns (p6, iterations, converged)."""
+        p = np.asarray(p0, dtype=np.float64).copy()
+        it = 0
+        while True:
+            _, g, H = self.derivatives(src, p)
+            U, s, Vt = np.linalg.svd(H)
+            keep = s > s.max() * 6 * np.finfo(float).eps
+            d = -(Vt.T[:, keep] @ ((U[:, keep].T @ g) / s[keep]))
+            nd = float(np.linalg.norm(d))
+            if nd == 0 or np.isnan(nd):
+                return p, it, not np.isnan(nd)
+            d /= nd
+            if g @ d < 0:  # not an ascent direction of the score: reverse (d_phi_0 >= 0 branch of computeStepLengthMT)
+                d = -d
+            step = min(max(nd, transformation_epsilon / 2), step_size)
+            p = p + step * d
+            if it > max_iterations or (it > 0 and step < transformation_epsilon):
+                return p, it + 1, True
+            it += 1
