@@ -9,7 +9,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 if [ $NOTEST = 0 ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q "$@" > "$O/pytest.txt" 2>&1; echo "pytest exit $?" >> "$O/pytest.txt"
+  timeout 600 python -m pytest tests -m gpu -x -q --timeout 150 --timeout-method thread "$@" > "$O/pytest.txt" 2>&1; echo "pytest exit $?" >> "$O/pytest.txt"
   tail -12 "$O/pytest.txt"
 fi
 MI355_KNN_STATS=1 timeout 300 python bench.py --no-cpu-baseline --steps 1 --warmup 0 --pairs 128 2>&1 | grep "k-NN tiles" | head -4

@@ -133,9 +133,10 @@ __global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pt
 }
 
 // Occupied cells over all levels of a cloud = entries the hash will hold: one per run of equal (key >> 3l) in the sorted keys.
-// The table is then sized to the entries (load factor 0.25 - 0.5), not to the worst case of 5 entries per point: a 16 k-point
-// cloud has ~6 k occupied cells — a 256 KB table that stays in the XCD's L2 while the cloud is searched, instead of 4 MB
-// (the clears alone moved 3.2 GB per 1 024-cloud launch).
+// The table is then sized to the entries (load factor 0.125 - 0.25: the tile searches probe mostly EMPTY cells, and an
+// unsuccessful probe walks to the end of its cluster — 6.6 dependent loads per 64-cell lookup at load factor 0.5), not to the
+// worst case of 5 entries per point: a 16 k-point cloud has ~6 k occupied cells — a 0.5 MB table that stays in the XCD's L2
+// while the cloud is searched, instead of 4 MB (the clears alone moved 3.2 GB per 1 024-cloud launch).
 __global__ __launch_bounds__(256) void k_count_cells(const uint32_t* __restrict__ keys, GridMeta* __restrict__ meta, size_t cap) {
   const int c = blockIdx.y;
   const int n = meta[c].n, top = meta[c].top_level;
@@ -155,7 +156,7 @@ __global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t sl
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= B) return;
   uint32_t slots = 16, lg = 4;
-  while (slots < 2u * (uint32_t)max(meta[c].n_cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  while (slots < 4u * (uint32_t)max(meta[c].n_cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
   meta[c].hshift = 32 - lg;
   meta[c].hmask = slots - 1;
 }
@@ -684,33 +685,51 @@ __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts,
     for (;;) {
       // candidates: the cells of the box q +- r, or the whole cloud once the box outgrows 64 top-level cells
       const TileCells cells = tile_cells(g, grow(qb, r), 0x7fffffff);
-      const bool whole = !cells.ok;
-      if (!whole && cells.total < k && cells.total < n) { r *= 2.f; continue; }
+      const bool whole = !cells.ok || cells.total >= n;  // (a cloud smaller than k is scanned whole and yields what it has)
+      if (!whole && cells.total < k) { r *= 2.f; continue; }
       const unsigned long long cellmask = __ballot(cells.ce > cells.cs);
-      // visit(j, d2) for every candidate of this lane's share
-      auto scan = [&](auto&& visit) {
-        if (whole) {
-          for (int j = lane; j < n; j += kWave) {
-            const float4 p = g.pts[j];
-            visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+      // Walk the candidates 64 at a time in lock step, kGatherDepth chunk loads in flight (the chunk loads do not depend on
+      // each other; one load per cell at a time made a query take ~70 us): body(sorted index, point, is a candidate).
+      auto walk = [&](auto&& body) {
+        unsigned long long todo = whole ? 0ull : cellmask;
+        int j = whole ? -kWave : 0, e = whole ? n : 0;
+        auto advance = [&]() -> bool {
+          j += kWave;
+          if (j < e) return true;
+          if (!todo) return false;
+          const int cl = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          j = __builtin_amdgcn_readlane(cells.cs, cl);
+          e = __builtin_amdgcn_readlane(cells.ce, cl);
+          return true;
+        };
+        for (;;) {
+          int jb[kGatherDepth];
+          bool have[kGatherDepth], in[kGatherDepth];
+          float4 p[kGatherDepth];
+#pragma unroll
+          for (int u = 0; u < kGatherDepth; u++) {
+            have[u] = advance();
+            jb[u] = j;
+            in[u] = have[u] && j + lane < e;
+            p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[u]) p[u] = g.pts[j + lane];
           }
-        } else {
-          unsigned long long todo = cellmask;
-          while (todo) {
-            const int cl = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int s0 = __builtin_amdgcn_readlane(cells.cs, cl), e0 = __builtin_amdgcn_readlane(cells.ce, cl);
-            for (int j = s0 + lane; j < e0; j += kWave) {
-              const float4 p = g.pts[j];
-              visit(j, dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
-            }
+          if (!have[0]) break;
+#pragma unroll
+          for (int u = 0; u < kGatherDepth; u++) {
+            if (!have[u]) break;
+            body(jb[u] + lane, p[u], in[u]);
           }
+          if (!have[kGatherDepth - 1]) break;
         }
       };
       // ---- A: per-lane network of distances (positive floats order like unsigned integers)
       SmallestKeys<K + 1> nk;
       nk.init();
-      scan([&](int, float d2) { nk.insert(__float_as_uint(d2)); });
+      walk([&](int, const float4& p, bool in) {
+        nk.insert(in ? __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z)) : SmallestKeys<K + 1>::kEmpty);
+      });
 #pragma unroll
       for (int u = 0; u < K + 1; u++) col[u][lane] = nk.v[u];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -749,41 +768,22 @@ __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts,
       const int want_eq = enough ? (k - n_lt) : n_eq;
       int n_out = 0, n_tie = 0;
       mine = -1;
-      // the collection needs wave-wide ballots per step, so it walks the candidates in lock step instead of through scan()
-      {
-        auto step = [&](int j, bool in_range) {
-          float d2 = INFINITY;
-          if (in_range) {
-            const float4 p = g.pts[j];
-            d2 = dist2f(q.x, q.y, q.z, p.x, p.y, p.z);
-          }
-          const uint32_t key = __float_as_uint(d2);
-          const bool lt = in_range && key < tau, eq = in_range && key == tau;
-          const unsigned long long ml = __ballot(lt), me = __ballot(eq);
-          if (ml) {  // output slots n_out ... in candidate order
-            if (lt) out_j[n_out + __popcll(ml & below)] = j;  // n_lt < k <= 64 slots in all
-            n_out += __popcll(ml);
-          }
-          if (me) {
-            if (eq) {
-              const int at = n_tie + __popcll(me & below);
-              if (at < kWave) tie_j[at] = j;
-            }
-            n_tie += __popcll(me);
-          }
-        };
-        if (whole) {
-          for (int j0 = 0; j0 < n; j0 += kWave) step(j0 + lane, j0 + lane < n);
-        } else {
-          unsigned long long todo = cellmask;
-          while (todo) {
-            const int cl = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int s0 = __builtin_amdgcn_readlane(cells.cs, cl), e0 = __builtin_amdgcn_readlane(cells.ce, cl);
-            for (int j0 = s0; j0 < e0; j0 += kWave) step(j0 + lane, j0 + lane < e0);
-          }
+      walk([&](int j, const float4& p, bool in) {
+        const uint32_t key = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+        const bool lt = in && key < tau, eq = in && key == tau;
+        const unsigned long long ml = __ballot(lt), me = __ballot(eq);
+        if (ml) {  // output slots n_out ... in candidate order
+          if (lt) out_j[n_out + __popcll(ml & below)] = j;  // n_lt < k <= 64 slots in all
+          n_out += __popcll(ml);
         }
-      }
+        if (me) {
+          if (eq) {
+            const int at = n_tie + __popcll(me & below);
+            if (at < kWave) tie_j[at] = j;
+          }
+          n_tie += __popcll(me);
+        }
+      });
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       // ties at tau: the want_eq lowest caller indices (n_tie == n_eq; more than 64 candidates at one distance do not occur
       // in point clouds — the list is cut there)
