@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")
     ap.add_argument("--inflight", type=int, default=1, help="batch objects in flight, each on its own HIP stream (double buffering)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="A/B aid: no HIP events around the kernels (the JSON line then has no roofline block)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--host-inputs", action="store_true", help="hand HOST buffers to the C-ABI every step (PCIe-inclusive rate; never the headline value)")
     args = ap.parse_args()
@@ -145,7 +146,7 @@ def main():
     # latency-bound LM iterations the next one is prefiltered and indexed.  Every step still processes one full batch.
     batches = [BatchRegistration(P, P, cap, ctx=ctx, **params) for _ in range(max(1, args.inflight))]
     for b_ in batches:
-        b_.set_timing(True)
+        b_.set_timing(not args.no_kernel_timing)
     streams = []
     if len(batches) > 1:
         streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in batches]  # LM iterations ahead of the (low-priority) indexing chains
@@ -260,6 +261,9 @@ def main():
         by_kernel[name] = e
     dom = next((k for k in by_kernel if k in ALG_BYTES), None)
     if dom is None:
+        if args.no_kernel_timing:
+            print(json.dumps({"value": round(value, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 3), "note": "A/B run without kernel timing"}))
+            return
         raise SystemExit("bench.py: the library reported no kernel timings")
     d = by_kernel[dom]
     roofline = {

@@ -419,8 +419,9 @@ __device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int&
 template <int K>
 __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
-                                                     Cov6* __restrict__ cov, int* __restrict__ queue, int* __restrict__ queue_n,
-                                                     int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k, int method, int G, int B, float r_scale) {
+                                                     Cov6* __restrict__ cov, int* __restrict__ queue, float* __restrict__ queue_hint,
+                                                     int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k,
+                                                     int method, int G, int B, float r_scale) {
   __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
   __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
   int c, bx;
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   const bool valid = i < n;
   const float rcap = 16.f * g.m.cell, rmin = 0.6f * g.m.cell;
   bool fb = false;  // this lane goes to the fallback queue
+  float hint = 0.f;  // ... with a radius that is known to hold its k nearest neighbours (0: not known)
   int seg = 0, len = kWave;
   while (seg < kWave) {
     const bool act = valid && lane >= seg && lane < seg + len;
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         const uint32_t kk = keys.at(k - 1);
         const bool full = kk != SmallestKeys<K + 2>::kEmpty;
         const float ub = __uint_as_float(kk | kOrdMask);  // >= the exact k-th squared distance
+        if (act && full) hint = sqrtf(ub) * 1.001f + 2.f * eps;
         open = act && !fb && !(full && ub <= rsafe * rsafe);
         const unsigned long long om = __ballot(open);
         if (!om) break;
@@ -631,7 +634,10 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
     int base = 0;
     if (lane == 0) base = atomicAdd(&queue_n[c], __popcll(fm));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (fb) queue[(size_t)c * cap + base + __popcll(fm & below)] = i;
+    if (fb) {
+      queue[(size_t)c * cap + base + __popcll(fm & below)] = i;
+      queue_hint[(size_t)c * cap + base + __popcll(fm & below)] = hint;
+    }
   }
   }  // next tile
 }
@@ -651,7 +657,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
 template <int K>
 __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
                                                  const GridMeta* __restrict__ meta, Cov6* __restrict__ cov, const int* __restrict__ queue,
-                                                 const int* __restrict__ queue_n, size_t cap, size_t slots_cap, int k, int method, int G, int B) {
+                                                 const float* __restrict__ queue_hint, const int* __restrict__ queue_n, size_t cap, size_t slots_cap,
+                                                 int k, int method, int G, int B) {
   __shared__ uint32_t col[K + 1][kWave];  // per-lane sorted distance lists (column = lane)
   __shared__ double raw[kWave][6];        // raw covariances awaiting regularisation
   __shared__ int raw_i[kWave];
@@ -680,7 +687,9 @@ __global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts,
     const float4 q = g.pts[i];
     const TileBox qb{q.x, q.y, q.z, q.x, q.y, q.z};
     const float eps = tile_eps(qb, 0.f);
-    float r = 2.f * g.m.cell;
+    // the tile kernel's upper bound of the k-th distance, when it got that far: one round then covers the neighbourhood
+    const float hint = queue_hint[(size_t)c * cap + t];
+    float r = (hint > 0.f) ? hint : 2.f * g.m.cell;
     int mine = -1;  // lane u < k ends up holding the u-th neighbour (sorted index); fewer than k points in the cloud: -1
     for (;;) {
       // candidates: the cells of the box q +- r, or the whole cloud once the box outgrows 64 top-level cells
@@ -858,6 +867,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
     return;
   }
   set.fbq.ensure((size_t)set.B * set.cap);
+  set.fbhint.ensure((size_t)set.B * set.cap);
   set.fbn.ensure((size_t)2 * set.B);  // [0, B) fallback queue lengths, [B, 2B) tile counters
   MI_HIP(hipMemsetAsync(set.fbn.p, 0, sizeof(int) * 2 * set.B, s));
   // about two resident waves per SIMD over the whole batch, at least 8 and at most one wave per tile of a cloud
@@ -865,13 +875,13 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
   {
     TimedLaunch tl(KF_KNN_COV_TILE, s);
     hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                       set.fbq.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
+                       set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
   }
   // the points the tile kernel handed over: one wave per point, covariance included
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
   TimedLaunch tl(KF_KNN_HARD, s);
   hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                     (const int*)set.fbq.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, method, Gh, set.B);
+                     (const int*)set.fbq.p, (const float*)set.fbhint.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, method, Gh, set.B);
   if (tn.knn_stats) {  // tuning aid: how much of the work the tile kernel handed over
     std::vector<int> fbn(set.B), cnt(set.B);
     MI_HIP(hipStreamSynchronize(s));
@@ -887,7 +897,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k_correspondences must be in [1, 64]");
   set.cov.ensure((size_t)set.B * set.cap);
-  set.nbr.ensure((size_t)set.B * set.cap * k);
+  if (!tuning().knn_tiles) set.nbr.ensure((size_t)set.B * set.cap * k);  // neighbour lists exist only on the per-lane path
   if (k == 20) launch_covariances<20>(s, set, k, method);
   else if (k <= 8) launch_covariances<8>(s, set, k, method);
   else if (k <= 16) launch_covariances<16>(s, set, k, method);

@@ -61,7 +61,8 @@ struct CloudSet {
   DevBuf<int> count;
   DevBuf<Cov6> cov;   // [B*cap] regularised neighbourhood covariances
   DevBuf<int> nbr;  // [B*cap*k] k-NN lists (sorted indices) between the search and the covariance kernels
-  DevBuf<int> fbq, fbn;  // [B*cap] / [B] points the tile k-NN hands over to the per-lane search
+  DevBuf<int> fbq, fbn;  // [B*cap] / [2B] points the tile k-NN hands over to k_knn_hard, their number per cloud (+ the tile counters)
+  DevBuf<float> fbhint;  // [B*cap] radius known to hold the k nearest neighbours of a handed-over point (0: unknown)
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false;

@@ -119,13 +119,231 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const uint32_t* __r
   }
 }
 
+// ---- in-LDS tile sort + merges: the path for batch-sized segments ------------------------------------------------------
+// The global LSD sort above moves every (key, index) pair through HBM once per pass with scattered 4-byte writes (each wave
+// spreads its 64 elements over up to 64 digit buckets) and needs 3 launches per pass; at 1 024 clouds x 64 k points it ran
+// at 6 % of the HBM roofline (the k_sort_scan launches alone: 0.9 ms each, latency-bound).  Here a 1 024-thread block keeps a
+// TILE of up to 24 576 elements in registers and LDS for ALL passes: per pass every wave ranks its 1 536 consecutive elements
+// with wave ballots (as k_sort_scatter does), the 16 x 256 counters are scanned once, and the elements are permuted through
+// LDS.  HBM sees one coalesced read and one coalesced write.  A voxelised scan (~16 k points) is one tile = one launch; a raw
+// 64 k-point scan is 3 tiles followed by two rounds of pairwise merge-path merges.  Values are the element's index in its
+// segment (all callers sort (key, i) pairs), so a tile carries 16-bit local indices only.
+constexpr int kTsWaves = 16, kTsThreads = kTsWaves * kWave, kTsE = 24;
+constexpr int kTsSpan = kWave * kTsE;               // 1 536 consecutive elements per wave
+constexpr int kTsTile = kTsSpan * kTsWaves;         // 24 576 elements per tile
+constexpr int kMergeChunk = 4096, kMergeThreads = 256, kMergeE = kMergeChunk / kMergeThreads;
+
+// tile geometry of a cloud of n elements: nt tiles of tl elements (the last one shorter)
+__device__ __forceinline__ void tile_geometry(int n, int& nt, int& tl) {
+  nt = max(1, (n + kTsTile - 1) / kTsTile);
+  tl = (((n + nt - 1) / nt) + kWave - 1) / kWave * kWave;
+}
+
+__global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
+                                                          const int* __restrict__ counts, size_t cap, int passes) {
+  __shared__ uint32_t keyL[kTsTile];
+  __shared__ uint16_t idxL[kTsTile];
+  __shared__ uint16_t cnt[kTsWaves][256];
+  __shared__ int wtot[kTsWaves];
+  const int c = blockIdx.y;
+  const int n = counts[c];
+  int nt, tl;
+  tile_geometry(n, nt, tl);
+  if ((int)blockIdx.x >= nt) return;
+  const int base = blockIdx.x * tl;
+  const int len = max(0, min(tl, n - base));
+  const int w = wave_id(), l = lane_id();
+  const size_t o = (size_t)c * cap + base;
+  uint32_t key[kTsE];
+  uint32_t il[kTsE];  // local index (high half) | rank inside the wave for the current pass (low half)
+  // element p of the tile lives in wave p / 1536, round (p % 1536) / 64, lane p % 64; padding sorts to the end (all-ones key,
+  // last in the stable order)
+#pragma unroll
+  for (int r = 0; r < kTsE; r++) {
+    const int p = w * kTsSpan + r * kWave + l;
+    key[r] = (p < len) ? keys_in[o + p] : 0xFFFFFFFFu;
+    il[r] = (uint32_t)p << 16;
+  }
+  const unsigned long long lt_mask = (1ull << l) - 1ull;
+  // (fully unrolled: carried through a rolled loop the two register arrays become 32-wide vector values that the compiler
+  // copies and spills wholesale — 4 KB of scratch per lane)
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++) {
+    if (pass >= passes) break;
+    const int shift = 8 * pass;
+    for (int d = l; d < 256; d += kWave) cnt[w][d] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // ---- rank inside the wave: elements of earlier rounds first, then lower lanes
+#pragma unroll
+    for (int r = 0; r < kTsE; r++) {
+      const uint32_t d = (key[r] >> shift) & 255u;
+      unsigned long long peers = ~0ull;
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const unsigned long long m = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? m : ~m;
+      }
+      const int rank = __popcll(peers & lt_mask);
+      const int before = cnt[w][d];
+      __builtin_amdgcn_wave_barrier();
+      if (rank == 0) cnt[w][d] = (uint16_t)(before + __popcll(peers));
+      __builtin_amdgcn_wave_barrier();
+      il[r] = (il[r] & 0xFFFF0000u) | (uint32_t)(before + rank);
+    }
+    __syncthreads();
+    // ---- exclusive scan of the 256 x 16 counters, digit-major: thread t owns digit t / 4, waves 4 (t % 4) .. + 3
+    {
+      static_assert(kTsWaves == 16, "counter scan mapping");
+      const int t = threadIdx.x, d = t >> 2, w0 = (t & 3) * 4;
+      const int c0 = cnt[w0][d], c1 = cnt[w0 + 1][d], c2 = cnt[w0 + 2][d], c3 = cnt[w0 + 3][d];
+      const int sum = c0 + c1 + c2 + c3;
+      int incl = sum;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int u = __shfl_up(incl, off, kWave);
+        if (l >= off) incl += u;
+      }
+      if (l == kWave - 1) wtot[w] = incl;
+      __syncthreads();
+      int wbase = 0;
+      for (int ww = 0; ww < w; ww++) wbase += wtot[ww];
+      const int ex = wbase + incl - sum;
+      cnt[w0][d] = (uint16_t)ex;
+      cnt[w0 + 1][d] = (uint16_t)(ex + c0);
+      cnt[w0 + 2][d] = (uint16_t)(ex + c0 + c1);
+      cnt[w0 + 3][d] = (uint16_t)(ex + c0 + c1 + c2);
+    }
+    __syncthreads();
+    // ---- permute through LDS
+#pragma unroll
+    for (int r = 0; r < kTsE; r++) {
+      const int dest = (int)cnt[w][(key[r] >> shift) & 255u] + (int)(il[r] & 0xFFFFu);
+      keyL[dest] = key[r];
+      idxL[dest] = (uint16_t)(il[r] >> 16);
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // 8 elements in flight, not 24: the registers are full of elements
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kTsE; r++) {
+      const int p = w * kTsSpan + r * kWave + l;
+      key[r] = keyL[p];
+      il[r] = (uint32_t)idxL[p] << 16;
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kTsE; r++) {
+    const int p = w * kTsSpan + r * kWave + l;
+    if (p < len) {
+      keys_out[o + p] = key[r];
+      vals_out[o + p] = base + (int)(il[r] >> 16);
+    }
+  }
+}
+
+// One round of pairwise merges of sorted runs of `run` tiles each (run = 1, 2, 4, ...): output chunk blockIdx.x of the cloud.
+// Stable: on equal keys the element of the lower run goes first.  A run without a partner is copied.
+__global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
+                                                              const int* __restrict__ counts, size_t cap, int run) {
+  __shared__ uint32_t sk[kMergeChunk + 1];
+  __shared__ int sv[kMergeChunk + 1];
+  __shared__ int split[4];
+  const int c = blockIdx.y;
+  const int n = counts[c];
+  const int o0 = blockIdx.x * kMergeChunk;
+  if (o0 >= n) return;
+  int nt, tl;
+  tile_geometry(n, nt, tl);
+  const size_t o = (size_t)c * cap;
+  const uint32_t* K = keys_in + o;
+  const int* V = vals_in + o;
+  const long L = (long)tl * run;  // elements per input run
+  // a chunk may straddle the boundary between two output runs (2 L elements each): handle the (at most two) pieces in turn
+  int pos = o0;
+  const int end = min(o0 + kMergeChunk, n);
+  while (pos < end) {
+    const long pair = pos / (2 * L);
+    const int a0 = (int)min((long)n, pair * 2 * L), b0 = (int)min((long)n, a0 + L), b1 = (int)min((long)n, a0 + 2 * L);
+    const int la = b0 - a0, lb = b1 - b0;
+    const int d0 = pos - a0, d1 = min(end, b1) - a0;  // diagonals of this piece inside the merged pair
+    // merge-path split of diagonal d: number of A elements among the first d outputs
+    auto path = [&](int d) {
+      int lo = max(0, d - lb), hi = min(d, la);
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (K[a0 + mid] <= K[b0 + d - 1 - mid]) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    if (threadIdx.x == 0) { const int i0 = path(d0); split[0] = i0; split[1] = d0 - i0; }
+    if (threadIdx.x == 64) { const int i1 = path(d1); split[2] = i1; split[3] = d1 - i1; }
+    __syncthreads();
+    const int i0 = split[0], j0 = split[1], na = split[2] - i0, nb = split[3] - j0;
+    // stage A[i0, i0 + na) then B[j0, j0 + nb)
+    for (int t = threadIdx.x; t < na + nb; t += kMergeThreads) {
+      const int src = (t < na) ? (a0 + i0 + t) : (b0 + j0 + (t - na));
+      sk[t] = K[src];
+      sv[t] = V[src];
+    }
+    __syncthreads();
+    // every thread merges kMergeE consecutive outputs of the piece
+    const int total = na + nb;
+    const int q0 = min(total, (int)threadIdx.x * kMergeE), q1 = min(total, q0 + kMergeE);
+    if (q0 < q1) {
+      int lo = max(0, q0 - nb), hi = min(q0, na);
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sk[mid] <= sk[na + q0 - 1 - mid]) lo = mid + 1; else hi = mid;
+      }
+      int ia = lo, ib = q0 - lo;
+      for (int q = q0; q < q1; q++) {
+        const bool take_a = (ib >= nb) || (ia < na && sk[ia] <= sk[na + ib]);
+        const int src = take_a ? ia : na + ib;
+        keys_out[o + a0 + d0 + q] = sk[src];
+        vals_out[o + a0 + d0 + q] = sv[src];
+        ia += take_a ? 1 : 0;
+        ib += take_a ? 0 : 1;
+      }
+    }
+    __syncthreads();
+    pos = a0 + d1;
+  }
+}
+
+// Sorts B segments of (key, index-in-segment) pairs by the low 8 * passes key bits, stably; the result ends up in
+// (keys_a, vals_a) of the workspace.  vals_a on input must be the identity (vals[i] = i) — every caller's is.
 void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes) {
+  TimedLaunch tl(KF_SORT, s);
+  const int max_tiles = div_up((long)cap, kTsTile);
+  if (max_tiles <= 4) {
+    // tile sort a -> b, then ceil(log2(max_tiles)) merge rounds ping-ponging; an odd number of hops ends in b: swap the handles
+    hipLaunchKernelGGL(k_sort_tile, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p, d_counts, cap, passes);
+    int hops = 1;
+    uint32_t* ki = ws.keys_b.p; uint32_t* ko = ws.keys_a.p;
+    int* vi = ws.vals_b.p; int* vo = ws.vals_a.p;
+    for (int run = 1; run < max_tiles; run *= 2) {
+      hipLaunchKernelGGL(k_sort_merge, dim3(div_up((long)cap, kMergeChunk), B), dim3(kMergeThreads), 0, s, ki, vi, ko, vo, d_counts, cap, run);
+      std::swap(ki, ko);
+      std::swap(vi, vo);
+      hops++;
+    }
+    MI_LAUNCH_CHECK();
+    if (hops & 1) {
+      std::swap(ws.keys_a.p, ws.keys_b.p);
+      std::swap(ws.keys_a.n, ws.keys_b.n);
+      std::swap(ws.vals_a.p, ws.vals_b.p);
+      std::swap(ws.vals_a.n, ws.vals_b.n);
+    }
+    return;
+  }
+  // large segments (sub-maps of 10^5 - 10^6 points): global LSD passes
   const int nsub = div_up((long)cap, kSubTile);
   ws.hist.ensure((size_t)B * 256 * nsub);
   const dim3 grid(div_up((long)cap, kBlockTile), B);
   uint32_t* ka = ws.keys_a.p; uint32_t* kb = ws.keys_b.p;
   int* va = ws.vals_a.p; int* vb = ws.vals_b.p;
-  TimedLaunch tl(KF_SORT, s);
   for (int p = 0; p < passes; p++) {
     const int shift = 8 * p;
     hipLaunchKernelGGL(k_sort_hist, grid, dim3(kSortBlock), 0, s, ka, d_counts, ws.hist.p, cap, nsub, shift);
