@@ -73,7 +73,8 @@ typedef struct mi355_ndt_params {
   double outlier_ratio;          /* PCL default 0.55 */
   int min_points_per_voxel;      /* 6 */
   double min_covar_eigvalue_mult;/* 0.01 */
-  int legacy_mt_skip;            /* see oracle/oracle.h */
+  int legacy_mt_skip;            /* 1 (default): the More-Thuente loop never iterates, as in ndt_omp / PCL 1.8
+                                    (`interval_converged = (step_max - step_min) > 0`); 0: PCL >= 1.10's line search */
   int num_threads;               /* unused on the GPU */
 } mi355_ndt_params;
 

@@ -176,7 +176,11 @@ extern "C" void mi355_ndt_default_params(mi355_ndt_params* p) {
   p->outlier_ratio = 0.55;
   p->min_points_per_voxel = 6;
   p->min_covar_eigvalue_mult = 0.01;
-  p->legacy_mt_skip = 0;
+  // ndt_omp (the engine the reference links: thirdparty/ndt_omp, koide3 lineage = PCL 1.8's NDT) evaluates
+  // `interval_converged = (step_max - step_min) > 0`: the More-Thuente loop never iterates and the step length is the Newton
+  // step clamped to [transformation_epsilon / 2, step_size].  That engine is what MI355_METHOD_NDT_OMP stands for, so it is the
+  // default; 0 selects the `< 0` test of PCL >= 1.10 (the line search iterates).
+  p->legacy_mt_skip = 1;
   p->num_threads = 0;
 }
 extern "C" void mi355_prefilter_default_params(mi355_prefilter_params* p) {

@@ -65,9 +65,10 @@ typedef struct orc_ndt_params {
   double outlier_ratio;          /* PCL default 0.55 */
   int min_points_per_voxel;      /* VoxelGridCovariance default 6 */
   double min_covar_eigvalue_mult;/* VoxelGridCovariance default 0.01 */
-  int legacy_mt_skip;            /* 1 = restate the `interval_converged = (step_max-step_min) > 0` variant found in
-                                    older PCL / some ndt_omp trees (line search never iterates); 0 = More-Thuente as in
-                                    SURVEY.md row N4 */
+  int legacy_mt_skip;            /* 1 (default) = `interval_converged = (step_max-step_min) > 0` as in PCL 1.8 and the
+                                    ndt_omp trees forked from it (the reference links thirdparty/ndt_omp): the line search
+                                    never iterates, step = clamp(|dp|, eps/2, step_size); 0 = the `< 0` test of PCL >= 1.10:
+                                    More-Thuente as in SURVEY.md row N4 */
   int num_threads;               /* lidar_scan_matcher.cpp:70 */
 } orc_ndt_params;
 

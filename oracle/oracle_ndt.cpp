@@ -30,7 +30,7 @@ extern "C" void orc_ndt_default_params(orc_ndt_params* p) {
   p->outlier_ratio = 0.55;
   p->min_points_per_voxel = 6;
   p->min_covar_eigvalue_mult = 0.01;
-  p->legacy_mt_skip = 0;
+  p->legacy_mt_skip = 1;  /* the ndt_omp lineage (PCL 1.8): see oracle.h */
   p->num_threads = 0;
 }
 

@@ -61,8 +61,10 @@ def main():
     p6 = np.array([0.8, 0.05, 0.01, 0.004, -0.003, 0.03])
     sc, g, Hn = O.ndt_derivatives(v, tv, p6, O.ndt_params(resolution=2.0))
     out.update(ndt_p6=p6, ndt_score=sc, ndt_grad=g, ndt_hess=Hn)
-    rn = O.ndt_align(v, tv, O.ndt_params(resolution=2.0))
+    rn = O.ndt_align(v, tv, O.ndt_params(resolution=2.0))  # the ndt_omp default: the line search never iterates
     out.update(ndt_T=rn["T"], ndt_iterations=rn["iterations"])
+    rm = O.ndt_align(v, tv, O.ndt_params(resolution=2.0, legacy_mt_skip=0))  # PCL >= 1.10: More-Thuente iterates
+    out.update(ndt_T_mt=rm["T"], ndt_iterations_mt=rm["iterations"])
     path = os.path.join(ROOT, "tests", "golden", "golden_small.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; src", v.shape, "tgt", tv.shape, "gicp err vs truth", synth.pose_error(r["T"], T_gt))

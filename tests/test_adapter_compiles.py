@@ -1,0 +1,53 @@
+"""Compile-only check of the PCL-typed adapter (adapters/pcl_registration.hpp) against tests/pcl_stub — a STUB of the part of
+PCL's surface the adapter touches (PCL itself is absent from the build image).  Nothing is linked or run: the check is that the
+header parses, overrides what it claims to override, and that a node-shaped translation unit using it through
+pcl::Registration::Ptr type-checks."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+NODE_SHAPED_TU = r"""
+#include "pcl_registration.hpp"
+using PointType = pcl::PointXYZI;
+// the shape of lidar_scan_matcher.cpp:37-72,149,162-172 and graph_based_slam.cpp:315-322
+double use(pcl::PointCloud<PointType>::Ptr target, pcl::PointCloud<PointType>::Ptr source) {
+  pcl::Registration<PointType, PointType>::Ptr registration_;
+  {
+    mi355_pcl::FastGICP::Ptr gicp(new mi355_pcl::FastGICP());
+    gicp->setCorrespondenceRandomness(20);
+    gicp->setMaximumIterations(64);
+    gicp->setTransformationEpsilon(0.01);
+    gicp->setMaxCorrespondenceDistance(2.0);
+    gicp->setNumThreads(4);
+    registration_ = gicp;
+  }
+  {
+    mi355_pcl::NormalDistributionsTransform::Ptr ndt(new mi355_pcl::NormalDistributionsTransform());
+    ndt->setTransformationEpsilon(0.01);
+    ndt->setStepSize(0.1);
+    ndt->setResolution(2.0f);
+    ndt->setMaximumIterations(64);
+    ndt->setNeighborhoodSearchMethod(0);
+    ndt->setNumThreads(4);
+    (void)ndt->getTransformationProbability();
+  }
+  registration_->setInputTarget(target);
+  registration_->setInputSource(source);
+  pcl::PointCloud<PointType> out;
+  registration_->align(out, Eigen::Matrix<float, 4, 4>::Identity());
+  if (!registration_->hasConverged()) return -1.0;
+  (void)registration_->getFinalTransformation();
+  return mi355_pcl::getFitnessScore(registration_);  // the device statistic through the base pointer
+}
+"""
+
+
+def test_adapter_type_checks_against_the_pcl_stub(tmp_path):
+    tu = tmp_path / "node_shaped.cpp"
+    tu.write_text(NODE_SHAPED_TU)
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
+           "-I", os.path.join(ROOT, "tests", "pcl_stub"), "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "lidar_graph_slam_amd", "adapters"), str(tu)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

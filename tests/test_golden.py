@@ -74,6 +74,12 @@ def test_hip_path_reproduces_golden(golden):
     sc, g, Hn = ndt.derivatives(G["ndt_p6"])
     np.testing.assert_allclose(sc, G["ndt_score"], rtol=1e-4)
     np.testing.assert_allclose(g, G["ndt_grad"], rtol=1e-3, atol=1e-3 * np.abs(G["ndt_grad"]).max())
-    ndt.align()
+    ndt.align()  # default: ndt_omp's line search (never iterates)
     dt, dr = synth.pose_error(ndt.getFinalTransformation(), G["ndt_T"])
+    assert dt <= 0.01 and dr <= 2e-3, (dt, dr)
+    ndt_mt = R.NormalDistributionsTransform(resolution=2.0, legacy_mt_skip=0)  # PCL >= 1.10: More-Thuente iterates
+    ndt_mt.setInputTarget(G["tgt_voxel"])
+    ndt_mt.setInputSource(G["voxel"])
+    ndt_mt.align()
+    dt, dr = synth.pose_error(ndt_mt.getFinalTransformation(), G["ndt_T_mt"])
     assert dt <= 0.01 and dr <= 2e-3, (dt, dr)
