@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 as a runnable multi-GPU program: a global list of loop-closure candidates against sub-maps, sharded over
+the ranks of a torch.distributed job (one process per GPU), registered with one BatchRegistration sequence per rank, results
+all-gathered over RCCL, every pair verified against its ground truth on rank 0.
+
+    python benchmarks/config5.py --candidates 512 --submaps 8                         (one GPU: the per-GPU share)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
+        benchmarks/config5.py --gpus 8 --candidates 4096 --submaps 64                 (the full config)
+
+Synthetic data (no network, the reference ships none): sub-map s = 5 key-frame scans around x = 20 s on the street scene,
+transformed to the map frame; a candidate = a scan cast at the true pose P, placed at a wrong graph pose G (what the pose graph
+believes before the loop is closed); aligning it to the sub-map must return P G^-1.  Every rank casts only what it owns."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--candidates", type=int, default=512, help="global number of candidates (4096 in BASELINE config 5)")
+    ap.add_argument("--submaps", type=int, default=8, help="global number of sub-maps (64 in BASELINE config 5)")
+    ap.add_argument("--casts-per-submap", type=int, default=8, help="distinct candidate scans per sub-map; the rest are other wrong placements of those")
+    ap.add_argument("--n-azimuth", type=int, default=1024, help="1024 = 65 536 rays per scan")
+    ap.add_argument("--capacity", type=int, default=65536)
+    ap.add_argument("--max-iterations", type=int, default=64)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N benchmarks/config5.py --gpus N ...")
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))  # BENCH_DEVICE / BENCH_BACKEND: several ranks on ONE GPU (tests)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend == "nccl" or world == 1:
+        if not torch.cuda.is_available():
+            raise SystemExit("config5.py needs an MI355X: there is no CPU fallback for the product path")
+        torch.cuda.set_device(dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+
+    from lidar_graph_slam_amd import loop_batch, synth
+    from lidar_graph_slam_amd.context import Context
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+
+    ctx = Context(dev_index)
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0, ctx=ctx)
+    scene = synth.street(20.0 * args.submaps + 20.0)
+
+    # ---- the GLOBAL list: metadata only (every rank builds the same one) ------------------------------------------
+    n, S = args.candidates, args.submaps
+    rng = np.random.default_rng(5)
+    tgt_of_src = np.arange(n) % S
+    cast_of = (np.arange(n) // S) % args.casts_per_submap          # which of the sub-map's candidate scans
+    true_off = [synth.random_perturbation(np.random.default_rng(1000 + s * 64 + c), 1.0, 2.0) for s in range(S) for c in range(args.casts_per_submap)]
+    wrong = [synth.random_perturbation(rng, 1.5, 4.0) for _ in range(n)]  # the graph's error of candidate p (<= 2 m / 5 deg in all)
+
+    def submap_pose(s):
+        return synth.se3(20.0 * s, 0.0, 0.0)
+
+    def true_pose(p):
+        s = int(tgt_of_src[p])
+        return submap_pose(s) @ true_off[s * args.casts_per_submap + int(cast_of[p])]
+
+    def graph_pose(p):  # where the (drifted) pose graph believes the candidate is
+        return true_pose(p) @ wrong[p]
+
+    cache = {}
+
+    def scan_at(s, c):  # prefiltered scan (what points_prefiltering publishes), sensor frame
+        if (s, c) not in cache:
+            P = submap_pose(s) @ true_off[s * args.casts_per_submap + c]
+            cache[(s, c)] = pre.callback_sensor_points(synth.cast_scan(scene, P, n_azimuth=args.n_azimuth, seed=9000 + s * 64 + c, ground_max_range=30.0))
+        return cache[(s, c)]
+
+    def place(cloud, T):
+        o = cloud.copy()
+        o[:, :3] = (cloud[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        return o
+
+    def load_source(p):  # the candidate key frame at its graph pose (graph_based_slam.cpp:297-309 transforms with the graph's poses)
+        return place(scan_at(int(tgt_of_src[p]), int(cast_of[p])), graph_pose(p))
+
+    def load_target(s):  # +-2 key frames around the sub-map pose, in the map frame (voxel 0.5 m happens on the device)
+        parts = []
+        for j in range(-2, 3):
+            P = submap_pose(s) @ synth.se3(1.0 * j, 0.0, 0.0)
+            c = pre.callback_sensor_points(synth.cast_scan(scene, P, n_azimuth=args.n_azimuth, seed=500 + 10 * s + j, ground_max_range=30.0))
+            parts.append(place(c, P))
+        return np.concatenate(parts, axis=0)
+
+    cap = max(args.capacity, 5 * 20000 if args.n_azimuth >= 1024 else 0)
+    t0 = time.perf_counter()
+    out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, cap, rank=rank, world=world, ctx=ctx,
+                                      target_prefilter=loop_batch.voxel_prefilter(0.5), max_iterations=args.max_iterations)
+    t_total = time.perf_counter() - t0
+    if rank == 0:
+        from lidar_graph_slam_amd import synth as S_
+        errs = np.array([S_.pose_error(out["T"][p], true_pose(p) @ np.linalg.inv(graph_pose(p))) for p in range(n)])
+        accepted = out["converged"] & (out["fitness"] < 0.3)  # graph_based_slam.cpp:321-328
+        good = (errs[:, 0] < 0.05) & (errs[:, 1] < 5e-3)
+        line = {
+            "config": "BASELINE configs[4]: loop-closure batch, candidates sharded by sub-map over the ranks, results all-gathered",
+            "n_gpus": world, "backend": backend if world > 1 else "single process", "collective_ranks": dist.get_world_size() if world > 1 else 1,
+            "candidates": n, "submaps": S, "all_reported": bool(out["reported"].all()),
+            "pairs_per_s_registration": round(n / max(out["seconds_register"], 1e-9), 1),
+            "seconds_register_max_over_ranks": round(out["seconds_register"], 3), "seconds_gather": round(out["seconds_gather"], 4),
+            "seconds_total_incl_synthesis": round(t_total, 1),
+            "accepted(fitness<0.3)": int(accepted.sum()), "within_5cm_of_truth": int(good.sum()),
+            "median_pose_err_m": round(float(np.median(errs[:, 0])), 4), "max_pose_err_m_of_accepted": round(float(errs[accepted, 0].max()), 4) if accepted.any() else None,
+            "mean_iterations": round(float(out["iterations"].mean()), 1),
+        }
+        print(json.dumps(line))
+        if not out["reported"].all() or good.sum() < 0.9 * n:
+            raise SystemExit("config5: results missing or wrong")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

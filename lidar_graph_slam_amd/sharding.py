@@ -37,45 +37,53 @@ def shard_by_target(tgt_of_src, world: int):
     return out
 
 
-def gather_results(local_idx, local_T, local_fitness, n_total: int, group=None):
-    """All-gather per-pair results: returns (T [n_total,4,4] float32, fitness [n_total] float64) on every rank.
-    local_idx: global pair indices this rank processed."""
+def gather_rows(local_idx, rows, n_total: int, group=None) -> np.ndarray:
+    """All-gather fixed-size per-pair records: `rows` is [n_local, C] float64 for the global pair indices `local_idx`; returns
+    [n_total, C] on every rank (NaN rows for pairs nobody reported).  Ragged shards are padded to the largest one — the payload
+    is tiny (<= 20 doubles per pair), so ONE all_gather over RCCL / xGMI is the whole exchange step of the path."""
     import torch
     import torch.distributed as dist
 
     local_idx = np.asarray(local_idx, dtype=np.int64)
+    rows = np.asarray(rows, dtype=np.float64).reshape(len(local_idx), -1)
+    C = rows.shape[1]
+    out = np.full((n_total, C), np.nan)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        T = np.zeros((n_total, 4, 4), dtype=np.float32)
-        f = np.full(n_total, np.nan)
-        T[local_idx] = local_T
-        f[local_idx] = local_fitness
-        return T, f
+        out[local_idx] = rows
+        return out
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    # ragged shards: pad to the largest shard (the payload is tiny: 18 doubles per pair)
-    n_local = torch.tensor([len(local_idx)], dtype=torch.int64, device=dev)
+    n_local = torch.tensor([len(local_idx), C], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
-    n_max = int(max(int(s.item()) for s in sizes))
-    payload = torch.zeros((n_max, 18), dtype=torch.float64, device=dev)
+    n_max = int(max(int(s[0].item()) for s in sizes))
+    C_all = int(max(int(s[1].item()) for s in sizes))  # a rank without pairs does not know C
+    payload = torch.zeros((n_max, C_all + 1), dtype=torch.float64, device=dev)
     if len(local_idx):
         payload[: len(local_idx), 0] = torch.from_numpy(local_idx.astype(np.float64)).to(dev)
-        payload[: len(local_idx), 1:17] = torch.from_numpy(np.asarray(local_T, dtype=np.float64).reshape(-1, 16)).to(dev)
-        payload[: len(local_idx), 17] = torch.from_numpy(np.asarray(local_fitness, dtype=np.float64)).to(dev)
+        payload[: len(local_idx), 1 : C + 1] = torch.from_numpy(rows).to(dev)
     parts = [torch.zeros_like(payload) for _ in range(world)]
     dist.all_gather(parts, payload, group=group)
-    T = np.zeros((n_total, 4, 4), dtype=np.float32)
-    f = np.full(n_total, np.nan)
+    out = np.full((n_total, C_all), np.nan)
     for r in range(world):
-        k = int(sizes[r].item())
+        k = int(sizes[r][0].item())
         if k == 0:
             continue
         a = parts[r][:k].cpu().numpy()
-        idx = a[:, 0].astype(np.int64)
-        T[idx] = a[:, 1:17].reshape(-1, 4, 4).astype(np.float32)
-        f[idx] = a[:, 17]
-    return T, f
+        out[a[:, 0].astype(np.int64)] = a[:, 1:]
+    return out
+
+
+def gather_results(local_idx, local_T, local_fitness, n_total: int, group=None):
+    """All-gather per-pair results: returns (T [n_total,4,4] float32, fitness [n_total] float64) on every rank.
+    local_idx: global pair indices this rank processed."""
+    local_idx = np.asarray(local_idx, dtype=np.int64)
+    rows = np.concatenate([np.asarray(local_T, dtype=np.float64).reshape(len(local_idx), 16),
+                           np.asarray(local_fitness, dtype=np.float64).reshape(len(local_idx), 1)], axis=1)
+    g = gather_rows(local_idx, rows, n_total, group)
+    T = np.nan_to_num(g[:, :16], nan=0.0).reshape(n_total, 4, 4).astype(np.float32)
+    return T, g[:, 16]
 
 
 def max_over_ranks(value: float, group=None) -> float:

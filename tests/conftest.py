@@ -19,16 +19,24 @@ if os.path.join(ROOT, "tests") not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
-    # torch bundles its own ROCm runtime; once libmi355_lidar.so has pulled /opt/rocm's libamdhip64 into the process torch can no
-    # longer initialise its GPU context ("No HIP GPUs are available").  Tests that hand torch tensors to the C-ABI need both, so
-    # torch goes first (a no-op on the CPU-only container).  INTEGRATION.md states the same load order for callers.
-    try:
-        import torch
+    config.addinivalue_line("markers", "children_only: the test starts its GPU work in child processes; the pytest process itself stays off the GPU")
 
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:  # torch is plumbing for a few tests only
-        pass
+
+@pytest.fixture(autouse=True)
+def _torch_before_the_library(request):
+    """torch bundles its own ROCm runtime; once libmi355_lidar.so has pulled /opt/rocm's libamdhip64 into the process torch can
+    no longer initialise its GPU context ("No HIP GPUs are available").  Tests that hand torch tensors to the C-ABI need both,
+    so for every GPU test torch goes first — except the tests that only start child processes (they sort first, and the
+    parent has then not touched the GPU when it spawns them).  INTEGRATION.md states the same load order for callers."""
+    if request.node.get_closest_marker("gpu") and not request.node.get_closest_marker("children_only"):
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # torch is plumbing for a few tests only
+            pass
+    yield
 
 
 @pytest.fixture(scope="session")

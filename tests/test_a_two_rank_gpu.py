@@ -1,0 +1,34 @@
+"""The N > 1 path with REAL registrations: benchmarks/config5.py under torch.distributed.run with two ranks
+sharing the one GPU of the test box (BENCH_DEVICE=0, gloo for the gather), against the same program run as a single rank.
+The file name sorts first on purpose: the ranks are child processes, and the pytest process has not touched the GPU yet when
+it starts them (children are started, never exec'd into)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.gpu, pytest.mark.children_only]
+
+ARGS = ["--candidates", "12", "--submaps", "3", "--casts-per-submap", "2", "--n-azimuth", "128", "--capacity", "16384", "--max-iterations", "32"]
+
+
+def _run(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_ranks_register_their_shards_and_gather():
+    env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 300)
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "benchmarks/config5.py", "--gpus", "2"] + ARGS, env)
+    one = _run([sys.executable, "benchmarks/config5.py", "--gpus", "1"] + ARGS, env)
+    assert two["n_gpus"] == 2 and two["collective_ranks"] == 2 and two["all_reported"] and one["all_reported"]
+    assert two["candidates"] == 12 and two["within_5cm_of_truth"] >= 11
+    # sharding must not change any result: same acceptance and accuracy as the single-rank run
+    for k in ("accepted(fitness<0.3)", "within_5cm_of_truth", "median_pose_err_m", "mean_iterations"):
+        assert two[k] == one[k], (k, two[k], one[k])

@@ -74,3 +74,38 @@ def test_two_rank_gloo_gather():
         np.testing.assert_array_equal(Tall[:, 0, 3], np.arange(n_pairs))  # every pair present, in global order
         np.testing.assert_allclose(fall, np.arange(n_pairs) * 0.5)
     np.testing.assert_array_equal(results[0][1], results[1][1])  # all ranks hold the same gathered result
+
+
+def _worker_rows(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tgt = np.zeros(5, dtype=np.int64)  # ONE sub-map: the second rank owns nothing but still takes part in the gather
+        mine = sharding.shard_by_target(tgt, world)[rank]
+        rows = np.stack([mine * 10.0 + c for c in range(22)], axis=1) if len(mine) else np.zeros((0, 22))
+        q.put((rank, len(mine), sharding.gather_rows(mine, rows, 5)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_with_an_idle_rank():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 977) % 2000)
+    procs = [ctx.Process(target=_worker_rows, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[1] for r in results) == [0, 5]
+    for _, _, g in results:
+        assert g.shape == (5, 22)
+        np.testing.assert_array_equal(g[:, 0], np.arange(5) * 10.0)
+        np.testing.assert_array_equal(g[:, 21], np.arange(5) * 10.0 + 21)
