@@ -45,7 +45,9 @@ def gather_rows(local_idx, rows, n_total: int, group=None) -> np.ndarray:
     import torch.distributed as dist
 
     local_idx = np.asarray(local_idx, dtype=np.int64)
-    rows = np.asarray(rows, dtype=np.float64).reshape(len(local_idx), -1)
+    rows = np.asarray(rows, dtype=np.float64)
+    if rows.ndim != 2:
+        rows = rows.reshape(len(local_idx), -1) if len(local_idx) else np.zeros((0, 0))
     C = rows.shape[1]
     out = np.full((n_total, C), np.nan)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
