@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--n-azimuth", type=int, default=1024, help="1024 = 65 536 rays per scan")
     ap.add_argument("--capacity", type=int, default=65536)
     ap.add_argument("--max-iterations", type=int, default=64)
+    ap.add_argument("--min-good", type=float, default=0.9, help="fail unless this fraction of the pairs lands within 5 cm / 5 mrad of the truth")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +129,7 @@ def main():
             "mean_iterations": round(float(out["iterations"].mean()), 1),
         }
         print(json.dumps(line))
-        if not out["reported"].all() or good.sum() < 0.9 * n:
+        if not out["reported"].all() or good.sum() < args.min_good * n:
             raise SystemExit("config5: results missing or wrong")
     if world > 1:
         dist.destroy_process_group()

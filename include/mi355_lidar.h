@@ -168,6 +168,34 @@ int mi355_reg_ndt_derivatives(mi355_reg* reg, const double p6[6], double* score,
 int mi355_reg_ndt_num_cells(mi355_reg* reg, size_t* n_cells);
 int mi355_reg_ndt_cells(mi355_reg* reg, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3);
 
+/* ---- device-resident clouds: the key-frame ring --------------------------------------------- */
+/* The odometry node rebuilds its sub-map at every key frame by transforming up to 20 stored key-frame clouds on the CPU and
+ * concatenating them (lidar_scan_matcher.cpp:187-212); the back end does the same around a loop candidate
+ * (graph_based_slam.cpp:297-309).  A mi355_cloud keeps a cloud in HBM: uploaded once, transformed / concatenated by kernels,
+ * handed to a registration object without crossing PCIe again.  A cloud that has been a GICP source carries its per-point
+ * covariances; transforms rotate them (C' = R C R^T), so a sub-map assembled with carry_covariances needs only its spatial
+ * index rebuilt, not the k-NN covariance pass over ~3 x 10^5 points. */
+typedef struct mi355_cloud mi355_cloud;
+mi355_cloud* mi355_cloud_upload(mi355_ctx* ctx, const mi355_cloud_view* points);
+void mi355_cloud_destroy(mi355_cloud* cloud);
+size_t mi355_cloud_size(const mi355_cloud* cloud);
+int mi355_cloud_has_covariances(const mi355_cloud* cloud);
+/* packed float4, the caller's point order; capacity in points */
+int mi355_cloud_download(mi355_cloud* cloud, float* out_packed, size_t capacity);
+/* pcl::transformPointCloud (lidar_scan_matcher.cpp:275-294) on the device: a NEW cloud */
+mi355_cloud* mi355_cloud_transform(mi355_cloud* cloud, const float T16[16]);
+/* T_0 cloud_0 ++ T_1 cloud_1 ++ ... in list order (lidar_scan_matcher.cpp:199-210): a NEW cloud.  carry_covariances != 0
+ * requires every input to carry covariances (MI355_ESTATE otherwise) and gives the result the rotated ones. */
+mi355_cloud* mi355_cloud_concat(mi355_ctx* ctx, mi355_cloud* const* clouds, const float* T16s, int n, int carry_covariances);
+/* fast_gicp's calculate_covariances for a cloud that has not been a registration source (key frame #0 of the odometry node is
+ * the first TARGET): computed once, kept with the cloud. */
+int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k_correspondences, int regularization_method);
+/* setInputSource / setInputTarget from a device cloud.  FAST_GICP: a source cloud without covariances gets them computed and
+ * cached (same k / regularisation as the registration object); a target cloud that carries covariances uses them instead
+ * of recomputing over the union (carry_covariances above), one that does not gets them computed as mi355_reg_set_target does. */
+int mi355_reg_set_source_cloud(mi355_reg* reg, mi355_cloud* cloud);
+int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud);
+
 /* ---- batch mode: many independent scan pairs per launch (BASELINE configs 2 and 5) --------------------- */
 /* n_sources source clouds and n_targets target clouds, each up to `capacity` points; pair p aligns source p to
  * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates). */
@@ -180,6 +208,9 @@ int mi355_batch_set_sources_dev(mi355_batch* b, const void* d_points, const int*
 /* Host-pointer variants (PCIe copy included). */
 int mi355_batch_set_targets(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* prefilter);
 int mi355_batch_set_sources(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* prefilter);
+/* The same from device clouds (one per slot, at most `capacity` points each): copied slot by slot on the device. */
+int mi355_batch_set_targets_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* prefilter);
+int mi355_batch_set_sources_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* prefilter);
 /* tgt_of_src: n_sources ints (NULL = identity mapping, requires n_targets == n_sources); guesses: n_sources x 16 floats (NULL = I).
  * Enqueues every alignment; does not synchronise. */
 int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesses16, int with_fitness);

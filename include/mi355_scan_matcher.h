@@ -24,6 +24,10 @@ typedef struct mi355_scan_matcher_params {
   double ndt_resolution;              /* yaml:15 -> 2.0 */
   double max_correspondence_distance; /* yaml:18 -> 2.0 */
   int correspondence_randomness;      /* yaml:19 -> 20 */
+  int reuse_key_frame_covariances;    /* 1: a key frame's GICP covariances are computed once and rotated into every sub-map
+                                         (C' = R C R^T); 0: recomputed over the merged sub-map at every key frame,
+                                         as fast_gicp does (lidar_scan_matcher.cpp:212 -> setInputTarget).  The sub-map itself is
+                                         assembled on the device either way. */
 } mi355_scan_matcher_params;
 
 typedef struct mi355_scan_output {

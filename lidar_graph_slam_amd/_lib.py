@@ -109,6 +109,9 @@ EXPORTS = [
     "mi355_knn", "mi355_covariances",
     "mi355_reg_create", "mi355_reg_destroy", "mi355_reg_set_params", "mi355_reg_set_target", "mi355_reg_set_source", "mi355_reg_align",
     "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
+    "mi355_cloud_upload", "mi355_cloud_destroy", "mi355_cloud_size", "mi355_cloud_has_covariances", "mi355_cloud_download", "mi355_cloud_transform",
+    "mi355_cloud_concat", "mi355_cloud_compute_covariances", "mi355_reg_set_source_cloud", "mi355_reg_set_target_cloud",
+    "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
     "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times",
 ]
@@ -164,6 +167,7 @@ class ScanMatcherParams(C.Structure):
         ("ndt_resolution", C.c_double),
         ("max_correspondence_distance", C.c_double),
         ("correspondence_randomness", C.c_int),
+        ("reuse_key_frame_covariances", C.c_int),
     ]
 
 
@@ -221,6 +225,23 @@ def lib():
         L.mi355_reg_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_reg_ndt_num_cells.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         L.mi355_reg_ndt_cells.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.mi355_cloud_upload.restype = C.c_void_p
+        L.mi355_cloud_upload.argtypes = [C.c_void_p, PV]
+        L.mi355_cloud_destroy.argtypes = [C.c_void_p]
+        L.mi355_cloud_destroy.restype = None
+        L.mi355_cloud_size.restype = C.c_size_t
+        L.mi355_cloud_size.argtypes = [C.c_void_p]
+        L.mi355_cloud_has_covariances.argtypes = [C.c_void_p]
+        L.mi355_cloud_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mi355_cloud_transform.restype = C.c_void_p
+        L.mi355_cloud_transform.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_cloud_concat.restype = C.c_void_p
+        L.mi355_cloud_concat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.mi355_cloud_compute_covariances.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mi355_reg_set_source_cloud.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_reg_set_target_cloud.argtypes = [C.c_void_p, C.c_void_p]
+        L.mi355_batch_set_targets_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
+        L.mi355_batch_set_sources_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
         L.mi355_batch_create.restype = C.c_void_p
         L.mi355_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
         L.mi355_batch_destroy.argtypes = [C.c_void_p]

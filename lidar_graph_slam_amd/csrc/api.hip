@@ -113,6 +113,15 @@ struct mi355_reg {
   }
 };
 
+struct mi355_cloud {
+  mi355_ctx* ctx = nullptr;
+  size_t n = 0;
+  DevBuf<float4> pts;  // caller's point order
+  DevBuf<Cov6> cov;    // caller's point order; valid when has_cov
+  bool has_cov = false;
+  int cov_k = 0, cov_method = 0;
+};
+
 struct mi355_batch {
   mi355_ctx* ctx = nullptr;
   int method = MI355_METHOD_FAST_GICP;
@@ -136,6 +145,7 @@ struct mi355_batch {
   GicpBatch gb;
   KernelTimers timers;  // mi355_batch_set_timing / mi355_batch_kernel_times
   DevBuf<float4> host_stage;
+  DevBuf<float4> cloud_stage_src, cloud_stage_tgt;  // mi355_batch_set_*_clouds: the slots assembled on the device
   hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
   bool has_own_stream = false;
   hipStream_t stream() const { return has_own_stream ? own_stream : ctx->stream; }
@@ -647,6 +657,182 @@ extern "C" int mi355_reg_ndt_cells(mi355_reg* reg, int64_t* leaf_idx, int* leaf_
   });
 }
 
+// ---- device-resident clouds ----------------------------------------------------------------------------------------
+static mi355_cloud* new_cloud(mi355_ctx* ctx, size_t n) {
+  auto* c = new mi355_cloud();
+  c->ctx = ctx;
+  c->n = n;
+  c->pts.ensure(std::max<size_t>(n, 1));
+  return c;
+}
+
+extern "C" mi355_cloud* mi355_cloud_upload(mi355_ctx* ctx, const mi355_cloud_view* points) {
+  if (!ctx || !points) return nullptr;
+  mi355_cloud* c = nullptr;
+  const int rc = guarded(ctx, [&] {
+    MI_HIP(hipSetDevice(ctx->device));
+    check_view(points);
+    c = new_cloud(ctx, points->n);
+    extras(ctx)->fs.up.upload(ctx->stream, points, c->pts.p);
+  });
+  if (rc != MI355_OK) {
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" void mi355_cloud_destroy(mi355_cloud* cloud) {
+  if (!cloud) return;
+  (void)hipSetDevice(cloud->ctx->device);
+  (void)hipStreamSynchronize(cloud->ctx->stream);  // kernels that still read the cloud
+  delete cloud;
+}
+
+extern "C" size_t mi355_cloud_size(const mi355_cloud* cloud) { return cloud ? cloud->n : 0; }
+extern "C" int mi355_cloud_has_covariances(const mi355_cloud* cloud) { return (cloud && cloud->has_cov) ? 1 : 0; }
+
+extern "C" int mi355_cloud_download(mi355_cloud* cloud, float* out_packed, size_t capacity) {
+  if (!cloud || (cloud->n && !out_packed)) return MI355_EINVAL;
+  return guarded(cloud->ctx, [&] {
+    if (cloud->n > capacity) throw ArgError(MI355_ECAPACITY, "output capacity too small");
+    MI_HIP(hipSetDevice(cloud->ctx->device));
+    if (cloud->n) MI_HIP(hipMemcpyAsync(out_packed, cloud->pts.p, cloud->n * sizeof(float4), hipMemcpyDeviceToHost, cloud->ctx->stream));
+    MI_HIP(hipStreamSynchronize(cloud->ctx->stream));
+  });
+}
+
+extern "C" mi355_cloud* mi355_cloud_concat(mi355_ctx* ctx, mi355_cloud* const* clouds, const float* T16s, int n, int carry_covariances) {
+  if (!ctx || n < 0 || (n && (!clouds || !T16s))) return nullptr;
+  mi355_cloud* out = nullptr;
+  const int rc = guarded(ctx, [&] {
+    MI_HIP(hipSetDevice(ctx->device));
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+      if (!clouds[i] || clouds[i]->ctx != ctx) throw ArgError(MI355_EINVAL, "cloud belongs to another context");
+      if (carry_covariances && !clouds[i]->has_cov) throw ArgError(MI355_ESTATE, "carry_covariances: an input cloud carries no covariances");
+      if (carry_covariances && (clouds[i]->cov_k != clouds[0]->cov_k || clouds[i]->cov_method != clouds[0]->cov_method))
+        throw ArgError(MI355_ESTATE, "carry_covariances: the input clouds' covariances were computed with different parameters");
+      total += clouds[i]->n;
+    }
+    out = new_cloud(ctx, total);
+    if (carry_covariances && n > 0) {
+      out->cov.ensure(std::max<size_t>(total, 1));
+      out->has_cov = true;
+      out->cov_k = clouds[0]->cov_k;
+      out->cov_method = clouds[0]->cov_method;
+    }
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+      transform_points_cov(ctx->stream, clouds[i]->pts.p, out->has_cov ? clouds[i]->cov.p : nullptr, out->pts.p + off,
+                           out->has_cov ? out->cov.p + off : nullptr, clouds[i]->n, T16s + 16 * (size_t)i);
+      off += clouds[i]->n;
+    }
+  });
+  if (rc != MI355_OK) {
+    delete out;
+    return nullptr;
+  }
+  return out;
+}
+
+extern "C" mi355_cloud* mi355_cloud_transform(mi355_cloud* cloud, const float T16[16]) {
+  if (!cloud || !T16) return nullptr;
+  mi355_cloud* one[1] = {cloud};
+  return mi355_cloud_concat(cloud->ctx, one, T16, 1, cloud->has_cov ? 1 : 0);
+}
+
+extern "C" int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k, int method) {
+  if (!cloud) return MI355_EINVAL;
+  mi355_ctx* ctx = cloud->ctx;
+  return guarded(ctx, [&] {
+    if (cloud->has_cov && cloud->cov_k == k && cloud->cov_method == method) return;
+    if (cloud->n == 0 || (size_t)k > cloud->n || k < 1) throw ArgError(MI355_EINVAL, "k must be in [1, n]");
+    MI_HIP(hipSetDevice(ctx->device));
+    FilterScratch& fs = extras(ctx)->fs;
+    fs.na.ensure(1);
+    const int ni = (int)cloud->n;
+    MI_HIP(hipMemcpyAsync(fs.na.p, &ni, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));  // &ni
+    if (fs.set.B != 1 || fs.set.cap != cloud->n) fs.set.alloc(1, cloud->n);
+    build_grid(ctx->stream, fs.ws, cloud->pts.p, fs.na.p, fs.set, ctx->grid_cell);
+    compute_covariances(ctx->stream, fs.set, k, method);
+    cloud->cov.ensure(cloud->n);
+    cov_to_caller_order(ctx->stream, fs.set, cloud->n, cloud->cov.p);
+    cloud->has_cov = true;
+    cloud->cov_k = k;
+    cloud->cov_method = method;
+  });
+}
+
+// caller-order device points of a cloud -> the registration object's staging (what the host-pointer entry points fill by upload)
+static void reg_take_cloud(mi355_reg* reg, mi355_cloud* cloud, DevBuf<float4>& stage, DevBuf<int>& cnt) {
+  mi355_ctx* ctx = reg->ctx;
+  if (cloud->ctx != ctx) throw ArgError(MI355_EINVAL, "cloud belongs to another context");
+  MI_HIP(hipSetDevice(ctx->device));
+  stage.ensure(std::max<size_t>(cloud->n, 1));
+  cnt.ensure(1);
+  if (cloud->n) MI_HIP(hipMemcpyAsync(stage.p, cloud->pts.p, cloud->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  const int ni = (int)cloud->n;
+  MI_HIP(hipMemcpyAsync(cnt.p, &ni, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  MI_HIP(hipStreamSynchronize(ctx->stream));  // &ni
+}
+
+extern "C" int mi355_reg_set_source_cloud(mi355_reg* reg, mi355_cloud* cloud) {
+  if (!reg || !cloud) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_take_cloud(reg, cloud, reg->stage_src, reg->cnt_src);
+    reg->n_src = cloud->n;
+    reg->has_src = false;
+    reg->aligned = false;
+    if (reg->n_src == 0) throw ArgError(MI355_EINVAL, "empty source cloud");
+    reg->src.alloc(1, reg->n_src);
+    build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
+    if (reg->method == MI355_METHOD_FAST_GICP) {
+      if ((size_t)reg->gp.k_correspondences > reg->n_src) throw ArgError(MI355_EINVAL, "source has fewer points than k_correspondences");
+      const bool cached = cloud->has_cov && cloud->cov_k == reg->gp.k_correspondences && cloud->cov_method == reg->gp.regularization_method;
+      if (cached) {
+        cov_from_caller_order(ctx->stream, reg->src, reg->n_src, cloud->cov.p);
+      } else {  // compute once, keep with the cloud: it follows the key frame into every sub-map
+        compute_covariances(ctx->stream, reg->src, reg->gp.k_correspondences, reg->gp.regularization_method);
+        cloud->cov.ensure(reg->n_src);
+        cov_to_caller_order(ctx->stream, reg->src, reg->n_src, cloud->cov.p);
+        cloud->has_cov = true;
+        cloud->cov_k = reg->gp.k_correspondences;
+        cloud->cov_method = reg->gp.regularization_method;
+      }
+    }
+    gicp_alloc(reg->gb, 1, reg->n_src, ctx->compute_units);
+    reg->has_src = true;
+  });
+}
+
+extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
+  if (!reg || !cloud) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_take_cloud(reg, cloud, reg->stage_tgt, reg->cnt_tgt);
+    reg->n_tgt = cloud->n;
+    reg->has_tgt = false;
+    reg->aligned = false;
+    if (reg->n_tgt == 0) throw ArgError(MI355_EINVAL, "empty target cloud");
+    if (reg->method == MI355_METHOD_FAST_GICP) {
+      if ((size_t)reg->gp.k_correspondences > reg->n_tgt) throw ArgError(MI355_EINVAL, "target has fewer points than k_correspondences");
+      reg->tgt.alloc(1, reg->n_tgt);
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+      const bool carried = cloud->has_cov && cloud->cov_k == reg->gp.k_correspondences && cloud->cov_method == reg->gp.regularization_method;
+      if (carried) cov_from_caller_order(ctx->stream, reg->tgt, reg->n_tgt, cloud->cov.p);
+      else compute_covariances(ctx->stream, reg->tgt, reg->gp.k_correspondences, reg->gp.regularization_method);
+    } else {
+      ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
+      reg->tgt.alloc(1, reg->n_tgt);
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+    }
+    reg->has_tgt = true;
+  });
+}
+
 // ---- batch ---------------------------------------------------------------------------------------------------------
 extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity) {
   if (!ctx || method != MI355_METHOD_FAST_GICP || n_sources <= 0 || n_targets <= 0 || capacity == 0) {
@@ -774,6 +960,32 @@ static int batch_set_host(mi355_batch* b, bool targets, const float* points, con
     if (targets) b->has_tgt = true; else b->has_src = true;
     b->aligned = false;
   });
+}
+static int batch_set_clouds(mi355_batch* b, bool targets, mi355_cloud* const* clouds, const mi355_prefilter_params* pf) {
+  if (!b || !clouds) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    MI_HIP(hipSetDevice(b->ctx->device));
+    const int B = targets ? b->n_targets : b->n_sources;
+    DevBuf<float4>& stage = targets ? b->cloud_stage_tgt : b->cloud_stage_src;  // stays valid until the next call: no sync needed
+    stage.ensure((size_t)B * b->cap);
+    std::vector<int> counts((size_t)B);
+    for (int i = 0; i < B; i++) {
+      if (!clouds[i] || clouds[i]->ctx != b->ctx) throw ArgError(MI355_EINVAL, "NULL cloud / cloud of another context");
+      if (clouds[i]->n > b->cap) throw ArgError(MI355_EINVAL, "cloud exceeds the batch capacity");
+      counts[(size_t)i] = (int)clouds[i]->n;
+      if (clouds[i]->n)
+        MI_HIP(hipMemcpyAsync(stage.p + (size_t)i * b->cap, clouds[i]->pts.p, clouds[i]->n * sizeof(float4), hipMemcpyDeviceToDevice, b->stream()));
+    }
+    batch_set(b, targets, stage.p, counts.data(), pf);
+    if (targets) b->has_tgt = true; else b->has_src = true;
+    b->aligned = false;
+  });
+}
+extern "C" int mi355_batch_set_targets_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* pf) {
+  return batch_set_clouds(b, true, clouds, pf);
+}
+extern "C" int mi355_batch_set_sources_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* pf) {
+  return batch_set_clouds(b, false, clouds, pf);
 }
 extern "C" int mi355_batch_set_targets(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* pf) {
   return batch_set_host(b, true, points, counts, pf);

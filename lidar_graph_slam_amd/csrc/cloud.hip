@@ -961,6 +961,49 @@ void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, co
   MI_LAUNCH_CHECK();
 }
 
+// ---- device-resident clouds (key-frame ring) ---------------------------------------------------------
+// out[i] = T * in[i] (the fmaf order of k_transform: bit-equal to the pcl::transformPointCloud restatement) and, when the
+// cloud carries covariances, cov_out[i] = R cov_in[i] R^T: a rigid motion rotates a neighbourhood covariance, and the
+// PLANE-regularised matrix (I - 0.999 n n^T) with it, so a key frame's covariances are computed ONCE and follow the key frame
+// into every sub-map it is part of.
+__global__ __launch_bounds__(256) void k_transform_cov(const float4* __restrict__ in, const Cov6* __restrict__ cov_in, float4* __restrict__ out,
+                                                       Cov6* __restrict__ cov_out, size_t n, Mat4f T) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  out[i] = make_float4(transform_row(T.m, p.x, p.y, p.z), transform_row(T.m + 4, p.x, p.y, p.z), transform_row(T.m + 8, p.x, p.y, p.z), p.w);
+  if (cov_in) {
+    const float R[9] = {T.m[0], T.m[1], T.m[2], T.m[4], T.m[5], T.m[6], T.m[8], T.m[9], T.m[10]};
+    const Sym3<float> c = sym3_rotate(R, cov6_unpack(cov_in[i]));
+    cov_out[i] = cov6_pack(c.xx, c.xy, c.xz, c.yy, c.yz, c.zz);
+  }
+}
+void transform_points_cov(hipStream_t s, const float4* in, const Cov6* cov_in, float4* out, Cov6* cov_out, size_t n, const float* T16_host) {
+  if (n == 0) return;
+  Mat4f T;
+  memcpy(T.m, T16_host, sizeof(T.m));
+  hipLaunchKernelGGL(k_transform_cov, dim3(div_up((long)n, 256)), dim3(256), 0, s, in, cov_in, out, cov_out, n, T);
+  MI_LAUNCH_CHECK();
+}
+// covariances between the caller's point order and the Morton order of a built single-cloud set
+__global__ __launch_bounds__(256) void k_cov_permute(const Cov6* __restrict__ in, Cov6* __restrict__ out, const int* __restrict__ orig, int n, int to_caller) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (to_caller) out[orig[i]] = in[i];
+  else out[i] = in[orig[i]];
+}
+void cov_to_caller_order(hipStream_t s, const CloudSet& set, size_t n, Cov6* out_caller) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_cov_permute, dim3(div_up((long)n, 256)), dim3(256), 0, s, (const Cov6*)set.cov.p, out_caller, (const int*)set.orig.p, (int)n, 1);
+  MI_LAUNCH_CHECK();
+}
+void cov_from_caller_order(hipStream_t s, CloudSet& set, size_t n, const Cov6* in_caller) {
+  set.cov.ensure((size_t)set.B * set.cap);
+  if (n) hipLaunchKernelGGL(k_cov_permute, dim3(div_up((long)n, 256)), dim3(256), 0, s, in_caller, set.cov.p, (const int*)set.orig.p, (int)n, 0);
+  MI_LAUNCH_CHECK();
+  set.has_cov = true;
+}
+
 // ---- order-preserving compaction --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ in, const int* __restrict__ counts, const int* __restrict__ flags,
                                                  const int* __restrict__ local, const int* __restrict__ blockoff, const int* __restrict__ totals,

@@ -95,6 +95,11 @@ void compute_covariances(hipStream_t s, CloudSet& set, int k, int method);
 // Exact k-NN of queries (packed float4 [m]) in cloud 0 of a built set; idx in the caller's point order.
 void knn_query(hipStream_t s, const CloudSet& set, const float4* d_queries, int m, int k, int* d_idx, float* d_d2);
 void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, const float* T16_host);
+// device-resident clouds: rigid transform of points (+ covariances, C' = R C R^T, when cov_in != nullptr)
+void transform_points_cov(hipStream_t s, const float4* in, const Cov6* cov_in, float4* out, Cov6* cov_out, size_t n, const float* T16_host);
+// covariances of a built single-cloud set <-> the caller's point order
+void cov_to_caller_order(hipStream_t s, const CloudSet& set, size_t n, Cov6* out_caller);
+void cov_from_caller_order(hipStream_t s, CloudSet& set, size_t n, const Cov6* in_caller);
 
 // ---- gicp.hip ------------------------------------------------------------------------------------------------
 struct GicpPairState;  // device-side LM state, one per source cloud

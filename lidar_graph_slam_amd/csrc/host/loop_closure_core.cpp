@@ -37,13 +37,9 @@ int LoopClosureCore::candidate(int query) const {
   return min_id;
 }
 
-void LoopClosureCore::append_transformed(const PointCloud& in, const Matrix4f& T, std::vector<float>& packed) {
-  packed.reserve(packed.size() + 4 * in.size());
-  for (const PointXYZI& p : in) {
-    for (int r = 0; r < 3; r++)
-      packed.push_back(std::fmaf(T[4 * r], p.x, std::fmaf(T[4 * r + 1], p.y, std::fmaf(T[4 * r + 2], p.z, T[4 * r + 3]))));
-    packed.push_back(p.intensity);
-  }
+LoopClosureCore::~LoopClosureCore() {
+  if (batch_) mi355_batch_destroy(batch_);
+  key_frames_.clear();  // device clouds go before the context
 }
 
 // double-precision rigid transform from a geometry Pose (what gtsam::Pose3(Rot3::Quaternion, Point3) holds)
@@ -72,64 +68,72 @@ std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) 
   }
   if (uniq.empty()) return out;
 
-  // sub-maps (:297-309): key frames min_id - N .. min_id + N, each moved by its own pose, concatenated in index order
+  if (!ctx_) ctx_.reset(new Context(device_id_));
+  auto on_device = [&](int k) -> const DeviceCloud::Ptr& {  // one upload per key frame, ever
+    KeyFrame& kf = key_frames_[(size_t)k];
+    if (!kf.device) kf.device = DeviceCloud::upload(*ctx_, kf.cloud);
+    return kf.device;
+  };
+  // sub-maps (:297-309): key frames min_id - N .. min_id + N, each moved by its own pose, concatenated in index order —
+  // transform kernels writing one device cloud per sub-map
   const int n_kf = (int)key_frames_.size();
-  std::vector<std::vector<float>> submap(uniq.size());
+  std::vector<DeviceCloud::Ptr> submap(uniq.size());
   size_t cap = 1;
   for (size_t u = 0; u < uniq.size(); u++) {
+    std::vector<DeviceCloud::Ptr> parts;
+    std::vector<Matrix4f> poses;
     for (int idx = -params_.search_key_frame_num; idx <= params_.search_key_frame_num; idx++) {
       const int k = uniq[u] + idx;
       if (k < 0 || n_kf <= k) continue;
-      append_transformed(key_frames_[(size_t)k].cloud, geometry_pose_to_matrix(key_frames_[(size_t)k].pose), submap[u]);
+      parts.push_back(on_device(k));
+      poses.push_back(geometry_pose_to_matrix(key_frames_[(size_t)k].pose));
     }
-    cap = std::max(cap, submap[u].size() / 4);
+    submap[u] = DeviceCloud::concat(*ctx_, parts, poses, /*carry_covariances=*/false);  // voxel-filtered next: new points
+    cap = std::max(cap, submap[u]->size());
   }
   // sources (:248-252): the query key frame moved by its pose
   std::vector<size_t> src_of;  // rows of `out` that are registered
-  std::vector<std::vector<float>> source;
+  std::vector<DeviceCloud::Ptr> source;
   for (size_t i = 0; i < queries.size(); i++) {
     if (cand[i] < 0) continue;
     src_of.push_back(i);
-    source.emplace_back();
-    const KeyFrame& kf = key_frames_[(size_t)queries[i]];
-    append_transformed(kf.cloud, geometry_pose_to_matrix(kf.pose), source.back());
-    cap = std::max(cap, source.back().size() / 4);
+    source.push_back(on_device(queries[i])->transformed(geometry_pose_to_matrix(key_frames_[(size_t)queries[i]].pose)));
+    cap = std::max(cap, source.back()->size());
   }
   const int S = (int)source.size(), U = (int)uniq.size();
 
-  if (!ctx_) ctx_.reset(new Context(device_id_));
   mi355_gicp_params gp;
   mi355_gicp_default_params(&gp);  // fast_gicp defaults, then the setters of :92-96
   gp.k_correspondences = params_.correspondence_randomness;
   gp.max_iterations = params_.max_iteration;
   gp.transformation_epsilon = params_.transformation_epsilon;
   gp.max_correspondence_distance = params_.max_correspondence_distance;
-  mi355_batch* b = mi355_batch_create(ctx_->get(), MI355_METHOD_FAST_GICP, &gp, S, U, cap);
-  if (!b) throw Error(MI355_EHIP, mi355_last_error(ctx_->get()));
-  struct Guard {
-    mi355_batch* b;
-    ~Guard() { mi355_batch_destroy(b); }
-  } guard{b};
-
-  std::vector<float> stage((size_t)std::max(S, U) * cap * 4, 0.f);
-  std::vector<int> counts((size_t)std::max(S, U));
-  for (int u = 0; u < U; u++) {
-    std::copy(submap[(size_t)u].begin(), submap[(size_t)u].end(), stage.begin() + (size_t)u * cap * 4);
-    counts[(size_t)u] = (int)(submap[(size_t)u].size() / 4);
+  if (!batch_ || S > batch_S_ || U > batch_U_ || cap > batch_cap_) {  // grow-only
+    if (batch_) mi355_batch_destroy(batch_);
+    batch_S_ = std::max(S, batch_S_); batch_U_ = std::max(U, batch_U_); batch_cap_ = std::max(cap, batch_cap_);
+    batch_ = mi355_batch_create(ctx_->get(), MI355_METHOD_FAST_GICP, &gp, batch_S_, batch_U_, batch_cap_);
+    if (!batch_) {
+      batch_S_ = batch_U_ = 0;
+      batch_cap_ = 0;
+      throw Error(MI355_EHIP, mi355_last_error(ctx_->get()));
+    }
   }
+  mi355_batch* b = batch_;
+  // unused slots of the persistent batch get an empty cloud
+  PointCloud none;
+  DeviceCloud::Ptr empty = DeviceCloud::upload(*ctx_, none);
+  std::vector<mi355_cloud*> th((size_t)batch_U_, empty->get()), sh((size_t)batch_S_, empty->get());
+  for (int u = 0; u < U; u++) th[(size_t)u] = submap[(size_t)u]->get();
+  for (int s2 = 0; s2 < S; s2++) sh[(size_t)s2] = source[(size_t)s2]->get();
   mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
-  ctx_->check(mi355_batch_set_targets(b, stage.data(), counts.data(), &pf));
-  for (int s = 0; s < S; s++) {
-    std::copy(source[(size_t)s].begin(), source[(size_t)s].end(), stage.begin() + (size_t)s * cap * 4);
-    counts[(size_t)s] = (int)(source[(size_t)s].size() / 4);
-  }
-  ctx_->check(mi355_batch_set_sources(b, stage.data(), counts.data(), nullptr));
-  std::vector<int> tgt_of_src((size_t)S);
+  ctx_->check(mi355_batch_set_targets_clouds(b, th.data(), &pf));
+  ctx_->check(mi355_batch_set_sources_clouds(b, sh.data(), nullptr));
+  std::vector<int> tgt_of_src((size_t)batch_S_, 0);
   for (int s = 0; s < S; s++)
     tgt_of_src[(size_t)s] = (int)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
   ctx_->check(mi355_batch_align(b, tgt_of_src.data(), nullptr /* align(*output): identity guess, :318 */, /*with_fitness=*/1));
-  std::vector<mi355_result> res((size_t)S);
-  std::vector<double> fit((size_t)S);
+  std::vector<mi355_result> res((size_t)batch_S_);
+  std::vector<double> fit((size_t)batch_S_);
   ctx_->check(mi355_batch_results(b, res.data(), fit.data()));
 
   for (int s = 0; s < S; s++) {
@@ -229,6 +233,7 @@ extern "C" const char* mi355_loop_closure_last_error(const mi355_loop_closure* h
 
 extern "C" int mi355_loop_closure_add_key_frame(mi355_loop_closure* h, const mi355_cloud_view* cloud, const double pose7[7], double accum_distance) {
   if (!h || !cloud || !pose7 || (cloud->n && !cloud->data)) return -1;
+  if (cloud->stride < 16 || cloud->stride % 4 || cloud->intensity_offset < 12 || cloud->intensity_offset + 4 > cloud->stride) return -1;
   try {
     mi355::PointCloud in(cloud->n);
     const char* base = (const char*)cloud->data;

@@ -36,6 +36,7 @@ struct LoopResult {
 class LoopClosureCore {
  public:
   LoopClosureCore(int device_id, const LoopClosureParams& p) : device_id_(device_id), params_(p) {}
+  ~LoopClosureCore();
   // key_frame_callback's bookkeeping (:354-380): the cloud is in the key frame's own frame
   int add_key_frame(PointCloud cloud, const Pose& pose, double accum_distance);
   void set_pose(int id, const Pose& pose) { key_frames_.at((size_t)id).pose = pose; }
@@ -46,12 +47,15 @@ class LoopClosureCore {
   size_t size() const { return key_frames_.size(); }
 
  private:
-  // pcl::transformPointCloud with the evaluation order the library and the oracle share (devmath.hpp transform_row)
-  static void append_transformed(const PointCloud& in, const Matrix4f& T, std::vector<float>& packed);
   int device_id_;
   LoopClosureParams params_;
-  std::vector<KeyFrame> key_frames_;
-  std::unique_ptr<Context> ctx_;  // created by the first close(): the bookkeeping above needs no GPU
+  std::vector<KeyFrame> key_frames_;   // KeyFrame::device is filled (one upload per key frame) by the first close() that needs it
+  std::unique_ptr<Context> ctx_;       // created by the first close(): the bookkeeping above needs no GPU
+  // the batch object outlives close(): its buffers (tens of GB at 512 candidates) are allocated once and grown only when a
+  // call needs more sources, sub-maps or capacity
+  mi355_batch* batch_ = nullptr;
+  int batch_S_ = 0, batch_U_ = 0;
+  size_t batch_cap_ = 0;
 };
 
 }  // namespace mi355

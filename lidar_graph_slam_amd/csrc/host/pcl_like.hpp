@@ -71,6 +71,51 @@ class Context {
   mi355_ctx* ctx_;
 };
 
+// ---- device-resident clouds (include/mi355_lidar.h: mi355_cloud) ------------------------------------------------------
+// A key frame's cloud lives in HBM from the moment the scan arrives: transformed, concatenated into sub-maps and handed to the
+// registration without crossing PCIe again (the reference does all of that on the CPU, lidar_scan_matcher.cpp:187-212).
+class DeviceCloud {
+ public:
+  using Ptr = std::shared_ptr<DeviceCloud>;
+  static Ptr upload(Context& ctx, const PointCloud& cloud) {
+    const mi355_cloud_view v = view_of(cloud);
+    return wrap(ctx, mi355_cloud_upload(ctx.get(), &v));
+  }
+  // pcl::transformPointCloud (lidar_scan_matcher.cpp:275-294)
+  Ptr transformed(const Matrix4f& T) const { return wrap(ctx_, mi355_cloud_transform(h_, T.data())); }
+  // T_0 c_0 ++ T_1 c_1 ++ ... (lidar_scan_matcher.cpp:199-210; graph_based_slam.cpp:297-309)
+  static Ptr concat(Context& ctx, const std::vector<Ptr>& clouds, const std::vector<Matrix4f>& Ts, bool carry_covariances) {
+    std::vector<mi355_cloud*> hs;
+    std::vector<float> T16;
+    for (size_t i = 0; i < clouds.size(); i++) {
+      hs.push_back(clouds[i]->h_);
+      T16.insert(T16.end(), Ts[i].begin(), Ts[i].end());
+    }
+    return wrap(ctx, mi355_cloud_concat(ctx.get(), hs.data(), T16.data(), (int)hs.size(), carry_covariances ? 1 : 0));
+  }
+  ~DeviceCloud() { mi355_cloud_destroy(h_); }
+  DeviceCloud(const DeviceCloud&) = delete;
+  DeviceCloud& operator=(const DeviceCloud&) = delete;
+  size_t size() const { return mi355_cloud_size(h_); }
+  bool has_covariances() const { return mi355_cloud_has_covariances(h_) != 0; }
+  void compute_covariances(int k, int method) { ctx_.check(mi355_cloud_compute_covariances(h_, k, method)); }
+  void download(PointCloud& out) const {
+    std::vector<float> packed(4 * std::max<size_t>(size(), 1));
+    ctx_.check(mi355_cloud_download(h_, packed.data(), packed.size() / 4));
+    unpack(packed.data(), size(), out);
+  }
+  mi355_cloud* get() const { return h_; }
+
+ private:
+  DeviceCloud(Context& ctx, mi355_cloud* h) : ctx_(ctx), h_(h) {}
+  static Ptr wrap(Context& ctx, mi355_cloud* h) {
+    if (!h) throw Error(MI355_EHIP, mi355_last_error(ctx.get()));
+    return Ptr(new DeviceCloud(ctx, h));
+  }
+  Context& ctx_;
+  mi355_cloud* h_;
+};
+
 // ---- filters --------------------------------------------------------------------------------------------------------
 class VoxelGrid {  // pcl::VoxelGrid<PointXYZI>
  public:
@@ -139,12 +184,28 @@ class Registration {  // pcl::Registration<PointXYZI, PointXYZI>
     const mi355_cloud_view v = view_of(*cloud);
     ctx_.check(mi355_reg_set_source(reg_, &v));
   }
+  // the same from clouds that already live on the device
+  void setInputTarget(const DeviceCloud::Ptr& cloud) {
+    push_params();
+    target_.reset();
+    ctx_.check(mi355_reg_set_target_cloud(reg_, cloud->get()));
+  }
+  void setInputSource(const DeviceCloud::Ptr& cloud) {
+    push_params();
+    source_.reset();
+    ctx_.check(mi355_reg_set_source_cloud(reg_, cloud->get()));
+  }
   void align(PointCloud& output) { align(output, identity4()); }
   void align(PointCloud& output, const Matrix4f& guess) {
     push_params();
     std::vector<float> out(4 * std::max<size_t>(source_ ? source_->size() : 0, 1));
     ctx_.check(mi355_reg_align(reg_, guess.data(), &result_, out.data()));
     unpack(out.data(), source_ ? source_->size() : 0, output);
+  }
+  // align without materialising the aligned cloud (the node never uses it: lidar_scan_matcher.cpp:164-165)
+  void align(const Matrix4f& guess) {
+    push_params();
+    ctx_.check(mi355_reg_align(reg_, guess.data(), &result_, nullptr));
   }
   bool hasConverged() const { return result_.converged != 0; }
   Matrix4f getFinalTransformation() const {

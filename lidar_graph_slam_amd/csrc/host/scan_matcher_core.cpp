@@ -14,6 +14,7 @@ ScanMatcherCore::ScanMatcherCore(Context& ctx, const ScanMatcherParams& p) : ctx
     gicp->setMaxCorrespondenceDistance(p.max_correspondence_distance);
     if (0 < p.omp_num_thread) gicp->setNumThreads(p.omp_num_thread);
     registration_ = gicp;
+    gicp_ = true;
   } else if (p.registration_method == "NDT_OMP") {  // :55-72
     auto ndt = std::make_shared<NormalDistributionsTransform>(ctx);
     ndt->setTransformationEpsilon(p.transformation_epsilon);
@@ -29,29 +30,27 @@ ScanMatcherCore::ScanMatcherCore(Context& ctx, const ScanMatcherParams& p) : ctx
   }
 }
 
-PointCloudPtr ScanMatcherCore::transform_point_cloud(Context& ctx, const PointCloud& in, const Matrix4f& T) {  // :287-294
+PointCloudPtr ScanMatcherCore::target_cloud() const {
   auto out = std::make_shared<PointCloud>();
-  std::vector<float> packed(4 * std::max<size_t>(in.size(), 1));
-  const mi355_cloud_view v = view_of(in);
-  ctx.check(mi355_transform(ctx.get(), &v, T.data(), packed.data()));
-  unpack(packed.data(), in.size(), *out);
+  if (target_cloud_) target_cloud_->download(*out);
   return out;
 }
 
 ScanOutput ScanMatcherCore::callback_cloud(const PointCloud& input_cloud, const Matrix4f& base_to_sensor) {
   ScanOutput out;
-  PointCloudPtr base_to_sensor_cloud = transform_point_cloud(ctx_, input_cloud, base_to_sensor);  // :129-131
+  // the scan crosses PCIe once; everything below works on device clouds
+  DeviceCloud::Ptr sensor_cloud = DeviceCloud::upload(ctx_, input_cloud);
+  DeviceCloud::Ptr base_to_sensor_cloud = sensor_cloud->transformed(base_to_sensor);  // :129-131
 
   if (!target_cloud_) {  // :133-160
     prev_translation_ = identity4();
     key_frame_ = identity4();
-    target_cloud_ = std::make_shared<PointCloud>();
     KeyFrame key_frame;
     key_frame.pose = convert_matrix_to_pose(prev_translation_);
     key_frame.id = id_++;
-    key_frame.cloud = input_cloud;  // key frame #0 keeps the SENSOR-frame cloud (:145) — reproduced as is
+    key_frame.device = sensor_cloud;  // key frame #0 keeps the SENSOR-frame cloud (:145) — reproduced as is
     key_frame_array_.emplace_back(std::move(key_frame));
-    target_cloud_->insert(target_cloud_->end(), base_to_sensor_cloud->begin(), base_to_sensor_cloud->end());
+    target_cloud_ = base_to_sensor_cloud;
     registration_->setInputTarget(target_cloud_);
     out.first_scan = true;
     out.new_key_frame = true;
@@ -60,9 +59,8 @@ ScanOutput ScanMatcherCore::callback_cloud(const PointCloud& input_cloud, const 
     return out;
   }
 
-  registration_->setInputSource(base_to_sensor_cloud);  // :162
-  PointCloud aligned;
-  registration_->align(aligned, prev_translation_);  // :165
+  registration_->setInputSource(base_to_sensor_cloud);  // :162 (FAST_GICP: the scan's covariances stay with the device cloud)
+  registration_->align(prev_translation_);              // :165
   out.iterations = registration_->result().iterations;
   if (!registration_->hasConverged()) {  // :167-170 — scan dropped, pose frozen
     out.converged = false;
@@ -82,23 +80,29 @@ ScanOutput ScanMatcherCore::callback_cloud(const PointCloud& input_cloud, const 
   if (params_.displacement <= delta) {                          // :183
     key_frame_ = translation_;
     accum_distance_ += delta;
-    target_cloud_->clear();  // same shared_ptr mutated in place (:187)
 
     KeyFrame key_frame;
     key_frame.pose = convert_matrix_to_pose(key_frame_);
     key_frame.accum_distance = accum_distance_;
     key_frame.id = id_++;
-    key_frame.cloud = *base_to_sensor_cloud;  // :196
+    key_frame.device = base_to_sensor_cloud;  // :196
     key_frame_array_.emplace_back(std::move(key_frame));
 
+    // :187,199-210 clear the target and refill it with the last N key frames, each moved by its own pose: ONE device
+    // cloud built by transform kernels writing at running offsets
+    std::vector<DeviceCloud::Ptr> parts;
+    std::vector<Matrix4f> poses;
+    const bool carry = gicp_ && params_.reuse_key_frame_covariances;
     const int sub_map_size = (int)key_frame_array_.size();
-    for (int idx = 0; idx < params_.max_scan_accumulate_num; idx++) {  // :199-210
+    for (int idx = 0; idx < params_.max_scan_accumulate_num; idx++) {
       if ((sub_map_size - 1 - idx) < 0) continue;
-      const KeyFrame& kf = key_frame_array_[sub_map_size - 1 - idx];
-      const Matrix4f matrix = geometry_pose_to_matrix(kf.pose);
-      PointCloudPtr transformed = transform_point_cloud(ctx_, kf.cloud, matrix);
-      target_cloud_->insert(target_cloud_->end(), transformed->begin(), transformed->end());
+      const KeyFrame& kf = key_frame_array_[(size_t)(sub_map_size - 1 - idx)];
+      // key frame #0 was the first target, never a source: its covariances are computed here, once
+      if (carry && !kf.device->has_covariances()) kf.device->compute_covariances(params_.correspondence_randomness, MI355_REG_PLANE);
+      parts.push_back(kf.device);
+      poses.push_back(geometry_pose_to_matrix(kf.pose));
     }
+    target_cloud_ = DeviceCloud::concat(ctx_, parts, poses, carry);
     registration_->setInputTarget(target_cloud_);  // :212
     out.new_key_frame = true;
     out.key_frame_id = key_frame_array_.back().id;
@@ -132,6 +136,7 @@ extern "C" mi355_scan_matcher* mi355_scan_matcher_create(int device_id, const mi
     sp.ndt_resolution = p->ndt_resolution;
     sp.max_correspondence_distance = p->max_correspondence_distance;
     sp.correspondence_randomness = p->correspondence_randomness;
+    sp.reuse_key_frame_covariances = p->reuse_key_frame_covariances != 0;
     h->core.reset(new mi355::ScanMatcherCore(*h->ctx, sp));
   } catch (const std::exception&) {
     delete h;
@@ -152,6 +157,8 @@ extern "C" const char* mi355_scan_matcher_last_error(const mi355_scan_matcher* h
 extern "C" int mi355_scan_matcher_callback_cloud(mi355_scan_matcher* h, const mi355_cloud_view* cloud, const float base_to_sensor16[16],
                                                  mi355_scan_output* out) {
   if (!h || !cloud || !out) return MI355_EINVAL;
+  if (cloud->n && !cloud->data) return MI355_EINVAL;
+  if (cloud->stride < 16 || cloud->stride % 4 || cloud->intensity_offset < 12 || cloud->intensity_offset + 4 > cloud->stride) return MI355_EINVAL;
   try {
     mi355::PointCloud in(cloud->n);
     const char* base = (const char*)cloud->data;
@@ -185,10 +192,10 @@ extern "C" int mi355_scan_matcher_callback_cloud(mi355_scan_matcher* h, const mi
 
 extern "C" int mi355_scan_matcher_target(mi355_scan_matcher* h, float* out_packed, size_t cap, size_t* n) {
   if (!h || !n) return MI355_EINVAL;
-  const auto& t = h->core->target_cloud();
-  *n = t ? t->size() : 0;
+  *n = h->core->target_points();
   if (!out_packed) return MI355_OK;
   if (*n > cap) return MI355_ECAPACITY;
+  const auto t = h->core->target_cloud();
   for (size_t i = 0; i < *n; i++) {
     out_packed[4 * i] = (*t)[i].x; out_packed[4 * i + 1] = (*t)[i].y; out_packed[4 * i + 2] = (*t)[i].z; out_packed[4 * i + 3] = (*t)[i].intensity;
   }

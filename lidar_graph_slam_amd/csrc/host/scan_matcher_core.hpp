@@ -72,7 +72,8 @@ inline Matrix4f matmul(const Matrix4f& a, const Matrix4f& b) {  // Eigen Matrix4
 }
 
 struct KeyFrame {  // lidar_graph_slam_msgs/msg/KeyFrame.msg:1-5 (header dropped)
-  PointCloud cloud;
+  PointCloud cloud;           // host copy: filled by callers that hand key frames over on the host (LoopClosureCore::add_key_frame)
+  DeviceCloud::Ptr device;    // the cloud in HBM (with its GICP covariances once it has been a registration source)
   Pose pose;
   double accum_distance = 0.0;
   long id = 0;
@@ -89,6 +90,11 @@ struct ScanMatcherParams {  // lidar_scan_matcher.param.yaml:3-19
   double ndt_resolution = 2.0;
   double max_correspondence_distance = 2.0;
   int correspondence_randomness = 20;
+  // a key frame's k-NN covariances are computed once (when the scan is registered) and ROTATED into every
+  // sub-map it is part of (C' = R C R^T) instead of being recomputed over the ~3 x 10^5-point union at every key frame.
+  // false = the reference's arithmetic: fast_gicp recomputes them over the merged sub-map (its neighbourhoods then also
+  // hold points of the other key frames); the sub-map is still assembled on the device.
+  bool reuse_key_frame_covariances = true;
 };
 
 struct ScanOutput {
@@ -107,15 +113,17 @@ class ScanMatcherCore {
   // `msg` cloud in the sensor frame; base_to_sensor = the TF the node looks up (identity when the lookup fails, cpp:259-271)
   ScanOutput callback_cloud(const PointCloud& input_cloud, const Matrix4f& base_to_sensor);
   const std::vector<KeyFrame>& key_frames() const { return key_frame_array_; }
-  const PointCloudPtr& target_cloud() const { return target_cloud_; }
+  // the sliding sub-map (target_cloud_), downloaded on demand
+  PointCloudPtr target_cloud() const;
+  size_t target_points() const { return target_cloud_ ? target_cloud_->size() : 0; }
   double accum_distance() const { return accum_distance_; }
 
  private:
-  static PointCloudPtr transform_point_cloud(Context& ctx, const PointCloud& in, const Matrix4f& T);
   Context& ctx_;
   ScanMatcherParams params_;
   Registration::Ptr registration_;
-  PointCloudPtr target_cloud_;
+  DeviceCloud::Ptr target_cloud_;  // device-resident: assembled by a gather kernel, never staged through the host
+  bool gicp_ = false;
   std::vector<KeyFrame> key_frame_array_;
   Matrix4f prev_translation_ = identity4(), key_frame_ = identity4(), translation_ = identity4();
   double accum_distance_ = 0.0;

@@ -15,6 +15,59 @@ from . import _lib as L
 from .context import Context, default_context
 
 
+class DeviceCloud:
+    """mi355_cloud: a cloud that lives in HBM (the key-frame ring of SURVEY 8f-2): uploaded once, transformed / concatenated on
+    the device (lidar_scan_matcher.cpp:199-210, 275-294), handed to a registration object without crossing PCIe again."""
+
+    def __init__(self, handle, ctx: Context):
+        if not handle:
+            raise L.Mi355Error(L.EHIP, ctx._lib.mi355_last_error(ctx.handle).decode())
+        self.handle, self.ctx = handle, ctx
+
+    @classmethod
+    def upload(cls, cloud, ctx: Context | None = None):
+        ctx = ctx or default_context()
+        v, keep = L.view(cloud)
+        return cls(ctx._lib.mi355_cloud_upload(ctx.handle, C.byref(v)), ctx)
+
+    def transformed(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+        return DeviceCloud(self.ctx._lib.mi355_cloud_transform(self.handle, T.ctypes.data), self.ctx)
+
+    @staticmethod
+    def concat(clouds, Ts, carry_covariances=False):
+        ctx = clouds[0].ctx
+        hs = (C.c_void_p * len(clouds))(*[c.handle for c in clouds])
+        T = np.ascontiguousarray(np.asarray(Ts, dtype=np.float32).reshape(len(clouds), 16))
+        return DeviceCloud(ctx._lib.mi355_cloud_concat(ctx.handle, hs, T.ctypes.data, len(clouds), 1 if carry_covariances else 0), ctx)
+
+    def compute_covariances(self, k=20, method=L.REG_PLANE):
+        self.ctx.check(self.ctx._lib.mi355_cloud_compute_covariances(self.handle, int(k), int(method)))
+
+    def __len__(self):
+        return int(self.ctx._lib.mi355_cloud_size(self.handle))
+
+    @property
+    def has_covariances(self):
+        return bool(self.ctx._lib.mi355_cloud_has_covariances(self.handle))
+
+    def download(self):
+        out = np.empty((max(len(self), 1), 4), dtype=np.float32)
+        self.ctx.check(self.ctx._lib.mi355_cloud_download(self.handle, out.ctypes.data, out.shape[0]))
+        return out[: len(self)]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx._lib.mi355_cloud_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _Registration:
     _method = None
 
@@ -41,11 +94,18 @@ class _Registration:
     # -- pcl::Registration interface ----------------------------------------------------------------------------
     def setInputTarget(self, cloud):
         self._push()
+        if isinstance(cloud, DeviceCloud):
+            self.ctx.check(self.ctx._lib.mi355_reg_set_target_cloud(self.handle, cloud.handle))
+            return
         v, keep = L.view(cloud)
         self.ctx.check(self.ctx._lib.mi355_reg_set_target(self.handle, C.byref(v)))
 
     def setInputSource(self, cloud):
         self._push()
+        if isinstance(cloud, DeviceCloud):
+            self._n_src = len(cloud)
+            self.ctx.check(self.ctx._lib.mi355_reg_set_source_cloud(self.handle, cloud.handle))
+            return
         v, keep = L.view(cloud)
         self._n_src = v.n
         self.ctx.check(self.ctx._lib.mi355_reg_set_source(self.handle, C.byref(v)))
@@ -219,6 +279,14 @@ class BatchRegistration:
         assert p.shape == (self.n_sources, self.capacity, 4), p.shape
         c = self._counts(counts, self.n_sources)
         self.ctx.check(self.ctx._lib.mi355_batch_set_sources(self.handle, p.ctypes.data, c.ctypes.data, C.byref(prefilter) if prefilter else None))
+
+    def set_targets_clouds(self, clouds, prefilter=None):
+        hs = (C.c_void_p * self.n_targets)(*[c.handle for c in clouds])
+        self.ctx.check(self.ctx._lib.mi355_batch_set_targets_clouds(self.handle, hs, C.byref(prefilter) if prefilter else None))
+
+    def set_sources_clouds(self, clouds, prefilter=None):
+        hs = (C.c_void_p * self.n_sources)(*[c.handle for c in clouds])
+        self.ctx.check(self.ctx._lib.mi355_batch_set_sources_clouds(self.handle, hs, C.byref(prefilter) if prefilter else None))
 
     def set_stream(self, hip_stream: int | None):
         """Run this batch on its own HIP stream (None: back to the context's); batches on different streams overlap."""

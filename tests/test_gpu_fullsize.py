@@ -1,0 +1,192 @@
+"""The BASELINE configs at their STATED sizes: every test here runs the HIP path through the C-ABI on
+full-size inputs and checks it against the oracle on the same inputs and/or against the known ground truth.
+
+  config 2  noise-free 64 k-point pair: <= 5 mm / 5e-4 rad vs truth, <= 1 mm / 1e-4 rad vs the oracle
+  config 3  64 k-point scan vs a ~1 M-point target, 1.0 m NDT cells, vs O.ndt_align
+  config 4  KITTI-shaped stream through ScanMatcherCore: 100 scans x 64 k rays, window 20 — FAST_GICP scan by scan against
+            the reference-policy restatement registering with the oracle (first 24 scans, covariances recomputed as fast_gicp
+            does), then both engines against the ground truth over the whole stream
+  config 5  the per-GPU share of the loop-closure batch (512 candidates, 8 sub-maps, 0.5 m voxel) vs truth, a sample vs the
+            oracle (pose and fitness)
+"""
+import numpy as np
+import pytest
+
+from lidar_graph_slam_amd import synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pf(c, leaf=0.2):
+    return O.voxel_grid(O.distance_filter(c, 1.0), leaf)[0]
+
+
+def test_config2_noise_free_pair_meets_the_stated_truth_tolerance():
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+    from lidar_graph_slam_amd.registration import FastGICP
+
+    scene = synth.Scene(1234)
+    T_gt = synth.default_pair_gt()
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+    for gmr, tol_t in ((None, 5e-3), (20.0, 2e-3)):
+        tgt = synth.cast_scan(scene, np.eye(4), noise_sigma=0.0, jitter_sigma=0.0, seed=1, ground_max_range=gmr)
+        src = synth.cast_scan(scene, T_gt, noise_sigma=0.0, jitter_sigma=0.0, seed=7920, ground_max_range=gmr)
+        s, t = pre.callback_sensor_points(src), pre.callback_sensor_points(tgt)
+        np.testing.assert_array_equal(s, _pf(src))  # the prefilter is bit-exact at full size
+        reg = FastGICP(max_iterations=20, force_iterations=1)
+        reg.setInputTarget(t)
+        reg.setInputSource(s)
+        reg.align()
+        dt, dr = synth.pose_error(reg.getFinalTransformation(), T_gt)
+        assert dt <= tol_t and dr <= 5e-4, (gmr, dt, dr)  # <= 5 mm / 5e-4 rad on the noise-free scene
+        ref = O.gicp_align(s, t, O.gicp_params(max_iterations=20, force_iterations=1))
+        dt, dr = synth.pose_error(reg.getFinalTransformation(), ref["T"])
+        assert dt <= 1e-3 and dr <= 1e-4, (gmr, dt, dr)
+
+
+def test_config3_ndt_scan_vs_1m_point_submap():
+    from lidar_graph_slam_amd.registration import NormalDistributionsTransform
+
+    scene = synth.Scene(1234)
+    poses = [synth.se3(1.0 * i, 0.02 * i, 0, 0, 0, 0.002 * i) for i in range(16)]
+    parts = []
+    for i, P in enumerate(poses):
+        c = synth.cast_scan(scene, P, seed=200 + i)
+        c = c[np.abs(c[:, :3]).sum(1) > 0]
+        c[:, :3] = (c[:, :3].astype(np.float64) @ P[:3, :3].T + P[:3, 3]).astype(np.float32)
+        parts.append(c)
+    sub = np.concatenate(parts, axis=0)
+    assert 0.9e6 < len(sub) < 1.1e6, len(sub)
+    T_true = synth.se3(7.5, 0.15, 0, 0, 0, 0.015)
+    scan = synth.cast_scan(scene, T_true, seed=999)
+    scan = scan[np.abs(scan[:, :3]).sum(1) > 0]
+    guess = synth.se3(7.2, 0.1, 0, 0, 0, 0.01).astype(np.float32)
+    ndt = NormalDistributionsTransform(resolution=1.0)
+    ndt.setInputTarget(sub)
+    ndt.setInputSource(scan)
+    ndt.align(guess)
+    ref = O.ndt_align(scan, sub, O.ndt_params(resolution=1.0), guess=guess)
+    cells = ndt.cells()
+    ref_cells = O.ndt_cells(sub, O.ndt_params(resolution=1.0))
+    assert abs(len(cells["idx"]) - len(ref_cells["idx"])) <= 2  # leaves (a voxel on the eigenvalue-sign edge may differ)
+    assert ndt.hasConverged() and ref["converged"]
+    assert abs(ndt.result["iterations"] - ref["iterations"]) <= 1
+    dt, dr = synth.pose_error(ndt.getFinalTransformation(), ref["T"])
+    assert dt <= 0.01 and dr <= 2e-3, (dt, dr)  # inside the convergence band of the last step
+    dt, dr = synth.pose_error(ndt.getFinalTransformation(), T_true)
+    assert dt <= 0.05 and dr <= 2e-3, (dt, dr)
+
+
+@pytest.fixture(scope="module")
+def street_stream():
+    n = 100
+    scene = synth.street(n * 0.8 + 10.0)
+    poses = synth.trajectory(n, seed=3)
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+    scans = [pre.callback_sensor_points(synth.cast_scan(scene, poses[i], seed=300 + i, ground_max_range=20.0)) for i in range(n)]
+    return poses, scans
+
+
+def test_config4_gicp_stream_matches_the_reference_policy(street_stream):
+    """Scan by scan against the restatement of callback_cloud registering with the ORACLE; reuse_key_frame_covariances = 0:
+    the target covariances are recomputed over the merged sub-map exactly as fast_gicp does."""
+    from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
+    from ref_scan_matcher import RefScanMatcher
+
+    poses, scans = street_stream
+    sm = LidarScanMatcher(registration_method="FAST_GICP", reuse_key_frame_covariances=False)
+    ref = RefScanMatcher(method="FAST_GICP")
+    for i in range(24):
+        a, b = sm.callback_cloud(scans[i]), ref.callback_cloud(scans[i])
+        assert a["first_scan"] == b["first_scan"]
+        if a["first_scan"]:
+            continue
+        assert a["converged"] and b["converged"], i
+        dt, dr = synth.pose_error(a["pose"], b["pose"])
+        assert dt <= 0.012 and dr <= 2.5e-3, (i, dt, dr)
+        assert a["new_key_frame"] == b["new_key_frame"], i
+        assert a["target_points"] == len(ref.target), i
+    tgt = sm.target_cloud()
+    np.testing.assert_array_equal(tgt, ref.target)  # the device-assembled sub-map is the reference's, bit for bit
+
+
+@pytest.mark.parametrize("method,reuse", [("FAST_GICP", True), ("NDT_OMP", True)])
+def test_config4_stream_tracks_the_ground_truth(street_stream, method, reuse):
+    """100 scans x 64 k rays, window 20 (80 m of path): odometry error against the ground truth at every scan.  NDT_OMP at 2 m
+    cells — the reference's default — tracks on this scene; the corridor scene of round 1 it could not track on is analysed in
+    tests/test_oracle_ndt.py::test_ring_trap_is_a_property_of_the_scene_not_of_the_optimiser."""
+    from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
+
+    poses, scans = street_stream
+    sm = LidarScanMatcher(registration_method=method, reuse_key_frame_covariances=reuse)
+    n_kf, worst = 0, 0.0
+    for i, s in enumerate(scans):
+        o = sm.callback_cloud(s)
+        if o["first_scan"]:
+            continue
+        assert o["converged"], (method, i)
+        n_kf += o["new_key_frame"]
+        dt, dr = synth.pose_error(o["pose"], np.linalg.inv(poses[0]) @ poses[i])
+        worst = max(worst, dt)
+        assert dt < 0.3 and dr < 0.02, (method, i, dt, dr)
+    # key frames every ~1.0 m of 0.8 m steps: every second scan, +-
+    assert 40 <= n_kf <= 60, n_kf
+    assert o["target_points"] > 150_000  # 20 key frames in the window
+
+
+def test_config5_per_gpu_share_of_the_loop_closure_batch():
+    from lidar_graph_slam_amd import loop_batch
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+
+    S, n, casts = 8, 512, 8
+    scene = synth.street(20.0 * S + 20.0)
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+    rng = np.random.default_rng(5)
+    tgt_of_src = np.arange(n) % S
+    cast_of = (np.arange(n) // S) % casts
+    true_off = [synth.random_perturbation(np.random.default_rng(1000 + s * 64 + c), 1.0, 2.0) for s in range(S) for c in range(casts)]
+    wrong = [synth.random_perturbation(rng, 1.5, 4.0) for _ in range(n)]
+    sub_pose = lambda s: synth.se3(20.0 * s, 0.0, 0.0)  # noqa: E731
+    true_pose = lambda p: sub_pose(int(tgt_of_src[p])) @ true_off[int(tgt_of_src[p]) * casts + int(cast_of[p])]  # noqa: E731
+    graph_pose = lambda p: true_pose(p) @ wrong[p]  # noqa: E731
+
+    def place(c, T):
+        o = c.copy()
+        o[:, :3] = (c[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        return o
+
+    scans, submaps = {}, {}
+
+    def scan_at(s, c):
+        if (s, c) not in scans:
+            scans[(s, c)] = pre.callback_sensor_points(synth.cast_scan(scene, sub_pose(s) @ true_off[s * casts + c], seed=9000 + s * 64 + c, ground_max_range=30.0))
+        return scans[(s, c)]
+
+    def load_source(p):
+        return place(scan_at(int(tgt_of_src[p]), int(cast_of[p])), graph_pose(p))
+
+    def load_target(s):
+        if s not in submaps:
+            parts = []
+            for j in range(-2, 3):
+                P = sub_pose(s) @ synth.se3(1.0 * j, 0.0, 0.0)
+                parts.append(place(pre.callback_sensor_points(synth.cast_scan(scene, P, seed=500 + 10 * s + j, ground_max_range=30.0)), P))
+            submaps[s] = np.concatenate(parts, axis=0)
+        return submaps[s]
+
+    out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, 100_000, target_prefilter=loop_batch.voxel_prefilter(0.5), max_iterations=64)
+    assert out["reported"].all() and (out["status"] == 0).all()
+    errs = np.array([synth.pose_error(out["T"][p], true_pose(p) @ np.linalg.inv(graph_pose(p))) for p in range(n)])
+    accepted = out["converged"] & (out["fitness"] < 0.3)  # graph_based_slam.cpp:321-328
+    assert accepted.sum() >= 0.98 * n and (errs[accepted, 0] < 0.05).mean() > 0.98, (accepted.sum(), np.median(errs[:, 0]))
+    # a sample against the oracle: same voxel-filtered sub-map, same candidate, identity guess (graph_based_slam.cpp:311-322)
+    for p in (0, 77, 203, 511):
+        t = O.voxel_grid(load_target(int(tgt_of_src[p])), 0.5)[0]
+        assert out["n_target"][p] == len(t)
+        ref = O.gicp_align(load_source(p), t, O.gicp_params(max_iterations=64))
+        dt, dr = synth.pose_error(out["T"][p], ref["T"])
+        assert dt <= 0.012 and dr <= 2.5e-3, (p, dt, dr)  # both stop inside the convergence band
+        np.testing.assert_allclose(out["fitness"][p], O.fitness(load_source(p), t, out["T"][p]), rtol=1e-6)

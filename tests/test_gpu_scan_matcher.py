@@ -20,12 +20,14 @@ def _stream(n_scans, n_azimuth=128):
     return poses, scans
 
 
-@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP"])
-def test_stream_matches_reference_policy(method):
+@pytest.mark.parametrize("method,reuse", [("FAST_GICP", False), ("FAST_GICP", True), ("NDT_OMP", True)])
+def test_stream_matches_reference_policy(method, reuse):
+    """reuse = False: target covariances recomputed over the merged sub-map as fast_gicp does; True: each key frame's
+    covariances rotated into the sub-map — both inside the convergence band of the oracle's pose."""
     from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
 
     poses, scans = _stream(10)
-    sm = LidarScanMatcher(registration_method=method, max_scan_accumulate_num=4)
+    sm = LidarScanMatcher(registration_method=method, max_scan_accumulate_num=4, reuse_key_frame_covariances=reuse)
     ref = RefScanMatcher(method=method, max_scan_accumulate_num=4)
     n_kf = 0
     for i, s in enumerate(scans):
@@ -47,7 +49,7 @@ def test_stream_matches_reference_policy(method):
             assert dt < 0.15 and dr < 0.01, (i, dt, dr)  # odometry stays on the ground truth
     assert n_kf >= 3
     tgt = sm.target_cloud()
-    assert tgt.shape == ref.target.shape
+    np.testing.assert_array_equal(tgt, ref.target)  # the device-assembled sub-map is the reference's, bit for bit
     assert sm.callback_cloud(scans[-1])["n_key_frames"] == len(ref.key_frames)
 
 
