@@ -110,7 +110,7 @@ def test_config4_gicp_stream_matches_the_reference_policy(street_stream):
         assert a["new_key_frame"] == b["new_key_frame"], i
         assert a["target_points"] == len(ref.target), i
     tgt = sm.target_cloud()
-    np.testing.assert_array_equal(tgt, ref.target)  # the device-assembled sub-map is the reference's, bit for bit
+    np.testing.assert_allclose(tgt, ref.target, rtol=0, atol=2e-5)  # the device-assembled sub-map is the reference's (pose matrices through two quaternion codes: ulps)
 
 
 @pytest.mark.parametrize("method,reuse", [("FAST_GICP", True), ("NDT_OMP", True)])
