@@ -196,6 +196,29 @@ int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k_correspondences, i
 int mi355_reg_set_source_cloud(mi355_reg* reg, mi355_cloud* cloud);
 int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud);
 
+/* ---- wire / on-disk formats ------------------------------------------------------------------ */
+/* sensor_msgs/PointCloud2 as the nodes receive and publish it (pcl::fromROSMsg at lidar_scan_matcher.cpp:127,196,203 and
+ * points_prefiltering.cpp:70; pcl::toROSMsg at lidar_scan_matcher.cpp:145,196 and graph_based_slam.cpp:462): the raw message
+ * bytes cross PCIe once and are unpacked / packed by a kernel.  Field offsets and datatypes are the message's `fields`
+ * entries for x, y, z, intensity (sensor_msgs/PointField: INT8=1 UINT8=2 INT16=3 UINT16=4 INT32=5 UINT32=6 FLOAT32=7 FLOAT64=8);
+ * x, y, z must be FLOAT32; an absent intensity field is off_intensity = -1 (intensity 0, as fromROSMsg leaves it). */
+typedef struct mi355_pointcloud2 {
+  const void* data;      /* msg.data */
+  uint32_t width, height;
+  uint32_t point_step, row_step;
+  int32_t off_x, off_y, off_z, off_intensity;
+  uint8_t intensity_datatype;
+  uint8_t is_bigendian;  /* must be 0 (every ROS 2 platform is little-endian) */
+} mi355_pointcloud2;
+mi355_cloud* mi355_cloud_from_pointcloud2(mi355_ctx* ctx, const mi355_pointcloud2* msg);
+/* pcl::toROSMsg(pcl::PointCloud<pcl::PointXYZI>): point_step 32, x@0 y@4 z@8 (data[3] = 1.0f @12) intensity@16, padding 0;
+ * width = n, height = 1, row_step = 32 n.  out: 32 n bytes. */
+int mi355_cloud_to_pointcloud2(mi355_cloud* cloud, void* out_data, size_t capacity_bytes);
+/* pcl::io::savePCDFile (graph_based_slam.cpp:499: ASCII by default, binary_mode = 0): FIELDS x y z intensity, SIZE 4 4 4 4,
+ * TYPE F F F F, WIDTH n, HEIGHT 1, VIEWPOINT 0 0 0 1 0 0 0, values with 8 significant digits.  Host-only (no GPU needed). */
+int mi355_pcd_write(const char* path, const mi355_cloud_view* points, int binary);
+int mi355_cloud_save_pcd(mi355_cloud* cloud, const char* path, int binary);
+
 /* ---- batch mode: many independent scan pairs per launch (BASELINE configs 2 and 5) --------------------- */
 /* n_sources source clouds and n_targets target clouds, each up to `capacity` points; pair p aligns source p to
  * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates). */

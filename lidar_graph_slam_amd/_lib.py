@@ -68,6 +68,12 @@ class PrefilterParams(C.Structure):
 PAIR_OK, PAIR_TOO_FEW_POINTS = 0, 1
 
 
+class PointCloud2(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("point_step", C.c_uint32), ("row_step", C.c_uint32),
+                ("off_x", C.c_int32), ("off_y", C.c_int32), ("off_z", C.c_int32), ("off_intensity", C.c_int32), ("intensity_datatype", C.c_uint8),
+                ("is_bigendian", C.c_uint8)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("total_ms", C.c_double), ("launches", C.c_int), ("reserved", C.c_int)]
 
@@ -112,6 +118,7 @@ EXPORTS = [
     "mi355_cloud_upload", "mi355_cloud_destroy", "mi355_cloud_size", "mi355_cloud_has_covariances", "mi355_cloud_download", "mi355_cloud_transform",
     "mi355_cloud_concat", "mi355_cloud_compute_covariances", "mi355_reg_set_source_cloud", "mi355_reg_set_target_cloud",
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
+    "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
     "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times",
 ]
@@ -242,6 +249,11 @@ def lib():
         L.mi355_reg_set_target_cloud.argtypes = [C.c_void_p, C.c_void_p]
         L.mi355_batch_set_targets_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
         L.mi355_batch_set_sources_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
+        L.mi355_cloud_from_pointcloud2.restype = C.c_void_p
+        L.mi355_cloud_from_pointcloud2.argtypes = [C.c_void_p, C.POINTER(PointCloud2)]
+        L.mi355_cloud_to_pointcloud2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.mi355_pcd_write.argtypes = [C.c_char_p, PV, C.c_int]
+        L.mi355_cloud_save_pcd.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.mi355_batch_create.restype = C.c_void_p
         L.mi355_batch_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
         L.mi355_batch_destroy.argtypes = [C.c_void_p]

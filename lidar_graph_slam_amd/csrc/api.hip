@@ -765,6 +765,89 @@ extern "C" int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k, int me
   });
 }
 
+// ---- wire / on-disk formats -----------------------------------------------------------------------------------------
+extern "C" mi355_cloud* mi355_cloud_from_pointcloud2(mi355_ctx* ctx, const mi355_pointcloud2* m) {
+  if (!ctx || !m) return nullptr;
+  mi355_cloud* c = nullptr;
+  const int rc = guarded(ctx, [&] {
+    const size_t n = (size_t)m->width * m->height;
+    if (n && !m->data) throw ArgError(MI355_EINVAL, "PointCloud2 data is NULL");
+    if (m->is_bigendian) throw ArgError(MI355_EINVAL, "big-endian PointCloud2 is not supported");
+    static const int size_of[9] = {0, 1, 1, 2, 2, 4, 4, 4, 8};
+    if (m->off_intensity >= 0 && (m->intensity_datatype < 1 || m->intensity_datatype > 8)) throw ArgError(MI355_EINVAL, "bad intensity datatype");
+    const int isz = m->off_intensity >= 0 ? size_of[m->intensity_datatype] : 0;
+    if (m->off_x < 0 || m->off_y < 0 || m->off_z < 0 || (uint32_t)std::max(m->off_x, std::max(m->off_y, m->off_z)) + 4 > m->point_step ||
+        (m->off_intensity >= 0 && (uint32_t)(m->off_intensity + isz) > m->point_step) || (size_t)m->width * m->point_step > m->row_step)
+      throw ArgError(MI355_EINVAL, "PointCloud2 field offsets / steps are inconsistent");
+    MI_HIP(hipSetDevice(ctx->device));
+    c = new_cloud(ctx, n);
+    if (n == 0) return;
+    const size_t bytes = (size_t)m->row_step * m->height;
+    FilterScratch& fs = extras(ctx)->fs;
+    fs.mask.ensure(bytes);
+    MI_HIP(hipMemcpyAsync(fs.mask.p, m->data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    pointcloud2_unpack(ctx->stream, fs.mask.p, c->pts.p, m->width, m->height, m->point_step, m->row_step, m->off_x, m->off_y, m->off_z,
+                       m->off_intensity, m->intensity_datatype);
+    MI_HIP(hipStreamSynchronize(ctx->stream));  // the caller's message buffer and the raw staging are free again
+  });
+  if (rc != MI355_OK) {
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" int mi355_cloud_to_pointcloud2(mi355_cloud* cloud, void* out_data, size_t capacity_bytes) {
+  if (!cloud || (cloud->n && !out_data)) return MI355_EINVAL;
+  mi355_ctx* ctx = cloud->ctx;
+  return guarded(ctx, [&] {
+    if (cloud->n * 32 > capacity_bytes) throw ArgError(MI355_ECAPACITY, "output capacity too small (32 bytes per point)");
+    if (cloud->n == 0) return;
+    MI_HIP(hipSetDevice(ctx->device));
+    FilterScratch& fs = extras(ctx)->fs;
+    fs.b.ensure(2 * cloud->n);
+    pointcloud2_pack(ctx->stream, cloud->pts.p, fs.b.p, cloud->n);
+    MI_HIP(hipMemcpyAsync(out_data, fs.b.p, cloud->n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+// pcl::PCDWriter for PointXYZI: header + one line per point (ASCII, 8 significant digits as `fs.precision(8)` prints them)
+// or the packed 16-byte records (binary).  Host only.
+extern "C" int mi355_pcd_write(const char* path, const mi355_cloud_view* v, int binary) {
+  if (!path || !v || (v->n && !v->data) || v->stride < 16 || v->intensity_offset + 4 > v->stride) return MI355_EINVAL;
+  FILE* f = fopen(path, "wb");
+  if (!f) return MI355_EINVAL;
+  fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+             "WIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA %s\n", v->n, v->n, binary ? "binary" : "ascii");
+  const char* base = (const char*)v->data;
+  bool ok = true;
+  for (size_t i = 0; i < v->n && ok; i++) {
+    float rec[4];
+    memcpy(rec, base + i * v->stride, 12);
+    memcpy(rec + 3, base + i * v->stride + v->intensity_offset, 4);
+    if (binary) {
+      ok = fwrite(rec, sizeof(rec), 1, f) == 1;
+    } else {
+      for (int k = 0; k < 4; k++) {
+        if (std::isnan(rec[k])) ok = ok && fprintf(f, "nan%s", k < 3 ? " " : "\n") > 0;
+        else ok = ok && fprintf(f, "%.8g%s", (double)rec[k], k < 3 ? " " : "\n") > 0;
+      }
+    }
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? MI355_OK : MI355_EINVAL;
+}
+
+extern "C" int mi355_cloud_save_pcd(mi355_cloud* cloud, const char* path, int binary) {
+  if (!cloud || !path) return MI355_EINVAL;
+  std::vector<float> host(4 * std::max<size_t>(cloud->n, 1));
+  const int rc = mi355_cloud_download(cloud, host.data(), host.size() / 4);
+  if (rc != MI355_OK) return rc;
+  const mi355_cloud_view v{host.data(), cloud->n, 16, 12};
+  return mi355_pcd_write(path, &v, binary);
+}
+
 // caller-order device points of a cloud -> the registration object's staging (what the host-pointer entry points fill by upload)
 static void reg_take_cloud(mi355_reg* reg, mi355_cloud* cloud, DevBuf<float4>& stage, DevBuf<int>& cnt) {
   mi355_ctx* ctx = reg->ctx;

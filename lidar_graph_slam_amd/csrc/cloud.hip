@@ -1004,6 +1004,49 @@ void cov_from_caller_order(hipStream_t s, CloudSet& set, size_t n, const Cov6* i
   set.has_cov = true;
 }
 
+// ---- sensor_msgs/PointCloud2 <-> packed float4 -----------------------------------------------------------
+__device__ __forceinline__ float load_field_as_float(const unsigned char* p, int datatype) {
+  switch (datatype) {  // sensor_msgs/PointField datatypes; unaligned offsets are legal in a PointCloud2: assemble from bytes
+    case 1: return (float)(signed char)p[0];
+    case 2: return (float)p[0];
+    case 3: { short v; memcpy(&v, p, 2); return (float)v; }
+    case 4: { unsigned short v; memcpy(&v, p, 2); return (float)v; }
+    case 5: { int v; memcpy(&v, p, 4); return (float)v; }
+    case 6: { unsigned v; memcpy(&v, p, 4); return (float)v; }
+    case 8: { double v; memcpy(&v, p, 8); return (float)v; }
+    default: { float v; memcpy(&v, p, 4); return v; }
+  }
+}
+__global__ __launch_bounds__(256) void k_pc2_unpack(const unsigned char* __restrict__ raw, float4* __restrict__ out, uint32_t width, uint32_t height,
+                                                    uint32_t point_step, uint32_t row_step, int ox, int oy, int oz, int oi, int itype) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)width * height) return;
+  const unsigned char* p = raw + (i / width) * (size_t)row_step + (i % width) * (size_t)point_step;
+  float x, y, z;
+  memcpy(&x, p + ox, 4); memcpy(&y, p + oy, 4); memcpy(&z, p + oz, 4);
+  out[i] = make_float4(x, y, z, oi >= 0 ? load_field_as_float(p + oi, itype) : 0.f);
+}
+void pointcloud2_unpack(hipStream_t s, const unsigned char* d_raw, float4* out, uint32_t width, uint32_t height, uint32_t point_step,
+                        uint32_t row_step, int ox, int oy, int oz, int oi, int itype) {
+  const size_t n = (size_t)width * height;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pc2_unpack, dim3(div_up((long)n, 256)), dim3(256), 0, s, d_raw, out, width, height, point_step, row_step, ox, oy, oz, oi, itype);
+  MI_LAUNCH_CHECK();
+}
+// pcl::PointXYZI memory image: {x, y, z, 1.0f}, {intensity, 0, 0, 0}
+__global__ __launch_bounds__(256) void k_pc2_pack(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  out[2 * i] = make_float4(p.x, p.y, p.z, 1.0f);
+  out[2 * i + 1] = make_float4(p.w, 0.f, 0.f, 0.f);
+}
+void pointcloud2_pack(hipStream_t s, const float4* in, float4* out32, size_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pc2_pack, dim3(div_up((long)n, 256)), dim3(256), 0, s, in, out32, n);
+  MI_LAUNCH_CHECK();
+}
+
 // ---- order-preserving compaction --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact(const float4* __restrict__ in, const int* __restrict__ counts, const int* __restrict__ flags,
                                                  const int* __restrict__ local, const int* __restrict__ blockoff, const int* __restrict__ totals,

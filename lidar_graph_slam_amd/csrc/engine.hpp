@@ -97,6 +97,10 @@ void knn_query(hipStream_t s, const CloudSet& set, const float4* d_queries, int 
 void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, const float* T16_host);
 // device-resident clouds: rigid transform of points (+ covariances, C' = R C R^T, when cov_in != nullptr)
 void transform_points_cov(hipStream_t s, const float4* in, const Cov6* cov_in, float4* out, Cov6* cov_out, size_t n, const float* T16_host);
+// sensor_msgs/PointCloud2 bytes (device) <-> packed float4
+void pointcloud2_unpack(hipStream_t s, const unsigned char* d_raw, float4* out, uint32_t width, uint32_t height, uint32_t point_step,
+                        uint32_t row_step, int ox, int oy, int oz, int oi, int itype);
+void pointcloud2_pack(hipStream_t s, const float4* in, float4* out32, size_t n);
 // covariances of a built single-cloud set <-> the caller's point order
 void cov_to_caller_order(hipStream_t s, const CloudSet& set, size_t n, Cov6* out_caller);
 void cov_from_caller_order(hipStream_t s, CloudSet& set, size_t n, const Cov6* in_caller);

@@ -356,3 +356,41 @@ class NdtModel:
             if it > max_iterations or (it > 0 and step < transformation_epsilon):
                 return p, it + 1, True
             it += 1
+
+
+# ---------------------------------------------------------------- wire formats
+_PF_DTYPE = {1: "i1", 2: "u1", 3: "<i2", 4: "<u2", 5: "<i4", 6: "<u4", 7: "<f4", 8: "<f8"}
+
+
+def pointcloud2_unpack(msg: dict) -> np.ndarray:
+    """pcl::fromROSMsg into pcl::PointXYZI, restated with NumPy byte views: [n, 4] float32 (x, y, z, intensity)."""
+    raw = np.frombuffer(msg["data"], dtype=np.uint8)
+    w, h, ps, rs = msg["width"], msg["height"], msg["point_step"], msg["row_step"]
+    out = np.zeros((w * h, 4), np.float32)
+    rows = raw[: rs * h].reshape(h, rs)[:, : w * ps].reshape(h * w, ps)
+    for k, name in enumerate(("x", "y", "z", "intensity")):
+        if name not in msg["fields"]:
+            continue
+        off, dt = msg["fields"][name]
+        size = np.dtype(_PF_DTYPE[dt]).itemsize
+        out[:, k] = np.ascontiguousarray(rows[:, off : off + size]).view(_PF_DTYPE[dt])[:, 0].astype(np.float32)
+    return out
+
+
+def pointcloud2_pack_xyzi(points: np.ndarray) -> bytes:
+    """pcl::toROSMsg of pcl::PointXYZI points: 32-byte records {x, y, z, 1.0f, intensity, 0, 0, 0}."""
+    p = np.asarray(points, dtype=np.float32)
+    rec = np.zeros((len(p), 8), np.float32)
+    rec[:, :3] = p[:, :3]
+    rec[:, 3] = 1.0
+    rec[:, 4] = p[:, 3]
+    return rec.tobytes()
+
+
+def pcd_ascii(points: np.ndarray) -> str:
+    """What pcl::io::savePCDFile(path, cloud) (ASCII) writes for pcl::PointXYZI points: `fs.precision(8)` stream output."""
+    p = np.asarray(points, dtype=np.float32)
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+            f"WIDTH {len(p)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(p)}\nDATA ascii\n")
+    fmt = lambda v: "nan" if np.isnan(v) else ("%.8g" % float(v))  # noqa: E731
+    return head + "".join(" ".join(fmt(v) for v in row) + "\n" for row in p)
