@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = [pytest.mark.gpu, pytest.mark.children_only]
 
-ARGS = ["--candidates", "12", "--submaps", "3", "--casts-per-submap", "2", "--n-azimuth", "256", "--capacity", "32768", "--min-good", "0"]
+ARGS = ["--candidates", "12", "--submaps", "3", "--casts-per-submap", "2", "--n-azimuth", "256", "--capacity", "65536", "--min-good", "0"]
 
 
 def _run(cmd, env):
