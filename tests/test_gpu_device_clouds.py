@@ -10,13 +10,6 @@ from oracle import oracle_py as O
 pytestmark = pytest.mark.gpu
 
 
-def _cov6_to_33(c):
-    M = np.zeros((len(c), 3, 3))
-    M[:, 0, 0], M[:, 0, 1], M[:, 0, 2], M[:, 1, 1], M[:, 1, 2], M[:, 2, 2] = c.T
-    M[:, 1, 0], M[:, 2, 0], M[:, 2, 1] = M[:, 0, 1], M[:, 0, 2], M[:, 1, 2]
-    return M
-
-
 def test_transform_and_concat_are_bit_equal_to_the_oracle(small_pair):
     from lidar_graph_slam_amd.registration import DeviceCloud
 
@@ -58,8 +51,8 @@ def test_covariances_follow_the_key_frame_rigidly(small_pair):
     dt, dr = synth.pose_error(a.getFinalTransformation(), b.getFinalTransformation())
     assert dt <= 2e-4 and dr <= 2e-5, (dt, dr)
     # and numerically: R C R^T of the device covariances vs covariances computed on the transformed cloud
-    c0 = _cov6_to_33(F.covariances(s, 20))
-    c1 = _cov6_to_33(F.covariances(O.transform(s, T), 20))
+    c0 = F.covariances(s, 20).astype(np.float64)
+    c1 = F.covariances(O.transform(s, T), 20).astype(np.float64)
     R = T[:3, :3].astype(np.float64)
     np.testing.assert_allclose(R @ c0 @ R.T, c1, atol=2e-5)
 
