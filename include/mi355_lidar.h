@@ -40,7 +40,8 @@ typedef struct mi355_cloud_view {
 } mi355_cloud_view;
 
 /* registration_method of lidar_scan_matcher.param.yaml:4 / lidar_scan_matcher.cpp:37,55 */
-enum { MI355_METHOD_FAST_GICP = 0, MI355_METHOD_NDT_OMP = 1 };
+enum { MI355_METHOD_FAST_GICP = 0, MI355_METHOD_NDT_OMP = 1,
+       MI355_METHOD_ICP = 2 /* pcl::IterativeClosestPoint: the back end's default (graph_based_slam.param.yaml:9, cpp:142-151) */ };
 /* fast_gicp::RegularizationMethod (default PLANE) */
 enum { MI355_REG_NONE = 0, MI355_REG_MIN_EIG = 1, MI355_REG_NORMALIZED_MIN_EIG = 2, MI355_REG_PLANE = 3, MI355_REG_FROBENIUS = 4 };
 /* fast_gicp::LSQ_OPTIMIZER_TYPE (default LevenbergMarquardt) */
@@ -78,6 +79,16 @@ typedef struct mi355_ndt_params {
   int num_threads;               /* unused on the GPU */
 } mi355_ndt_params;
 
+/* pcl::IterativeClosestPoint as graph_based_slam.cpp:142-151 configures it (the setters' values are the defaults here). */
+typedef struct mi355_icp_params {
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance(30): a pair is kept iff d2 <= max^2 */
+  int max_iterations;                 /* setMaximumIterations(100); reaching it counts as converged (DefaultConvergenceCriteria) */
+  double transformation_epsilon;      /* setTransformationEpsilon(1e-8): compared with the SQUARED incremental translation */
+  double euclidean_fitness_epsilon;   /* setEuclideanFitnessEpsilon(1e-6): relative change of the mean squared distance */
+  double rotation_epsilon;            /* 0: PCL's default, cos(angle) >= 1 - transformation_epsilon */
+  int ransac_iterations;              /* setRANSACIterations(0): only 0 (no outlier rejector) is built */
+} mi355_icp_params;
+
 /* points_prefiltering parameters — points_prefiltering.launch.xml:2-13. */
 typedef struct mi355_prefilter_params {
   double min_distance;   /* min_distance_cloud 1.0; <= 0 disables the distance filter (points_prefiltering.cpp:102-112) */
@@ -107,6 +118,7 @@ typedef struct mi355_result {
 void mi355_gicp_default_params(mi355_gicp_params* p);
 void mi355_ndt_default_params(mi355_ndt_params* p);
 void mi355_prefilter_default_params(mi355_prefilter_params* p);
+void mi355_icp_default_params(mi355_icp_params* p);
 
 /* ---- context ------------------------------------------------------------------------------------------- */
 mi355_ctx* mi355_create(int device_id);
@@ -145,7 +157,8 @@ int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, int k, int me
 
 /* ---- registration object: replaces pcl::Registration<PointXYZI,PointXYZI>::Ptr registration_ ----------- */
 /* new fast_gicp::FastGICP / new pclomp::NormalDistributionsTransform (lidar_scan_matcher.cpp:38-39,56-57;
- * graph_based_slam.cpp:84-85,103-104).  params: mi355_gicp_params* or mi355_ndt_params* (NULL = defaults). */
+ * graph_based_slam.cpp:84-85,103-104) / new pcl::IterativeClosestPoint (graph_based_slam.cpp:143-144).
+ * params: mi355_gicp_params*, mi355_ndt_params* or mi355_icp_params* by method (NULL = defaults). */
 mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* params);
 void mi355_reg_destroy(mi355_reg* reg);
 int mi355_reg_set_params(mi355_reg* reg, const void* params);

@@ -97,6 +97,8 @@ struct mi355_reg {
   int method = MI355_METHOD_FAST_GICP;
   mi355_gicp_params gp;
   mi355_ndt_params np;
+  mi355_icp_params ip;
+  IcpScratch icp;
   Workspace ws;
   Uploader up;
   DevBuf<float4> stage_src, stage_tgt;
@@ -192,6 +194,14 @@ extern "C" void mi355_ndt_default_params(mi355_ndt_params* p) {
   // default; 0 selects the `< 0` test of PCL >= 1.10 (the line search iterates).
   p->legacy_mt_skip = 1;
   p->num_threads = 0;
+}
+extern "C" void mi355_icp_default_params(mi355_icp_params* p) {  // graph_based_slam.cpp:146-150
+  p->max_correspondence_distance = 30.0;
+  p->max_iterations = 100;
+  p->transformation_epsilon = 1e-8;
+  p->euclidean_fitness_epsilon = 1e-6;
+  p->rotation_epsilon = 0.0;
+  p->ransac_iterations = 0;
 }
 extern "C" void mi355_prefilter_default_params(mi355_prefilter_params* p) {
   p->min_distance = 1.0;
@@ -466,15 +476,17 @@ extern "C" int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, in
 
 // ---- registration object -------------------------------------------------------------------------------------------
 extern "C" mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* params) {
-  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP)) return nullptr;
+  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP)) return nullptr;
   auto* r = new mi355_reg();
   r->ctx = ctx;
   r->method = method;
   mi355_gicp_default_params(&r->gp);
   mi355_ndt_default_params(&r->np);
+  mi355_icp_default_params(&r->ip);
   if (params) {
     if (method == MI355_METHOD_FAST_GICP) r->gp = *(const mi355_gicp_params*)params;
-    else r->np = *(const mi355_ndt_params*)params;
+    else if (method == MI355_METHOD_NDT_OMP) r->np = *(const mi355_ndt_params*)params;
+    else r->ip = *(const mi355_icp_params*)params;
   }
   if (method == MI355_METHOD_NDT_OMP) r->ndt = ndt_target_create();
   for (int i = 0; i < 16; i++) r->last_T[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -494,6 +506,12 @@ extern "C" int mi355_reg_set_params(mi355_reg* reg, const void* params) {
     const int old_k = reg->gp.k_correspondences, old_m = reg->gp.regularization_method;
     reg->gp = *(const mi355_gicp_params*)params;
     if (old_k != reg->gp.k_correspondences || old_m != reg->gp.regularization_method) { reg->src.has_cov = false; reg->tgt.has_cov = false; }
+  } else if (reg->method == MI355_METHOD_ICP) {
+    reg->ip = *(const mi355_icp_params*)params;
+    if (reg->ip.ransac_iterations != 0) {
+      reg->ctx->err = "ICP: only setRANSACIterations(0) (graph_based_slam.cpp:150) is built";
+      return MI355_EINVAL;
+    }
   } else {
     // pclomp re-initialises its voxel grid only when the grid itself changes (setResolution and friends), and does so from
     // the target it already holds: the other setters (iterations, epsilon, step size, threads) leave the target alone
@@ -537,6 +555,9 @@ extern "C" int mi355_reg_set_target(mi355_reg* reg, const mi355_cloud_view* clou
       reg->tgt.alloc(1, reg->n_tgt);
       build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
       compute_covariances(ctx->stream, reg->tgt, reg->gp.k_correspondences, reg->gp.regularization_method);
+    } else if (reg->method == MI355_METHOD_ICP) {  // the NN structure is all point-to-point ICP needs
+      reg->tgt.alloc(1, reg->n_tgt);
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
     } else {
       ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
       // getFitnessScore needs the NN structure of the target as well
@@ -585,6 +606,12 @@ extern "C" int mi355_reg_align(mi355_reg* reg, const float guess16[16], mi355_re
     if (reg->method == MI355_METHOD_FAST_GICP) {
       gicp_align(ctx->stream, reg->gb, reg->src, reg->tgt, reg->gp, nullptr, guess16);
       gicp_results(ctx->stream, reg->gb, reg->src, reg->tgt, result, nullptr);
+    } else if (reg->method == MI355_METHOD_ICP) {
+      float I[16];
+      for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
+      icp_align(ctx->stream, reg->icp, reg->tgt, reg->stage_src.p, reg->n_src, reg->ip, guess16 ? guess16 : I, result);
+      result->n_source = (int)reg->n_src;
+      result->n_target = (int)reg->n_tgt;
     } else {
       float I[16];
       for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -907,6 +934,9 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
       const bool carried = cloud->has_cov && cloud->cov_k == reg->gp.k_correspondences && cloud->cov_method == reg->gp.regularization_method;
       if (carried) cov_from_caller_order(ctx->stream, reg->tgt, reg->n_tgt, cloud->cov.p);
       else compute_covariances(ctx->stream, reg->tgt, reg->gp.k_correspondences, reg->gp.regularization_method);
+    } else if (reg->method == MI355_METHOD_ICP) {
+      reg->tgt.alloc(1, reg->n_tgt);
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
     } else {
       ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
       reg->tgt.alloc(1, reg->n_tgt);

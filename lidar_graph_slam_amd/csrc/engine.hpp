@@ -139,6 +139,16 @@ void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
 void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T16,
                          double* H36, double* b6, double* err, int* corr_caller_order);
 
+// ---- icp.hip -------------------------------------------------------------------------------------------------
+struct IcpScratch {
+  DevBuf<float4> cur;        // the source as moved so far (input_transformed)
+  DevBuf<double> partials, sums;
+  PinnedBuf<double> h_sums;
+};
+// pcl::IterativeClosestPoint::align: source `d_src` (caller order, n points) against a built target set
+void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4* d_src, size_t n, const mi355_icp_params& p, const float* guess16,
+               mi355_result* out);
+
 // ---- ndt.hip -------------------------------------------------------------------------------------------------
 struct NdtTarget;
 struct NdtState;

@@ -242,6 +242,25 @@ class NormalDistributionsTransform(_Registration):
         return {"idx": idx[:k], "n": cnt[:k], "mean": mean[:k], "cov": cov[:k], "icov": icov[:k], "min_b": min_b, "div_b": div_b}
 
 
+class IterativeClosestPoint(_Registration):
+    """pcl::IterativeClosestPoint<PointXYZI,PointXYZI>: the back end's default registration method
+    (graph_based_slam.param.yaml:9; graph_based_slam.cpp:142-151: the defaults here are that block's setter values)."""
+
+    _method = L.METHOD_ICP
+
+    def __init__(self, ctx: Context | None = None, **params):
+        super().__init__(L.icp_params(**params), ctx)
+
+    def setMaxCorrespondenceDistance(self, d):
+        self._set(max_correspondence_distance=float(d))
+
+    def setEuclideanFitnessEpsilon(self, e):
+        self._set(euclidean_fitness_epsilon=float(e))
+
+    def setRANSACIterations(self, n):
+        self._set(ransac_iterations=int(n))
+
+
 class BatchRegistration:
     """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one GICP per pair."""
 

@@ -394,3 +394,41 @@ def pcd_ascii(points: np.ndarray) -> str:
             f"WIDTH {len(p)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(p)}\nDATA ascii\n")
     fmt = lambda v: "nan" if np.isnan(v) else ("%.8g" % float(v))  # noqa: E731
     return head + "".join(" ".join(fmt(v) for v in row) + "\n" for row in p)
+
+
+# ---------------------------------------------------------------- pcl::IterativeClosestPoint
+def icp_align(src, tgt, guess=None, max_correspondence_distance=30.0, max_iterations=100, transformation_epsilon=1e-8,
+              euclidean_fitness_epsilon=1e-6):
+    """Independent restatement (cKDTree + Kabsch by numpy SVD) of the ICP loop oracle_icp.cpp restates: (T float32, converged,
+    iterations)."""
+    from scipy.spatial import cKDTree
+
+    tree = cKDTree(np.asarray(tgt[:, :3], dtype=np.float64))
+    T = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, dtype=np.float32).copy()
+    cur = (src[:, :3].astype(np.float32) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    prev_mse, it = np.finfo(np.float64).max, 0
+    rot_thr = 1.0 - transformation_epsilon
+    while True:
+        d, j = tree.query(cur.astype(np.float64), k=1)
+        ok = d * d <= max_correspondence_distance ** 2
+        if ok.sum() < 3:
+            return T, False, it
+        P, Q = cur[ok].astype(np.float64), np.asarray(tgt[j[ok], :3], dtype=np.float64)
+        mp, mq = P.mean(0), Q.mean(0)
+        U, _, Vt = np.linalg.svd((P - mp).T @ (Q - mq))
+        R = Vt.T @ np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))]) @ U.T
+        Ti = np.eye(4)
+        Ti[:3, :3], Ti[:3, 3] = R, mq - R @ mp
+        Ti = Ti.astype(np.float32)
+        cur = (cur @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+        T = (Ti @ T).astype(np.float32)
+        it += 1
+        if it >= max_iterations:
+            return T, True, it
+        cos_angle = 0.5 * (float(Ti[0, 0]) + float(Ti[1, 1]) + float(Ti[2, 2]) - 1.0)
+        if cos_angle >= rot_thr and float((Ti[:3, 3].astype(np.float64) ** 2).sum()) <= transformation_epsilon:
+            return T, True, it
+        mse = float((d[ok] ** 2).mean())
+        if abs(mse - prev_mse) < 1e-12 or abs(mse - prev_mse) / prev_mse < euclidean_fitness_epsilon:
+            return T, True, it
+        prev_mse = mse

@@ -108,6 +108,20 @@ int orc_ndt_derivatives(const float* src, size_t n, const float* tgt, size_t m, 
 int orc_ndt_align(const float* src, size_t n, const float* tgt, size_t m, const orc_ndt_params* p,
                   const float* guess16, orc_result* r);
 
+/* ---- pcl::IterativeClosestPoint (the back end's default method, graph_based_slam.cpp:142-151) ---- */
+typedef struct orc_icp_params {
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance(30) */
+  int max_iterations;                 /* setMaximumIterations(100) */
+  double transformation_epsilon;      /* setTransformationEpsilon(1e-8): compared with the SQUARED incremental translation */
+  double euclidean_fitness_epsilon;   /* setEuclideanFitnessEpsilon(1e-6): relative MSE change */
+  double rotation_epsilon;            /* 0 = PCL's default: cos threshold 1 - transformation_epsilon */
+  int num_threads;
+} orc_icp_params;
+void orc_icp_default_params(orc_icp_params* p);
+/* least-squares rigid fit from the 17 correspondence sums (n, sum p, sum q, sum p q^T, sum d2): T16 row-major */
+int orc_rigid_from_sums(const double* sums17, double* T16);
+int orc_icp_align(const float* src, size_t n, const float* tgt, size_t m, const orc_icp_params* p, const float* guess16, orc_result* r);
+
 #ifdef __cplusplus
 }
 #endif

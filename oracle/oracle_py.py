@@ -271,3 +271,38 @@ def ndt_align(src, tgt, params: NdtParams | None = None, guess=None):
                              _p(g, C.c_float), C.byref(r))
     assert rc == 0, rc
     return _result(r)
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iterations", C.c_int), ("transformation_epsilon", C.c_double),
+                ("euclidean_fitness_epsilon", C.c_double), ("rotation_epsilon", C.c_double), ("num_threads", C.c_int)]
+
+
+def icp_params(**kw) -> IcpParams:
+    p = IcpParams()
+    lib().orc_icp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def rigid_from_sums(sums17):
+    s = np.ascontiguousarray(sums17, dtype=np.float64).reshape(17)
+    T = np.empty(16)
+    rc = lib().orc_rigid_from_sums(_p(s, C.c_double), _p(T, C.c_double))
+    return T.reshape(4, 4), rc
+
+
+def icp_align(src, tgt, params: IcpParams | None = None, guess=None):
+    """pcl::IterativeClosestPoint::align as the back end configures it (graph_based_slam.cpp:142-151)."""
+    src, tgt = _f4(src), _f4(tgt)
+    params = params or icp_params()
+    g = np.eye(4, dtype=np.float32) if guess is None else np.ascontiguousarray(guess, dtype=np.float32)
+    g = g.reshape(16)
+    r = Result()
+    rc = lib().orc_icp_align(_p(src, C.c_float), C.c_size_t(len(src)), _p(tgt, C.c_float), C.c_size_t(len(tgt)), C.byref(params),
+                             _p(g, C.c_float), C.byref(r))
+    assert rc == 0, rc
+    return _result(r)
