@@ -313,3 +313,42 @@ def test_batches_on_their_own_streams(R, small_pair):
     batches[0].align()
     for g, w in zip([r["T"] for r in batches[0].results()], want):
         np.testing.assert_array_equal(g, w)
+
+
+def test_icp_matches_the_oracle(R, small_pair, medium_pair):
+    """SURVEY 8f-4: pcl::IterativeClosestPoint (the back end's default method, graph_based_slam.cpp:142-151) on the device vs
+    the oracle's restatement: iteration by iteration the same pose; with PCL's stopping rules both converge near the same
+    pose (the stopping iteration hinges on the last bits of the mean squared distance)."""
+    s, t, T_gt = small_pair
+    src, tgt, _ = medium_pair
+    s2, t2 = O.voxel_grid(O.distance_filter(src, 1.0), 0.2)[0], O.voxel_grid(O.distance_filter(tgt, 1.0), 0.2)[0]
+    for a, b in ((s, t), (s2, t2)):
+        for guess in (None, (T_gt @ synth.se3(0.05, -0.03, 0.0, 0, 0, 0.004)).astype(np.float32)):
+            for k in (1, 4, 12):
+                icp = R.IterativeClosestPoint(max_iterations=k)
+                icp.setInputTarget(b)
+                icp.setInputSource(a)
+                icp.align(guess)
+                ref = O.icp_align(a, b, O.icp_params(max_iterations=k), guess=guess)
+                assert icp.hasConverged() and icp.result["iterations"] == ref["iterations"] == k
+                dt, dr = synth.pose_error(icp.getFinalTransformation(), ref["T"])
+                assert dt <= 2e-5 and dr <= 2e-6, (k, dt, dr)
+            icp = R.IterativeClosestPoint()
+            icp.setInputTarget(b)
+            icp.setInputSource(a)
+            icp.align(guess)
+            ref = O.icp_align(a, b, O.icp_params(), guess=guess)
+            assert icp.hasConverged() and ref["converged"]
+            dt, dr = synth.pose_error(icp.getFinalTransformation(), ref["T"])
+            assert dt <= 0.02 and dr <= 1e-3, (dt, dr)
+            np.testing.assert_allclose(icp.getFitnessScore(), O.fitness(a, b, icp.getFinalTransformation()), rtol=1e-6)
+    far = s.copy()
+    far[:, :3] += 1000.0  # nothing within 30 m: "Not enough correspondences found"
+    icp = R.IterativeClosestPoint()
+    icp.setInputTarget(t)
+    icp.setInputSource(far)
+    icp.align()
+    assert not icp.hasConverged() and icp.result["iterations"] == 0
+    with pytest.raises(Exception):
+        bad = R.IterativeClosestPoint(ransac_iterations=5)
+        bad.setInputTarget(t)
