@@ -330,7 +330,7 @@ def test_icp_matches_the_oracle(R, small_pair, medium_pair):
                 icp.setInputSource(a)
                 icp.align(guess)
                 ref = O.icp_align(a, b, O.icp_params(max_iterations=k), guess=guess)
-                assert icp.hasConverged() and icp.result["iterations"] == ref["iterations"] == k
+                assert icp.hasConverged() and icp.result["iterations"] == ref["iterations"] <= k  # (the stopping rules may end it earlier)
                 dt, dr = synth.pose_error(icp.getFinalTransformation(), ref["T"])
                 assert dt <= 2e-5 and dr <= 2e-6, (k, dt, dr)
             icp = R.IterativeClosestPoint()
