@@ -488,6 +488,11 @@ extern "C" mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* p
     else if (method == MI355_METHOD_NDT_OMP) r->np = *(const mi355_ndt_params*)params;
     else r->ip = *(const mi355_icp_params*)params;
   }
+  if (method == MI355_METHOD_ICP && r->ip.ransac_iterations != 0) {
+    ctx->err = "ICP: only setRANSACIterations(0) (graph_based_slam.cpp:150) is built";
+    delete r;
+    return nullptr;
+  }
   if (method == MI355_METHOD_NDT_OMP) r->ndt = ndt_target_create();
   for (int i = 0; i < 16; i++) r->last_T[i] = (i % 5 == 0) ? 1.f : 0.f;
   return r;
