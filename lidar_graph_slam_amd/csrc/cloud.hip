@@ -370,23 +370,23 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
-// Bitonic sort of the wave's lanes by one coordinate of (x, y, z), ascending inside every aligned segment of S lanes; the
-// coordinate (axis 0 / 1 / 2) is the same for all lanes of a segment.  (x, y, z, i) travel together.
+// Bitonic sort of the wave's lanes by a float key, ascending inside every aligned segment of S lanes.  Only (key, src) travel
+// — src = the lane that held the point originally — so a compare-exchange stage costs two lane exchanges, not four.
 template <int S>
-__device__ __forceinline__ void segment_sort_lanes(float& x, float& y, float& z, int& i, int axis) {
+__device__ __forceinline__ void segment_sort_lanes(float& key, int& src) {
   const int lane = lane_id();
 #pragma unroll
   for (int k = 2; k <= S; k <<= 1) {
 #pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      const float px = __shfl_xor(x, j, kWave), py = __shfl_xor(y, j, kWave), pz = __shfl_xor(z, j, kWave);
-      const int pi = __shfl_xor(i, j, kWave);
-      const float mine = (axis == 0) ? x : ((axis == 1) ? y : z), theirs = (axis == 0) ? px : ((axis == 1) ? py : pz);
+      const float pk = __shfl_xor(key, j, kWave);
+      const int ps = __shfl_xor(src, j, kWave);
       const bool up = ((lane & k) == 0) || (k == S);  // the last merge is ascending in every segment
       const bool lower = (lane & j) == 0;
       // the lower lane of a pair keeps the smaller key in an ascending block; equal keys stay where they are
-      const bool take = (lower == up) ? (theirs < mine) : (theirs > mine);
-      x = take ? px : x; y = take ? py : y; z = take ? pz : z; i = take ? pi : i;
+      const bool take = (lower == up) ? (pk < key) : (pk > key);
+      key = take ? pk : key;
+      src = take ? ps : src;
     }
   }
 }
@@ -409,9 +409,20 @@ __device__ __forceinline__ int segment_longest_axis(float x, float y, float z) {
 // spatially compact.  64 consecutive points of the Morton curve are NOT: the curve jumps, and one ragged group of 8 sets
 // the trip count of the whole wave's ranking loop (measured: mean sub-list 77 candidates, longest 182).
 __device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int& i) {
-  segment_sort_lanes<64>(x, y, z, i, segment_longest_axis<64>(x, y, z));
-  segment_sort_lanes<32>(x, y, z, i, segment_longest_axis<32>(x, y, z));
-  segment_sort_lanes<16>(x, y, z, i, segment_longest_axis<16>(x, y, z));
+  const float x0 = x, y0 = y, z0 = z;
+  const int i0 = i;
+  int src = lane_id();
+  auto level = [&](auto seg) {
+    constexpr int S = decltype(seg)::value;
+    const int axis = segment_longest_axis<S>(x, y, z);
+    float key = (axis == 0) ? x : ((axis == 1) ? y : z);
+    segment_sort_lanes<S>(key, src);
+    x = __shfl(x0, src, kWave); y = __shfl(y0, src, kWave); z = __shfl(z0, src, kWave);
+  };
+  level(std::integral_constant<int, 64>{});
+  level(std::integral_constant<int, 32>{});
+  level(std::integral_constant<int, 16>{});
+  i = __shfl(i0, src, kWave);
 }
 
 // Launch: one-wave blocks, G per cloud (all on the cloud's XCD); a wave takes tiles from the cloud's counter until none
@@ -525,17 +536,25 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           // round, i.e. lies inside (sub-box + rs) but not inside (sub-box + rs_old).  One step tests kSubQ candidates against
           // all kNSub boxes: lane (s, j) tests candidate base + j against the box of ITS sub-tile s, one ballot gives every
           // sub-tile its 8 hit bits, and the hits are appended to the sub-tile's list in candidate order.
-          for (int base = 0; base < n_ord; base += kSubQ) {
-            const int o = base + sublane;
-            const float4 p = cand[min(o, kTileMaxCand - 1)];
-            // Chebyshev distance of p to the sub-box (<= 0 inside)
-            const float m = fmaxf(fmaxf(fabsf(p.x - scx) - shx, fabsf(p.y - scy) - shy), fabsf(p.z - scz) - shz);
-            const bool in = take && (o < n_ord) && (m <= rs) && !(m <= rs_old);
-            const unsigned long long mask = __ballot(in);
-            const uint32_t hits = (uint32_t)(mask >> (mysub * kSubQ)) & ((1u << kSubQ) - 1u);
-            const int at = slen + __popc(hits & ((1u << sublane) - 1u));
-            if (in && at < kSubCap) sub[mysub][at] = (uint16_t)(o << 4);  // byte offset of the candidate in cand[]
-            slen += __popc(hits);  // may run past kSubCap
+          // (four steps per trip: the four LDS reads and box tests are independent, only the list offsets chain)
+          for (int base = 0; base < n_ord; base += 4 * kSubQ) {
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int o = base + u * kSubQ + sublane;
+              const float4 p = cand[min(o, kTileMaxCand - 1)];
+              // Chebyshev distance of p to the sub-box (<= 0 inside)
+              const float m = fmaxf(fmaxf(fabsf(p.x - scx) - shx, fabsf(p.y - scy) - shy), fabsf(p.z - scz) - shz);
+              in[u] = take && (o < n_ord) && (m <= rs) && !(m <= rs_old);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const unsigned long long mask = __ballot(in[u]);
+              const uint32_t hits = (uint32_t)(mask >> (mysub * kSubQ)) & ((1u << kSubQ) - 1u);
+              const int at = slen + __popc(hits & ((1u << sublane) - 1u));
+              if (in[u] && at < kSubCap) sub[mysub][at] = (uint16_t)((base + u * kSubQ + sublane) << 4);  // byte offset of the candidate in cand[]
+              slen += __popc(hits);  // may run past kSubCap
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           // a FIRST list that does not fit is rebuilt with half the radius (the growth rounds bring back what a lane needs);

@@ -139,7 +139,10 @@ __device__ __forceinline__ void tile_geometry(int n, int& nt, int& tl) {
   tl = (((n + nt - 1) / nt) + kWave - 1) / kWave * kWave;
 }
 
+// A cloud of ONE tile is written straight to (keys_final, vals_final) — where the merge rounds would deliver it — and the merge
+// kernels skip it: a voxelised scan costs one launch's worth of traffic, not three.
 __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
+                                                          uint32_t* __restrict__ keys_final, int* __restrict__ vals_final,
                                                           const int* __restrict__ counts, size_t cap, int passes) {
   __shared__ uint32_t keyL[kTsTile];
   __shared__ uint16_t idxL[kTsTile];
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   int nt, tl;
   tile_geometry(n, nt, tl);
   if ((int)blockIdx.x >= nt) return;
+  if (nt == 1) { keys_out = keys_final; vals_out = vals_final; }
   const int base = blockIdx.x * tl;
   const int len = max(0, min(tl, n - base));
   const int w = wave_id(), l = lane_id();
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
   if (o0 >= n) return;
   int nt, tl;
   tile_geometry(n, nt, tl);
+  if (nt == 1) return;  // already in its final place (k_sort_tile)
   const size_t o = (size_t)c * cap;
   const uint32_t* K = keys_in + o;
   const int* V = vals_in + o;
@@ -319,8 +324,12 @@ void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_co
   const int max_tiles = div_up((long)cap, kTsTile);
   if (max_tiles <= 4) {
     // tile sort a -> b, then ceil(log2(max_tiles)) merge rounds ping-ponging; an odd number of hops ends in b: swap the handles
-    hipLaunchKernelGGL(k_sort_tile, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p, d_counts, cap, passes);
     int hops = 1;
+    for (int run = 1; run < max_tiles; run *= 2) hops++;
+    // after `hops` hops (a -> b -> a ...) the result sits in b when hops is odd
+    hipLaunchKernelGGL(k_sort_tile, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
+                       (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes);
+    hops = 1;
     uint32_t* ki = ws.keys_b.p; uint32_t* ko = ws.keys_a.p;
     int* vi = ws.vals_b.p; int* vo = ws.vals_a.p;
     for (int run = 1; run < max_tiles; run *= 2) {
