@@ -14,6 +14,7 @@
 #include "engine.hpp"
 #include "grid.hpp"
 #include "primitives.hpp"
+#include "tile.hpp"
 
 namespace mi355 {
 
@@ -123,65 +124,168 @@ __device__ __forceinline__ void residual(const Pose& x, const float4& p, const f
   ex = (float)dex; ey = (float)dey; ez = (float)dez;
 }
 
-// Full (re-)search of one source point: exact nearest neighbour in the target + how far the query may move before the
-// answer can change.  Seeded with the previous correspondent when there is one.
-__device__ __forceinline__ void search_point(const GridView& g, float qx, float qy, float qz, int jprev, float max_corr_d2, bool track_margin,
-                                             int& j_out, float& margin_out) {
-  const float max_corr = sqrtf(max_corr_d2);
+// ---- correspondence search of one source point -----------------------------------------------------------------------
+// State of a search: nearest (d1, j1), runner-up distance d2nd, the squared radius inside which everything has been seen.
+struct NnState {
+  float d1;
+  int j1;
+  float d2nd;
+  float explored2;
+  bool complete;  // explored2 covers what the result needs
+};
+constexpr int kLaneLevelCap = 1;  // per-lane searches stop at the 2 x base-cell level (shells r <= 1 there cover >= one cell edge)
+
+// From a finished search: the correspondence and how far the query may move before the answer can change.
+__device__ __forceinline__ void finish_search(const NnState& st, float max_corr_d2, bool track_margin, int& j_out, float& margin_out) {
   if (!track_margin) {
-    // The pose is still moving by more than any margin could absorb: plain exact 1-NN (prunes with the best distance, not
-    // the runner-up), seeded with the previous correspondent and started at the level whose cell is about that far.
-    Nearest1 nn{g.orig, INFINITY, -1};
-    int level0 = 0;
-    if (jprev >= 0 && jprev < g.m.n) {
-      const float4 pp = g.pts[jprev];
-      nn.best_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
-      nn.best_j = jprev;
-      const float rel = sqrtf(nn.best_d2) * g.m.inv_cell;
-      level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
-    }
-    grid_search(g, qx, qy, qz, max_corr_d2, nn, level0, 1);
-    j_out = (nn.best_j >= 0 && nn.best_d2 < max_corr_d2) ? nn.best_j : -1;
-    margin_out = 0.f;  // search again next iteration
+    j_out = (st.j1 >= 0 && st.d1 < max_corr_d2) ? st.j1 : -1;
+    margin_out = 1.0e-30f;  // the answer holds for THIS pose only: search again at the next one
     return;
   }
-  Nearest2 nn{g.orig, INFINITY, -1, INFINITY, INFINITY};
-  float explored2;
-  if (jprev >= 0 && jprev < g.m.n) {
-    const float4 pp = g.pts[jprev];
-    nn.d1 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
-    nn.j1 = jprev;
-  }
-  if (nn.j1 >= 0 && nn.d1 < 0.36f * g.m.cell * g.m.cell) {
-    // close seed: scan the ball a little larger than the seed distance (so that an isolated nearest neighbour still
-    // earns a non-zero margin) — a handful of base cells
-    const float r = sqrtf(nn.d1) * 1.25f + 0.02f;
-    nn.limit = r * r;
-    grid_ball_search(g, qx, qy, qz, nn, 2.1f);
-    explored2 = nn.limit;
-  } else if (nn.j1 >= 0 && nn.d1 < max_corr_d2) {
-    // far seed (sparse far field): shell search started at the level whose cell is about the seed distance
-    const float rel = sqrtf(nn.d1) * g.m.inv_cell;
-    const int level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
-    explored2 = grid_search(g, qx, qy, qz, max_corr_d2, nn, level0, 1);
-  } else {
-    // no seed / nothing in range so far: shell search with escalation.  The bound reaches a little past max_corr so that a
-    // point with nothing in range learns HOW far the nearest thing is and is not searched again at every iteration.
-    const float ext = max_corr + 0.25f * g.m.cell + 0.25f;
-    explored2 = grid_search(g, qx, qy, qz, isfinite(max_corr) ? ext * ext : INFINITY, nn, 0, 2);
-  }
+  const float max_corr = sqrtf(max_corr_d2);
   float margin;
-  if (nn.j1 >= 0 && nn.d1 < max_corr_d2) {
-    j_out = nn.j1;
+  if (st.j1 >= 0 && st.d1 < max_corr_d2) {
+    j_out = st.j1;
     // the correspondent stays the nearest while the query moves less than half the gap to the runner-up, and stays in range
     // while it moves less than its distance to the range limit: one margin covers both, so an unmoved point is never touched
-    margin = fminf(0.5f * (sqrtf(fminf(nn.d2nd, explored2)) - sqrtf(nn.d1)), max_corr - sqrtf(nn.d1));
+    margin = fminf(0.5f * (sqrtf(fminf(st.d2nd, st.explored2)) - sqrtf(st.d1)), max_corr - sqrtf(st.d1));
   } else {
     // nothing within range: stays so until the query has moved by (distance to the nearest thing) - max_corr
     j_out = -1;
-    margin = sqrtf(fminf(nn.j1 >= 0 ? nn.d1 : INFINITY, fmaxf(explored2, max_corr_d2))) - max_corr;
+    margin = sqrtf(fminf(st.j1 >= 0 ? st.d1 : INFINITY, fmaxf(st.explored2, max_corr_d2))) - max_corr;
   }
   margin_out = margin * (1.f - 1e-4f) - 1e-5f;  // fp32 slack
+}
+
+// squared radius a correspondence search has to cover: max_corr, or a little past it when margins are tracked — a point
+// with nothing in range then learns HOW far the nearest thing is and is not searched again at every iteration
+__device__ __forceinline__ float search_reach2(const GridView& g, float max_corr_d2, bool track_margin) {
+  if (!track_margin || !isfinite(max_corr_d2)) return max_corr_d2;
+  const float ext = sqrtf(max_corr_d2) + 0.25f * g.m.cell + 0.25f;
+  return ext * ext;
+}
+
+// Per-lane part: seeded with the previous correspondent, bounded to the fine levels.  st.complete == false: the query is handed
+// to coop_search (the whole wave searches for it).
+__device__ __forceinline__ NnState lane_search(const GridView& g, float qx, float qy, float qz, int jprev, float max_corr_d2, bool track_margin) {
+  NnState st{INFINITY, -1, INFINITY, 0.f, false};
+  const bool seeded = jprev >= 0 && jprev < g.m.n;
+  float seed_d2 = INFINITY;
+  if (seeded) {
+    const float4 pp = g.pts[jprev];
+    seed_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
+  }
+  if (!track_margin) {
+    // The pose is still moving by more than any margin could absorb: plain exact 1-NN (prunes with the best distance, not
+    // the runner-up), seeded with the previous correspondent.
+    Nearest1 nn{g.orig, seed_d2, seeded ? jprev : -1};
+    int level0 = 0;
+    if (seeded) {
+      const float rel = sqrtf(seed_d2) * g.m.inv_cell;
+      level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
+    }
+    st.explored2 = grid_search(g, qx, qy, qz, max_corr_d2, nn, level0, 1, kLaneLevelCap);
+    st.d1 = nn.best_d2;
+    st.j1 = nn.best_j;
+    st.complete = st.d1 < st.explored2 || st.explored2 >= max_corr_d2;
+    return st;
+  }
+  Nearest2 nn{g.orig, seed_d2, seeded ? jprev : -1, INFINITY, INFINITY};
+  if (seeded && seed_d2 < 0.36f * g.m.cell * g.m.cell) {
+    // close seed: scan the ball a little larger than the seed distance (so that an isolated nearest neighbour still
+    // earns a non-zero margin) — a handful of base cells
+    const float r = sqrtf(seed_d2) * 1.25f + 0.02f;
+    nn.limit = r * r;
+    grid_ball_search(g, qx, qy, qz, nn, 2.1f);
+    st = NnState{nn.d1, nn.j1, nn.d2nd, nn.limit, true};
+    return st;
+  }
+  const float reach2 = search_reach2(g, max_corr_d2, true);
+  int level0 = 0;
+  if (seeded && seed_d2 < max_corr_d2) {
+    const float rel = sqrtf(seed_d2) * g.m.inv_cell;
+    level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
+  }
+  st.explored2 = grid_search(g, qx, qy, qz, reach2, nn, level0, 1, kLaneLevelCap);
+  st.d1 = nn.d1;
+  st.j1 = nn.j1;
+  st.d2nd = nn.d2nd;
+  // the runner-up matters up to the explored radius only (finish_search clamps it), the nearest must lie inside it
+  st.complete = st.explored2 >= reach2 || (st.d1 < st.explored2);
+  return st;
+}
+
+// Wave-cooperative part: ALL lanes work on one query (wave-uniform arguments).  The cells of the box around the closed ball
+// of squared radius R2 are looked up by 64 lanes at once, their points are walked 64 at a time with kCoopDepth chunk loads in
+// flight, every lane keeps the nearest and runner-up of its share (ties: lower caller index) and a wave reduction gives the
+// exact nearest, its runner-up distance and explored2 = R2.  A lone lane doing this search walks the same cells one point
+// at a time — 250 k cycles for a far-field query, and every wave of the early iterations has a few of them.
+constexpr int kCoopDepth = 8;
+__device__ __forceinline__ NnState coop_search(const GridView& g, float qx, float qy, float qz, float R2) {
+  const int lane = lane_id();
+  const float R = sqrtf(R2) * (1.f + 1e-5f) + 1e-5f;
+  const TileBox box{qx - R, qy - R, qz - R, qx + R, qy + R, qz + R};
+  const TileCells cells = tile_cells(g, box, 0x7fffffff);
+  const bool whole = !cells.ok;  // cannot happen for R of a few metres (<= 8 top-level cells); kept for safety
+  const unsigned long long cellmask = __ballot(cells.ce > cells.cs);
+  float d1 = INFINITY, d2nd = INFINITY;
+  int j1 = -1;
+  unsigned long long todo = whole ? 0ull : cellmask;
+  int j = whole ? -kWave : 0, e = whole ? g.m.n : 0;
+  auto advance = [&]() -> bool {
+    j += kWave;
+    if (j < e) return true;
+    if (!todo) return false;
+    const int cl = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    j = __builtin_amdgcn_readlane(cells.cs, cl);
+    e = __builtin_amdgcn_readlane(cells.ce, cl);
+    return true;
+  };
+  for (;;) {
+    int jb[kCoopDepth];
+    bool have[kCoopDepth], in[kCoopDepth];
+    float4 p[kCoopDepth];
+#pragma unroll
+    for (int u = 0; u < kCoopDepth; u++) {
+      have[u] = advance();
+      jb[u] = j;
+      in[u] = have[u] && j + lane < e;
+      p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in[u]) p[u] = g.pts[j + lane];
+    }
+    if (!have[0]) break;
+#pragma unroll
+    for (int u = 0; u < kCoopDepth; u++) {
+      if (!have[u]) break;
+      const float dd = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+      if (in[u] && dd <= R2) {
+        const int jj = jb[u] + lane;
+        if (dd < d1 || (dd == d1 && j1 >= 0 && g.orig[jj] < g.orig[j1]) || j1 < 0) {
+          if (j1 >= 0) d2nd = fminf(d2nd, d1);
+          d1 = dd;
+          j1 = jj;
+        } else if (dd < d2nd) {
+          d2nd = dd;
+        }
+      }
+    }
+    if (!have[kCoopDepth - 1]) break;
+  }
+  // wave reduction: the nearest (ties: lowest caller index), then the runner-up = the best of everything else
+  const float best = uniform_f(wave_min_all(d1));
+  NnState st{INFINITY, -1, INFINITY, R2, true};
+  if (best < INFINITY) {
+    int oc = (d1 == best) ? g.orig[j1] : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) oc = min(oc, __shfl_xor(oc, off, kWave));
+    const bool win = (d1 == best) && g.orig[max(j1, 0)] == oc;
+    const int wl = __builtin_ctzll(__ballot(win));
+    st.d1 = best;
+    st.j1 = __builtin_amdgcn_readlane(j1, wl);
+    st.d2nd = uniform_f(wave_min_all(lane == wl ? d2nd : d1));
+  }
+  return st;
 }
 
 // F3 update_correspondences, incremental and exact.  PPT = points per thread and pass (tile = 256 * PPT points).
@@ -243,15 +347,33 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
     __syncthreads();
     // ---- phase 2: dense search of the queued points
     const int nq = qcount;
-    for (int tq = threadIdx.x; tq < nq; tq += kGicpBlock) {
-      const int i = queue[tq];
+    const float reach2 = search_reach2(g, max_corr_d2, track_margin);
+    for (int t0 = 0; t0 < nq; t0 += kGicpBlock) {  // whole waves go round together: the cooperative part needs all 64 lanes
+      const int tq = t0 + threadIdx.x;
+      const bool valid = tq < nq;
+      const int i = valid ? queue[tq] : 0;
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
-      int j;
-      float margin;
-      search_point(g, qx, qy, qz, corr[so + i], max_corr_d2, track_margin, j, margin);
-      corr[so + i] = j;
-      qsearch[so + i] = make_float4(qx, qy, qz, margin);
+      NnState st{INFINITY, -1, INFINITY, 0.f, true};
+      if (valid) st = lane_search(g, qx, qy, qz, corr[so + i], max_corr_d2, track_margin);
+      // the queries the fine levels could not finish, one at a time, by the whole wave
+      unsigned long long hard = __ballot(valid && !st.complete);
+      while (hard) {
+        const int hl = __builtin_ctzll(hard);
+        hard &= hard - 1;
+        const float hx = lane_f(qx, hl), hy = lane_f(qy, hl), hz = lane_f(qz, hl);
+        // without margins the ball shrinks to the best candidate the lane has already seen
+        const float hd = lane_f(st.d1, hl);
+        const NnState cs = coop_search(g, hx, hy, hz, track_margin ? reach2 : fminf(reach2, hd));
+        if (lane_id() == hl) st = cs;
+      }
+      if (valid) {
+        int j;
+        float margin;
+        finish_search(st, max_corr_d2, track_margin, j, margin);
+        corr[so + i] = j;
+        qsearch[so + i] = make_float4(qx, qy, qz, margin);
+      }
     }
     __syncthreads();  // correspondences written by other threads of this block are visible from here on
   }

@@ -112,13 +112,17 @@ __device__ __forceinline__ bool resolve_range(const GridView& g, uint32_t key, i
 // SIMT shape: for the shells r <= 1 every lane first builds a 27-bit mask of the neighbour cells that can still matter
 // (pure ALU), then walks only its own set bits — a wave iterates max-popcount times instead of 27, and no lane drags the
 // others through cells only it needs.
+// level_cap (optional): the search never works above that level — after the shells r <= 1 of level min(level_cap, top) it
+// returns what it has explored even if that does not cover the result yet (the caller hands such a query to a wave-cooperative
+// search: a lone lane walking the big cells of the coarse levels is what the slowest wave of a launch waits for).
 template <typename Visitor>
-__device__ __forceinline__ float grid_search(const GridView& g, float qx, float qy, float qz, float max_d2, Visitor& vis, int level0, int level_step) {
+__device__ __forceinline__ float grid_search(const GridView& g, float qx, float qy, float qz, float max_d2, Visitor& vis, int level0, int level_step,
+                                             int level_cap = kMaxLevel + 1) {
   const GridMeta& m = g.m;
   if (m.n <= 0) return INFINITY;
   const float bx = cell_coord(qx, m.ox, m.inv_cell), by = cell_coord(qy, m.oy, m.inv_cell), bz = cell_coord(qz, m.oz, m.inv_cell);
   const float margin = 1.0e-3f;  // in cell units: covers the fp32 fuzz of the cell lattice
-  int l = min(level0, m.top_level);
+  int l = min(min(level0, level_cap), m.top_level);
   for (;;) {
     const bool top = l >= m.top_level;
     const float scale = 1.0f / (float)(1 << l);
@@ -211,6 +215,7 @@ __device__ __forceinline__ float grid_search(const GridView& g, float qx, float 
       if (!done && rmax <= 1 && top) return INFINITY;  // the whole grid fits in these shells
     }
     if (done) return explored2;
+    if (l >= level_cap) return explored2;  // capped: the rest is the caller's
     if (top) {
       // ---- shells r >= 2 (or a query outside the grid): generic walk, top level only
       for (int r = max(r0, 2); r <= rmax; r++) {
@@ -246,7 +251,7 @@ __device__ __forceinline__ float grid_search(const GridView& g, float qx, float 
     }
     // next level; never coarser than the first level whose shell 1 is guaranteed to cover max_d2 (cell edge >= the radius):
     // beyond it the cells only get bigger, not the region that matters
-    int l_next = min(l + level_step, m.top_level);
+    int l_next = min(min(l + level_step, level_cap), m.top_level);
     if (max_d2 < INFINITY) {
       const float rel = sqrtf(max_d2) * m.inv_cell;
       const int l_cover = (rel <= 1.f) ? 0 : min(m.top_level, (int)ceilf(log2f(rel)));
