@@ -221,56 +221,85 @@ __device__ __forceinline__ NnState lane_search(const GridView& g, float qx, floa
 // exact nearest, its runner-up distance and explored2 = R2.  A lone lane doing this search walks the same cells one point
 // at a time — 250 k cycles for a far-field query, and every wave of the early iterations has a few of them.
 constexpr int kCoopDepth = 8;
+constexpr int kCoopCells = 128;  // cells of the cube around the ball, two per lane
 __device__ __forceinline__ NnState coop_search(const GridView& g, float qx, float qy, float qz, float R2) {
+  const GridMeta& m = g.m;
   const int lane = lane_id();
   const float R = sqrtf(R2) * (1.f + 1e-5f) + 1e-5f;
-  const TileBox box{qx - R, qy - R, qz - R, qx + R, qy + R, qz + R};
-  const TileCells cells = tile_cells(g, box, 0x7fffffff);
-  const bool whole = !cells.ok;  // cannot happen for R of a few metres (<= 8 top-level cells); kept for safety
-  const unsigned long long cellmask = __ballot(cells.ce > cells.cs);
+  // the finest level at which the cube around the ball needs at most kCoopCells cells; cells the ball does not reach are
+  // dropped before their probe, so a query above a dense surface scans the patch below it, not an 8 m cube
+  auto base_cell = [&](float v, float o, int d) { return min(max((int)floorf(cell_coord(v, o, m.inv_cell)), 0), d - 1); };
+  const int x0 = base_cell(qx - R, m.ox, m.dx), x1 = base_cell(qx + R, m.ox, m.dx);
+  const int y0 = base_cell(qy - R, m.oy, m.dy), y1 = base_cell(qy + R, m.oy, m.dy);
+  const int z0 = base_cell(qz - R, m.oz, m.dz), z1 = base_cell(qz + R, m.oz, m.dz);
+  int L = 0;
+  auto count = [&](int l) { return ((x1 >> l) - (x0 >> l) + 1) * ((y1 >> l) - (y0 >> l) + 1) * ((z1 >> l) - (z0 >> l) + 1); };
+  while (L < m.top_level && count(L) > kCoopCells) L++;
+  const int cx0 = x0 >> L, cy0 = y0 >> L, cz0 = z0 >> L;
+  const int sx = (x1 >> L) - cx0 + 1, sy = (y1 >> L) - cy0 + 1, sz = (z1 >> L) - cz0 + 1;
+  const int nc = sx * sy * sz;
+  const bool whole = nc > kCoopCells;  // cannot happen for a radius of a few metres; the whole cloud is scanned then
+  const float cell = m.cell * (float)(1 << L);
   float d1 = INFINITY, d2nd = INFINITY;
   int j1 = -1;
-  unsigned long long todo = whole ? 0ull : cellmask;
-  int j = whole ? -kWave : 0, e = whole ? g.m.n : 0;
-  auto advance = [&]() -> bool {
-    j += kWave;
-    if (j < e) return true;
-    if (!todo) return false;
-    const int cl = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    j = __builtin_amdgcn_readlane(cells.cs, cl);
-    e = __builtin_amdgcn_readlane(cells.ce, cl);
-    return true;
-  };
-  for (;;) {
-    int jb[kCoopDepth];
-    bool have[kCoopDepth], in[kCoopDepth];
-    float4 p[kCoopDepth];
-#pragma unroll
-    for (int u = 0; u < kCoopDepth; u++) {
-      have[u] = advance();
-      jb[u] = j;
-      in[u] = have[u] && j + lane < e;
-      p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in[u]) p[u] = g.pts[j + lane];
-    }
-    if (!have[0]) break;
-#pragma unroll
-    for (int u = 0; u < kCoopDepth; u++) {
-      if (!have[u]) break;
-      const float dd = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
-      if (in[u] && dd <= R2) {
-        const int jj = jb[u] + lane;
-        if (dd < d1 || (dd == d1 && j1 >= 0 && g.orig[jj] < g.orig[j1]) || j1 < 0) {
-          if (j1 >= 0) d2nd = fminf(d2nd, d1);
-          d1 = dd;
-          j1 = jj;
-        } else if (dd < d2nd) {
-          d2nd = dd;
-        }
+  for (int c0 = 0; c0 < (whole ? 1 : nc); c0 += kWave) {
+    int cs = 0, ce = 0;
+    if (!whole && c0 + lane < nc) {
+      const int ci = c0 + lane;
+      const int ix = cx0 + ci % sx, iy = cy0 + (ci / sx) % sy, iz = cz0 + ci / (sx * sy);
+      // lower bound of the distance from the query to the cell's cube (the grid clamps outside queries: clamp the test too)
+      const float lx = m.ox + (float)ix * cell, ly = m.oy + (float)iy * cell, lz = m.oz + (float)iz * cell;
+      const float gx = fmaxf(fmaxf(lx - qx, qx - (lx + cell)), 0.f), gy = fmaxf(fmaxf(ly - qy, qy - (ly + cell)), 0.f),
+                  gz = fmaxf(fmaxf(lz - qz, qz - (lz + cell)), 0.f);
+      const float lb = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - 1.0e-3f * cell, 0.f);
+      const bool edge = ix == 0 || iy == 0 || iz == 0 || ix == ((m.dx - 1) >> L) || iy == ((m.dy - 1) >> L) || iz == ((m.dz - 1) >> L);
+      if (edge || lb * lb <= R2) {  // (border cells also hold the points the clamping put there)
+        int s0, e0;
+        if (cell_range(g, ((uint32_t)L << 27) | morton27((uint32_t)ix, (uint32_t)iy, (uint32_t)iz), s0, e0)) { cs = s0; ce = e0; }
       }
     }
-    if (!have[kCoopDepth - 1]) break;
+    unsigned long long todo = whole ? 0ull : __ballot(ce > cs);
+    int j = whole ? -kWave : 0, e = whole ? m.n : 0;
+    auto advance = [&]() -> bool {
+      j += kWave;
+      if (j < e) return true;
+      if (!todo) return false;
+      const int cl = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      j = __builtin_amdgcn_readlane(cs, cl);
+      e = __builtin_amdgcn_readlane(ce, cl);
+      return true;
+    };
+    for (;;) {
+      int jb[kCoopDepth];
+      bool have[kCoopDepth], in[kCoopDepth];
+      float4 p[kCoopDepth];
+#pragma unroll
+      for (int u = 0; u < kCoopDepth; u++) {
+        have[u] = advance();
+        jb[u] = j;
+        in[u] = have[u] && j + lane < e;
+        p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[u]) p[u] = g.pts[j + lane];
+      }
+      if (!have[0]) break;
+#pragma unroll
+      for (int u = 0; u < kCoopDepth; u++) {
+        if (!have[u]) break;
+        const float dd = dist2f(qx, qy, qz, p[u].x, p[u].y, p[u].z);
+        if (in[u] && dd <= R2) {
+          const int jj = jb[u] + lane;
+          if (dd < d1 || (dd == d1 && j1 >= 0 && g.orig[jj] < g.orig[j1]) || j1 < 0) {
+            if (j1 >= 0) d2nd = fminf(d2nd, d1);
+            d1 = dd;
+            j1 = jj;
+          } else if (dd < d2nd) {
+            d2nd = dd;
+          }
+        }
+      }
+      if (!have[kCoopDepth - 1]) break;
+    }
   }
   // wave reduction: the nearest (ties: lowest caller index), then the runner-up = the best of everything else
   const float best = uniform_f(wave_min_all(d1));
@@ -347,7 +376,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
     __syncthreads();
     // ---- phase 2: dense search of the queued points
     const int nq = qcount;
-    const float reach2 = search_reach2(g, max_corr_d2, track_margin);
+    const float reach_coop2 = search_reach2(g, max_corr_d2, true);
     for (int t0 = 0; t0 < nq; t0 += kGicpBlock) {  // whole waves go round together: the cooperative part needs all 64 lanes
       const int tq = t0 + threadIdx.x;
       const bool valid = tq < nq;
@@ -355,6 +384,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
       NnState st{INFINITY, -1, INFINITY, 0.f, true};
+      bool was_hard = false;
       if (valid) st = lane_search(g, qx, qy, qz, corr[so + i], max_corr_d2, track_margin);
       // the queries the fine levels could not finish, one at a time, by the whole wave
       unsigned long long hard = __ballot(valid && !st.complete);
@@ -362,15 +392,15 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
         const int hl = __builtin_ctzll(hard);
         hard &= hard - 1;
         const float hx = lane_f(qx, hl), hy = lane_f(qy, hl), hz = lane_f(qz, hl);
-        // without margins the ball shrinks to the best candidate the lane has already seen
-        const float hd = lane_f(st.d1, hl);
-        const NnState cs = coop_search(g, hx, hy, hz, track_margin ? reach2 : fminf(reach2, hd));
-        if (lane_id() == hl) st = cs;
+        // the cooperative search always covers the full reach: its result comes with a margin whatever the mode — a far-field
+        // point with nothing in range keeps that answer while the pose moves less than its distance to the nearest thing
+        const NnState cs = coop_search(g, hx, hy, hz, reach_coop2);
+        if (lane_id() == hl) { st = cs; was_hard = true; }
       }
       if (valid) {
         int j;
         float margin;
-        finish_search(st, max_corr_d2, track_margin, j, margin);
+        finish_search(st, max_corr_d2, track_margin || was_hard, j, margin);
         corr[so + i] = j;
         qsearch[so + i] = make_float4(qx, qy, qz, margin);
       }
