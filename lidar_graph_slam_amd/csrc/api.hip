@@ -384,14 +384,15 @@ static void run_prefilter(hipStream_t s, Workspace& ws, CloudSet& sor_set, float
   };
   float4* dst;
   int* ndst;
-  if (p.min_distance > 0) {
+  const bool fused = p.min_distance > 0 && p.leaf_size > 0;  // distance filter inside the voxel grid's key pass
+  if (p.min_distance > 0 && !fused) {
     next(&dst, &ndst);
     distance_filter(s, ws, cur, ncur, dst, ndst, B, cap, p.min_distance);
     cur = dst; ncur = ndst;
   }
   if (p.leaf_size > 0) {
     next(&dst, &ndst);
-    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size);
+    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size, fused ? p.min_distance : 0.0);
     cur = dst; ncur = ndst;
   }
   if (p.mean_k > 0) {

@@ -34,6 +34,14 @@ void ws_reserve(Workspace& ws, int B, size_t cap) {
   ws.vmeta.ensure(B);
 }
 
+// PointsPreFiltering::distance_filter's predicate (points_prefiltering.cpp:102-112): Eigen Vector3f::norm() — fp32 sqrt of
+// (x*x + y*y) + z*z — promoted to double, strict '<' (NaN compares false).  min_distance <= 0: no filter.
+__device__ __forceinline__ bool passes_distance(const float4& p, double min_distance) {
+  if (!(min_distance > 0.0)) return true;
+  const float nrm = sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
+  return min_distance < (double)nrm;
+}
+
 // ---- bounding boxes ---------------------------------------------------------------------------------------------
 __global__ void k_bounds_init(uint32_t* bounds, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,14 +49,14 @@ __global__ void k_bounds_init(uint32_t* bounds, int B) {
 }
 
 __global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pts, const int* __restrict__ counts, uint32_t* __restrict__ bounds,
-                                                size_t cap) {
+                                                size_t cap, double min_distance) {
   const int c = blockIdx.y;
   const int n = counts[c];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   const float4* p = pts + (size_t)c * cap;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 v = p[i];
-    if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) {
+    if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && passes_distance(v, min_distance)) {
       mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z);
       mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z);
     }
@@ -72,10 +80,10 @@ __global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pts, 
   }
 }
 
-static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const int* cnt, int B, size_t cap) {
+static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const int* cnt, int B, size_t cap, double min_distance = 0.0) {
   hipLaunchKernelGGL(k_bounds_init, dim3(div_up(B * 6, 256)), dim3(256), 0, s, ws.bounds.p, B);
   const int gx = std::max(1, std::min(16, div_up((long)cap, 4096)));
-  hipLaunchKernelGGL(k_bounds, dim3(gx, B), dim3(256), 0, s, in, cnt, ws.bounds.p, cap);
+  hipLaunchKernelGGL(k_bounds, dim3(gx, B), dim3(256), 0, s, in, cnt, ws.bounds.p, cap, min_distance);
 }
 
 // ---- NN voxel-hash build ----------------------------------------------------------------------------------------
@@ -1086,9 +1094,7 @@ __global__ __launch_bounds__(256) void k_distance_flags(const float4* __restrict
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= counts[c]) return;
   const float4 p = in[(size_t)c * cap + i];
-  // Eigen Vector3f::norm(): fp32 sqrt of (x*x + y*y) + z*z, promoted to double, strict '<' (NaN compares false)
-  const float nrm = sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
-  flags[(size_t)c * cap + i] = (min_distance < (double)nrm) ? 1 : 0;
+  flags[(size_t)c * cap + i] = passes_distance(p, min_distance) ? 1 : 0;
 }
 
 void distance_filter(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap,
@@ -1131,14 +1137,14 @@ __global__ void k_voxel_meta(const uint32_t* __restrict__ bounds, const int* __r
 }
 
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ in, const GridMeta* __restrict__ vmeta, uint32_t* __restrict__ keys,
-                                                    int* __restrict__ vals, size_t cap) {
+                                                    int* __restrict__ vals, size_t cap, double min_distance) {
   const int c = blockIdx.y;
   const GridMeta m = vmeta[c];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   const float4 p = in[(size_t)c * cap + i];
   uint32_t key = kEmptyKey;
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !m.overflow) {
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !m.overflow && passes_distance(p, min_distance)) {
     const int mb0 = __float_as_int(m.ox), mb1 = __float_as_int(m.oy), mb2 = __float_as_int(m.oz);
     const int i0 = (int)(floorf(p.x * m.inv_cell) - (float)mb0);
     const int i1 = (int)(floorf(p.y * m.inv_cell) - (float)mb1);
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ i
 }
 
 __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict__ keys, const GridMeta* __restrict__ vmeta, int* __restrict__ flags,
-                                                     size_t cap) {
+                                                     size_t cap, const float4* __restrict__ in, double min_distance) {
   const int c = blockIdx.y;
   const GridMeta m = vmeta[c];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1158,7 +1164,9 @@ __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict_
   const size_t o = (size_t)c * cap;
   const uint32_t k = keys[o + i];
   int f;
-  if (m.overflow) f = 1;
+  // overflow ("Leaf size is too small"): VoxelGrid passes its input through — with the fused distance filter that input is what
+  // the filter keeps (all keys are empty then, so the stable sort left the points in their original order)
+  if (m.overflow) f = passes_distance(in[o + i], min_distance) ? 1 : 0;
   else f = (k != kEmptyKey) && (i == 0 || keys[o + i - 1] != k);
   flags[o + i] = f;
 }
@@ -1180,11 +1188,11 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
   if (i == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
   if (i >= m.n) return;
   const size_t o = (size_t)c * cap;
-  if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input
-    out[o + i] = in[o + i];
+  if (!flags[o + i]) return;
+  if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (k_voxel_heads flagged what passes through)
+    out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = in[o + i];
     return;
   }
-  if (!flags[o + i]) return;
   const uint32_t k = keys[o + i];
   float4 a = in[o + vals[o + i]];
   int cnt = 1;
@@ -1209,14 +1217,15 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
   out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc);
 }
 
-void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf) {
+void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf,
+                double min_distance) {
   ws_reserve(ws, B, cap);
-  compute_bounds(s, ws, in, cnt_in, B, cap);
+  compute_bounds(s, ws, in, cnt_in, B, cap, min_distance);
   hipLaunchKernelGGL(k_voxel_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, ws.vmeta.p, B, leaf);
   const dim3 grid(div_up((long)cap, 256), B);
-  hipLaunchKernelGGL(k_voxel_keys, grid, dim3(256), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap);
+  hipLaunchKernelGGL(k_voxel_keys, grid, dim3(256), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap, min_distance);
   sort_pairs(s, ws, B, cap, cnt_in, 4);
-  hipLaunchKernelGGL(k_voxel_heads, grid, dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap);
+  hipLaunchKernelGGL(k_voxel_heads, grid, dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap, in, min_distance);
   scan_flags(s, ws, B, cap, cnt_in);
   const int Gv = div_up((long)cap, 256);
   TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
