@@ -392,7 +392,7 @@ static void run_prefilter(hipStream_t s, Workspace& ws, CloudSet& sor_set, float
   }
   if (p.leaf_size > 0) {
     next(&dst, &ndst);
-    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size, fused ? p.min_distance : 0.0);
+    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size, fused ? p.min_distance : -1.0);
     cur = dst; ncur = ndst;
   }
   if (p.mean_k > 0) {

@@ -35,9 +35,10 @@ void ws_reserve(Workspace& ws, int B, size_t cap) {
 }
 
 // PointsPreFiltering::distance_filter's predicate (points_prefiltering.cpp:102-112): Eigen Vector3f::norm() — fp32 sqrt of
-// (x*x + y*y) + z*z — promoted to double, strict '<' (NaN compares false).  min_distance <= 0: no filter.
+// (x*x + y*y) + z*z — promoted to double, strict '<' (NaN compares false; min_distance = 0 still drops the all-zero no-return
+// points).  A NEGATIVE min_distance means "no filter" (the voxel grid without a fused distance filter).
 __device__ __forceinline__ bool passes_distance(const float4& p, double min_distance) {
-  if (!(min_distance > 0.0)) return true;
+  if (min_distance < 0.0) return true;
   const float nrm = sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
   return min_distance < (double)nrm;
 }
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pts, 
   }
 }
 
-static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const int* cnt, int B, size_t cap, double min_distance = 0.0) {
+static void compute_bounds(hipStream_t s, Workspace& ws, const float4* in, const int* cnt, int B, size_t cap, double min_distance = -1.0) {
   hipLaunchKernelGGL(k_bounds_init, dim3(div_up(B * 6, 256)), dim3(256), 0, s, ws.bounds.p, B);
   const int gx = std::max(1, std::min(16, div_up((long)cap, 4096)));
   hipLaunchKernelGGL(k_bounds, dim3(gx, B), dim3(256), 0, s, in, cnt, ws.bounds.p, cap, min_distance);

@@ -83,10 +83,10 @@ void ws_reserve(Workspace& ws, int B, size_t cap);
 // distance filter (A1): in -> out compacted, order preserved.
 void distance_filter(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap,
                      double min_distance);
-// VoxelGrid (P1): in -> out centroids in ascending voxel index.  min_distance > 0 fuses the distance filter (A1) in front of
+// VoxelGrid (P1): in -> out centroids in ascending voxel index.  min_distance >= 0 fuses the distance filter (A1) in front of
 // it: the points the filter drops take no part (same output as filter-then-grid, without the flag / scan / compact passes).
 void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf,
-                double min_distance = 0.0);
+                double min_distance = -1.0);
 // SOR (P2): in -> out, order preserved.  Optional diagnostics (device pointers, [B*cap]).
 void sor_filter(hipStream_t s, Workspace& ws, CloudSet& scratch_set, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B,
                 size_t cap, int mean_k, double stddev_mul, float cell, uint8_t* d_keep, float* d_mean_dist);
