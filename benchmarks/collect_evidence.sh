@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash benchmarks/collect_evidence.sh r01'): everything profiles/README.md cites, written
 # under gpurun_out/<round>/; benchmarks/summarize_evidence.py then distils it into profiles/.
 # rocprofv3 is given the program directly (no env/bash hop) and PMC passes carry --kernel-trace only.
-R=${1:-r01}
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
@@ -14,5 +14,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O
 timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinputs.json" 2> "$O/bench_hostinputs.err"
 timeout 300 python bench.py --inflight 2 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
 timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.json" 2> "$O/bench_128pairs.err"
-timeout 600 python benchmarks/other_configs.py > "$O/other_configs.txt" 2> "$O/other_configs.err"
+timeout 900 python benchmarks/other_configs.py --scans 200 > "$O/other_configs.txt" 2> "$O/other_configs.err"
+timeout 600 python benchmarks/config5.py --candidates 512 --submaps 8 > "$O/config5_1gpu.json" 2> "$O/config5_1gpu.err"
+MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"
 ls -la "$O"
