@@ -352,8 +352,8 @@ def main():
             "reference_config_threads": 4,
             "host_hw_threads": hw,
             "cpu_model": model,
-            "gpu_vs_cpu_pose_dt_m": round(dt, 6),
-            "gpu_vs_cpu_pose_dr_rad": round(dr, 7),
+            "gpu_vs_cpu_pose_dt_m": round(dt, 9),
+            "gpu_vs_cpu_pose_dr_rad": round(dr, 9),
         }
 
     out = {

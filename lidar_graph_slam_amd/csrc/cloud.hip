@@ -35,11 +35,11 @@ void ws_reserve(Workspace& ws, int B, size_t cap) {
 }
 
 // PointsPreFiltering::distance_filter's predicate (points_prefiltering.cpp:102-112): Eigen Vector3f::norm() — fp32 sqrt of
-// (x*x + y*y) + z*z — promoted to double, strict '<' (NaN compares false; min_distance = 0 still drops the all-zero no-return
+// x*x + (y*y + z*z) (the association of Eigen's unrolled 3-element redux, Redux.h redux_novec_unroller) — promoted to double, strict '<' (NaN compares false; min_distance = 0 still drops the all-zero no-return
 // points).  A NEGATIVE min_distance means "no filter" (the voxel grid without a fused distance filter).
 __device__ __forceinline__ bool passes_distance(const float4& p, double min_distance) {
   if (min_distance < 0.0) return true;
-  const float nrm = sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
+  const float nrm = sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z));
   return min_distance < (double)nrm;
 }
 

@@ -19,7 +19,7 @@ from scipy.spatial import cKDTree
 
 # ---------------------------------------------------------------- PCL pieces
 def distance_filter(pts: np.ndarray, min_distance: float) -> np.ndarray:
-    nrm = np.sqrt((pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]) + pts[:, 2] * pts[:, 2]).astype(np.float32)
+    nrm = np.sqrt(pts[:, 0] * pts[:, 0] + (pts[:, 1] * pts[:, 1] + pts[:, 2] * pts[:, 2])).astype(np.float32)  # Eigen's 3-vector redux order
     return pts[min_distance < nrm.astype(np.float64)]
 
 

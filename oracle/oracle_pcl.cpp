@@ -24,8 +24,9 @@ extern "C" int orc_distance_filter(const float* pts, size_t n, double min_distan
   size_t o = 0;
   for (size_t i = 0; i < n; i++) {
     const float* p = pts + 4 * i;
-    // Eigen's Vector3f::norm(): sqrt of the fp32 sum of squares (x*x + y*y) + z*z.
-    const float nrm = std::sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    // Eigen's Vector3f::norm() = sqrt(cwiseAbs2().sum()); a fixed-size 3-vector is summed by redux_novec_unroller<.., 0, 3>
+    // (Eigen/src/Core/Redux.h), which halves the range: func(x*x, func(y*y, z*z)) -> x*x + (y*y + z*z) in fp32.
+    const float nrm = std::sqrt(p[0] * p[0] + (p[1] * p[1] + p[2] * p[2]));
     const double distance = (double)nrm;
     if (min_distance < distance) {
       std::memcpy(out + 4 * o, p, 4 * sizeof(float));

@@ -25,6 +25,14 @@ def test_distance_filter_bit_exact(F, medium_pair):
     assert len(F.distance_filter(np.zeros((0, 4), np.float32), 1.0)) == 0
 
 
+def test_distance_filter_on_the_threshold(F):
+    """points where x*x + (y*y + z*z) and (x*x + y*y) + z*z fall on different sides of 1.0 m: Eigen's order decides"""
+    from test_oracle_pcl import _boundary_points
+
+    pts, keep = _boundary_points()
+    np.testing.assert_array_equal(F.distance_filter(pts, 1.0), pts[keep])
+
+
 def test_pointxyzi_layout(F, medium_pair):
     src, _, _ = medium_pair
     xyzi = np.zeros((len(src), 8), np.float32)  # pcl::PointXYZI: x y z 1 | intensity pad pad pad

@@ -7,6 +7,30 @@ from oracle import numpy_ref as NR
 from oracle import oracle_py as O
 
 
+def _boundary_points(n=200000, seed=5):
+    """Points whose fp32 squared norm depends on the association: x*x + (y*y + z*z) (Eigen's unrolled 3-element redux) differs
+    from (x*x + y*y) + z*z, scaled onto the 1.0 m threshold so that the two orders disagree about the predicate."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True).astype(np.float32)
+    v *= np.float32(1.0) + rng.integers(-2, 3, size=(n, 1)).astype(np.float32) * np.float32(2.0 ** -24)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    eigen = np.sqrt(x * x + (y * y + z * z))
+    other = np.sqrt((x * x + y * y) + z * z)
+    pick = (1.0 < eigen.astype(np.float64)) != (1.0 < other.astype(np.float64))
+    pts = np.zeros((int(pick.sum()), 4), np.float32)
+    pts[:, :3] = v[pick]
+    pts[:, 3] = np.arange(len(pts))
+    return pts, (1.0 < eigen[pick].astype(np.float64))
+
+
+def test_distance_filter_sums_squares_in_eigens_order():
+    pts, keep = _boundary_points()
+    assert len(pts) > 100 and 0 < keep.sum() < len(pts)
+    np.testing.assert_array_equal(O.distance_filter(pts, 1.0), pts[keep])
+    np.testing.assert_array_equal(NR.distance_filter(pts, 1.0), pts[keep])
+
+
 def test_distance_filter_strict_and_order():
     pts = np.array([[1, 0, 0, 1], [0.5, 0, 0, 2], [0, 2, 0, 3], [0, 0, 0, 4], [np.nan, 0, 0, 5], [0.6, 0.8, 0, 6]], dtype=np.float32)
     out = O.distance_filter(pts, 1.0)
