@@ -234,7 +234,12 @@ int mi355_cloud_save_pcd(mi355_cloud* cloud, const char* path, int binary);
 
 /* ---- batch mode: many independent scan pairs per launch (BASELINE configs 2 and 5) --------------------- */
 /* n_sources source clouds and n_targets target clouds, each up to `capacity` points; pair p aligns source p to
- * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates). */
+ * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates).
+ * method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params) or MI355_METHOD_NDT_OMP (params = mi355_ndt_params) — the
+ * engines GraphBasedSLAM::get_registration builds (graph_based_slam.cpp:101-141).  With NDT_OMP every pair's Newton /
+ * More-Thuente state lives in device memory and all pairs advance together, one derivative launch per evaluation for the
+ * whole batch and no read-back in between; mi355_batch_align then BLOCKS until the last pair has converged (FAST_GICP only
+ * enqueues).  Results: T, converged, iterations, error (= the NDT score), H, trans_probability; fitness as FAST_GICP. */
 mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity);
 void mi355_batch_destroy(mi355_batch* b);
 /* Device-resident inputs: packed float4 [n_clouds][capacity] + host counts.  prefilter (optional) is applied on device

@@ -128,6 +128,9 @@ struct mi355_batch {
   mi355_ctx* ctx = nullptr;
   int method = MI355_METHOD_FAST_GICP;
   mi355_gicp_params gp;
+  mi355_ndt_params np;       // method == MI355_METHOD_NDT_OMP
+  NdtBatch* ndt = nullptr;
+  std::vector<int> ndt_src_counts, ndt_tgt_counts;  // points per cloud after the prefilter (host copies)
   int n_sources = 0, n_targets = 0;
   size_t cap = 0;
   // Targets and sources are prepared (prefilter, sort, voxel hash, k-NN covariances) on two side streams forked from the
@@ -153,6 +156,7 @@ struct mi355_batch {
   hipStream_t stream() const { return has_own_stream ? own_stream : ctx->stream; }
   bool has_src = false, has_tgt = false, aligned = false, with_fitness = false;
   ~mi355_batch() {
+    if (ndt) ndt_batch_destroy(ndt);
     for (auto& sd : side) {
       if (sd.stream) { (void)hipStreamSynchronize(sd.stream); (void)hipStreamDestroy(sd.stream); }
       if (sd.fork) (void)hipEventDestroy(sd.fork);
@@ -954,15 +958,17 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
 
 // ---- batch ---------------------------------------------------------------------------------------------------------
 extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity) {
-  if (!ctx || method != MI355_METHOD_FAST_GICP || n_sources <= 0 || n_targets <= 0 || capacity == 0) {
-    if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP)";
+  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP) || n_sources <= 0 || n_targets <= 0 || capacity == 0) {
+    if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP or NDT_OMP)";
     return nullptr;
   }
   auto* b = new mi355_batch();
   b->ctx = ctx;
   b->method = method;
   mi355_gicp_default_params(&b->gp);
-  if (params) b->gp = *(const mi355_gicp_params*)params;
+  mi355_ndt_default_params(&b->np);
+  if (params && method == MI355_METHOD_FAST_GICP) b->gp = *(const mi355_gicp_params*)params;
+  if (params && method == MI355_METHOD_NDT_OMP) b->np = *(const mi355_ndt_params*)params;
   b->n_sources = n_sources;
   b->n_targets = n_targets;
   b->cap = capacity;
@@ -970,7 +976,13 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
     MI_HIP(hipSetDevice(ctx->device));
     b->src.alloc(n_sources, capacity);
     b->tgt.alloc(n_targets, capacity);
-    gicp_alloc(b->gb, n_sources, capacity, ctx->compute_units);
+    if (method == MI355_METHOD_NDT_OMP) {
+      if (!(b->np.resolution > 0)) throw ArgError(MI355_EINVAL, "ndt resolution must be positive");
+      gicp_alloc_fitness_only(b->gb, n_sources, capacity);  // getFitnessScore is the point-to-point one for every method
+      b->ndt = ndt_batch_create(n_sources, n_targets);
+    } else {
+      gicp_alloc(b->gb, n_sources, capacity, ctx->compute_units);
+    }
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
       // the preparation chains run at the lowest priority: when batches overlap (mi355_batch_set_stream), the short,
@@ -1025,7 +1037,18 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     run_prefilter(s, sd.ws, sd.sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, sd.cnt_in.p, sd.ws.stage_a, sd.ws.stage_b, sd.ws.count_a,
                   sd.ws.count_b, &pts, &cnt);
   build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell);
-  compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
+  if (b->method == MI355_METHOD_NDT_OMP) {
+    // NDT: the sources are just points; every target gets its voxel Gaussians (N1).  The leaf builder sizes its launches on
+    // the host, so the counts after the prefilter are read back here (one sync per set call, none per alignment).
+    std::vector<int>& hc = targets ? b->ndt_tgt_counts : b->ndt_src_counts;
+    hc.resize((size_t)B);
+    MI_HIP(hipMemcpyAsync(hc.data(), set.count.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (targets)
+      for (int u = 0; u < B; u++) ndt_batch_set_target(s, sd.ws, *b->ndt, u, set.pts.p + (size_t)u * b->cap, (size_t)hc[(size_t)u], b->np);
+  } else {
+    compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
+  }
   if (side_streams) {
     MI_HIP(hipEventRecord(sd.join, s));
     sd.pending = true;
@@ -1133,9 +1156,20 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
     MI_HIP(hipSetDevice(b->ctx->device));
     batch_join(b);
     TimerScope timing(&b->timers);
-    gicp_align(b->stream(), b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
     b->with_fitness = with_fitness != 0;
-    if (b->with_fitness) gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
+    if (b->method == MI355_METHOD_NDT_OMP) {
+      // blocks until every pair has converged (the More-Thuente states advance on the device; the host polls a counter)
+      gicp_set_map(b->stream(), b->gb, tgt_of_src, b->n_targets);
+      ndt_batch_align(b->stream(), *b->ndt, b->src.pts.p, b->cap, b->ndt_src_counts.data(), tgt_of_src, guesses16, b->np);
+      if (b->with_fitness) {
+        std::vector<float> T((size_t)b->n_sources * 16);
+        ndt_batch_results(*b->ndt, nullptr, T.data());
+        gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, false, T.data());
+      }
+    } else {
+      gicp_align(b->stream(), b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
+      if (b->with_fitness) gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
+    }
     b->aligned = true;
   });
 }
@@ -1146,7 +1180,16 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     if (!b->aligned) throw ArgError(MI355_ESTATE, "mi355_batch_align has not been called");
     if (fitness && !b->with_fitness) throw ArgError(MI355_ESTATE, "fitness was not requested in mi355_batch_align");
     MI_HIP(hipSetDevice(b->ctx->device));
-    gicp_results(b->stream(), b->gb, b->src, b->tgt, results, fitness);
+    if (b->method == MI355_METHOD_NDT_OMP) {
+      ndt_batch_results(*b->ndt, results, nullptr);
+      for (int i = 0; i < b->n_sources; i++) {
+        results[i].n_source = b->ndt_src_counts[(size_t)i];
+        results[i].n_target = b->ndt_tgt_counts[(size_t)b->gb.h_map[(size_t)i]];
+      }
+      if (fitness) gicp_fitness_values(b->stream(), b->gb, fitness);
+    } else {
+      gicp_results(b->stream(), b->gb, b->src, b->tgt, results, fitness);
+    }
   });
 }
 

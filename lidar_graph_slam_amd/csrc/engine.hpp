@@ -131,6 +131,9 @@ struct GicpBatch {
   int ppt = 1;              // points per thread and pass in k_gicp_correspond (Tuning::corr_ppt)
 };
 void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units);
+void gicp_alloc_fitness_only(GicpBatch& gb, int S, size_t cap);  // for gicp_fitness with host poses only
+void gicp_set_map(hipStream_t s, GicpBatch& gb, const int* tgt_of_src_host, int n_targets);
+void gicp_fitness_values(hipStream_t s, GicpBatch& gb, double* fitness_out);
 // Enqueue the full LM optimisation of every pair.  guesses_host: S x 16 floats or nullptr.
 void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
                 const float* guesses_host);
@@ -163,5 +166,16 @@ void ndt_derivatives(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d
                      double* score, double* grad6, double* hess36, bool hessian_fp64);
 size_t ndt_num_cells(NdtTarget& t);
 void ndt_cells(hipStream_t s, NdtTarget& t, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3);
+// P pairs against U targets with the More-Thuente state of every pair resident in HBM (graph_based_slam.cpp:101-119 lets the
+// loop-closure back end register its candidates with NDT_OMP)
+struct NdtBatch;
+NdtBatch* ndt_batch_create(int P, int U);
+void ndt_batch_destroy(NdtBatch*);
+void ndt_batch_set_target(hipStream_t s, Workspace& ws, NdtBatch& b, int u, const float4* d_pts, size_t n, const mi355_ndt_params& p);
+void ndt_batch_align(hipStream_t s, NdtBatch& b, const float4* d_src, size_t src_cap, const int* h_counts, const int* tgt_of_src_host,
+                     const float* guesses_host, const mi355_ndt_params& p);
+void ndt_batch_results(NdtBatch& b, mi355_result* out, float* T16_all);
+size_t ndt_batch_num_cells(NdtBatch& b, int u);
+int ndt_batch_rounds(const NdtBatch& b);
 
 }  // namespace mi355

@@ -79,6 +79,34 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.fitness.ensure((size_t)S * 2);
 }
 
+// What gicp_fitness alone needs (a batch that registers with another method still scores its pairs with it).
+void gicp_alloc_fitness_only(GicpBatch& gb, int S, size_t cap) {
+  gb.S = S;
+  gb.cap = cap;
+  gb.blocks_per_pair = 1;
+  gb.blocks_lin = std::max(1, std::min(std::max(4, std::min(32, 512 / std::max(S, 1))), div_up((long)cap, kGicpBlock * 2)));
+  gb.tgt_of_src.ensure(S);
+  gb.state.ensure(1);
+  gb.fit_partials.ensure((size_t)S * gb.blocks_lin * 2);
+  gb.fitness.ensure((size_t)S * 2);
+}
+
+void gicp_set_map(hipStream_t s, GicpBatch& gb, const int* tgt_of_src_host, int n_targets) {
+  gb.h_map.resize(gb.S);
+  for (int i = 0; i < gb.S; i++) {
+    gb.h_map[i] = tgt_of_src_host ? tgt_of_src_host[i] : i;
+    if (gb.h_map[i] < 0 || gb.h_map[i] >= n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src out of range");
+  }
+  MI_HIP(hipMemcpyAsync(gb.tgt_of_src.p, gb.h_map.data(), gb.S * sizeof(int), hipMemcpyHostToDevice, s));
+}
+
+void gicp_fitness_values(hipStream_t s, GicpBatch& gb, double* fitness_out) {
+  std::vector<double> fit((size_t)gb.S * 2);
+  MI_HIP(hipMemcpyAsync(fit.data(), gb.fitness.p, fit.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  for (int p = 0; p < gb.S; p++) fitness_out[p] = fit[2 * p + 1] > 0 ? fit[2 * p] / fit[2 * p + 1] : 1.7976931348623157e308;
+}
+
 // scount / tcount (optional): a pair whose clouds hold fewer than k_min points after the prefilter is not registered —
 // its covariances would be built from missing neighbours — and reports MI355_PAIR_TOO_FEW_POINTS instead.
 __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses, int S, int has_guess, const int* __restrict__ scount,

@@ -7,11 +7,13 @@
 //   derivatives   : one thread per source point: fp32 transform, 7-voxel gather, score + gradient(6) + Hessian(21 unique)
 //                   with ndt_omp's fp32 per-point maths, accumulated in fp64 registers and reduced by a fixed-order
 //                   wave/LDS tree (one partial per block).  Algorithmic bytes per point: 16 + 7 x 36.
-//   line search   : More-Thuente on the host (scalar logic on 8 doubles); every trial costs one derivative launch and a
-//                   224-byte read-back.
+//   control        : the Newton iteration + More-Thuente line search is the resumable state machine of ndt_mt.hpp.  One pair:
+//                   the host advances it (one launch + 224-byte read-back per evaluation).  A batch of pairs: every pair's
+//                   state lives in HBM and k_ndt_batch_advance advances all of them — no read-back between evaluations.
 #include <cmath>
 
 #include "engine.hpp"
+#include "ndt_mt.hpp"
 #include "primitives.hpp"
 
 namespace mi355 {
@@ -258,12 +260,6 @@ void ndt_cells(hipStream_t s, NdtTarget& t, int64_t* leaf_idx, int* leaf_n, doub
 }
 
 // ---- derivatives ------------------------------------------------------------------------------------------------------
-struct NdtAngles {
-  float jf[8][3];
-  float hf[15][3];
-  double jd[8][3];
-  double hd[15][3];
-};
 struct NdtPassParams {
   float T[16];
   float d1, d2;
@@ -301,15 +297,16 @@ __device__ __forceinline__ int ndt_neighbors7(const HashSlot* table, const NdtGr
 }
 
 // computeDerivatives with ndt_omp's fp32 per-point maths (N3).
-__global__ __launch_bounds__(kNdtBlock) void k_ndt_derivatives(const float4* __restrict__ src, int n, const NdtLeafF* __restrict__ leaves,
-                                                               const HashSlot* __restrict__ table, const NdtGridMeta* __restrict__ meta,
-                                                               NdtAngles A, NdtPassParams P, double* __restrict__ partials) {
-  __shared__ double smem[4 * kNdtAcc];
-  const NdtGridMeta m = *meta;
+// Block `block` of `nblocks` strides over the n source points; its 28 sums go to partials_row[0..27].  The single-pair
+// kernel and the batch kernel (pair state in HBM) share this body, so a pair gets the same sums either way.
+__device__ __forceinline__ void ndt_derivatives_body(const float4* __restrict__ src, int n, const NdtLeafF* __restrict__ leaves,
+                                                     const HashSlot* __restrict__ table, const NdtGridMeta& m, const NdtAngles& A,
+                                                     const NdtPassParams& P, int block, int nblocks, double* __restrict__ partials_row,
+                                                     double* smem) {
   double acc[kNdtAcc];
 #pragma unroll
   for (int k = 0; k < kNdtAcc; k++) acc[k] = 0.0;
-  for (int idx = blockIdx.x * kNdtBlock + threadIdx.x; idx < n; idx += gridDim.x * kNdtBlock) {
+  for (int idx = block * kNdtBlock + threadIdx.x; idx < n; idx += nblocks * kNdtBlock) {
     const float4 xp = src[idx];
     const float xt0 = transform_row(P.T, xp.x, xp.y, xp.z), xt1 = transform_row(P.T + 4, xp.x, xp.y, xp.z), xt2 = transform_row(P.T + 8, xp.x, xp.y, xp.z);
     int nb[7];
@@ -375,19 +372,25 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_derivatives(const float4* __r
   }
   block_sum<kNdtAcc, 4>(acc, smem);
   if (threadIdx.x == 0)
-    for (int k = 0; k < kNdtAcc; k++) partials[(size_t)blockIdx.x * 32 + k] = acc[k];
+    for (int k = 0; k < kNdtAcc; k++) partials_row[k] = acc[k];
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_derivatives(const float4* __restrict__ src, int n, const NdtLeafF* __restrict__ leaves,
+                                                               const HashSlot* __restrict__ table, const NdtGridMeta* __restrict__ meta,
+                                                               NdtAngles A, NdtPassParams P, double* __restrict__ partials) {
+  __shared__ double smem[4 * kNdtAcc];
+  const NdtGridMeta m = *meta;
+  ndt_derivatives_body(src, n, leaves, table, m, A, P, blockIdx.x, gridDim.x, partials + (size_t)blockIdx.x * 32, smem);
 }
 
 // computeHessian / updateHessian: fp64 per-point maths.
-__global__ __launch_bounds__(kNdtBlock) void k_ndt_hessian64(const float4* __restrict__ src, int n, const NdtLeafD* __restrict__ leaves,
-                                                             const HashSlot* __restrict__ table, const NdtGridMeta* __restrict__ meta, NdtAngles A,
-                                                             NdtPassParams P, double* __restrict__ partials) {
-  __shared__ double smem[4 * kNdtAcc];
-  const NdtGridMeta m = *meta;
+__device__ __forceinline__ void ndt_hessian64_body(const float4* __restrict__ src, int n, const NdtLeafD* __restrict__ leaves,
+                                                   const HashSlot* __restrict__ table, const NdtGridMeta& m, const NdtAngles& A,
+                                                   const NdtPassParams& P, int block, int nblocks, double* __restrict__ partials_row, double* smem) {
   double acc[kNdtAcc];
 #pragma unroll
   for (int k = 0; k < kNdtAcc; k++) acc[k] = 0.0;
-  for (int idx = blockIdx.x * kNdtBlock + threadIdx.x; idx < n; idx += gridDim.x * kNdtBlock) {
+  for (int idx = block * kNdtBlock + threadIdx.x; idx < n; idx += nblocks * kNdtBlock) {
     const float4 xp = src[idx];
     const float xt0 = transform_row(P.T, xp.x, xp.y, xp.z), xt1 = transform_row(P.T + 4, xp.x, xp.y, xp.z), xt2 = transform_row(P.T + 8, xp.x, xp.y, xp.z);
     int nb[7];
@@ -446,7 +449,15 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_hessian64(const float4* __res
   }
   block_sum<kNdtAcc, 4>(acc, smem);
   if (threadIdx.x == 0)
-    for (int k = 0; k < kNdtAcc; k++) partials[(size_t)blockIdx.x * 32 + k] = acc[k];
+    for (int k = 0; k < kNdtAcc; k++) partials_row[k] = acc[k];
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_hessian64(const float4* __restrict__ src, int n, const NdtLeafD* __restrict__ leaves,
+                                                             const HashSlot* __restrict__ table, const NdtGridMeta* __restrict__ meta, NdtAngles A,
+                                                             NdtPassParams P, double* __restrict__ partials) {
+  __shared__ double smem[4 * kNdtAcc];
+  const NdtGridMeta m = *meta;
+  ndt_hessian64_body(src, n, leaves, table, m, A, P, blockIdx.x, gridDim.x, partials + (size_t)blockIdx.x * 32, smem);
 }
 
 __global__ __launch_bounds__(64) void k_ndt_reduce(const double* __restrict__ partials, int G, double* __restrict__ sums) {
@@ -457,287 +468,276 @@ __global__ __launch_bounds__(64) void k_ndt_reduce(const double* __restrict__ pa
   sums[l] = s;
 }
 
-// ---- host-side control (N2, N4) -----------------------------------------------------------------------------------------
+
+// ---- executors of the ndt_mt.hpp state machine (N2, N4) ---------------------------------------------------------------------
 namespace {
 
-void angle_tables(const double p[6], NdtAngles& t) {
-  double cx, cy, cz, sx, sy, sz;
-  if (std::fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p[3]); sx = std::sin(p[3]); }
-  if (std::fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p[4]); sy = std::sin(p[4]); }
-  if (std::fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p[5]); sz = std::sin(p[5]); }
-  // eq. 6.19 [Magnusson 2009]: rows a..h
-  const double J[8][3] = {{-sx * sz + cx * sy * cz, -sx * cz - cx * sy * sz, -cx * cy},
-                          {cx * sz + sx * sy * cz, cx * cz - sx * sy * sz, -sx * cy},
-                          {-sy * cz, sy * sz, cy},
-                          {sx * cy * cz, -sx * cy * sz, sx * sy},
-                          {-cx * cy * cz, cx * cy * sz, -cx * sy},
-                          {-cy * sz, -cy * cz, 0},
-                          {cx * cz - sx * sy * sz, -cx * sz - sx * sy * cz, 0},
-                          {sx * cz + cx * sy * sz, cx * sy * cz - sx * sz, 0}};
-  // eq. 6.21: a2 a3 b2 b3 c2 c3 d1 d2 d3 e1 e2 e3 f1 f2 f3
-  const double H[15][3] = {{-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, sx * cy},
-                           {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, -cx * cy},
-                           {cx * cy * cz, -cx * cy * sz, cx * sy},
-                           {sx * cy * cz, -sx * cy * sz, sx * sy},
-                           {-sx * cz - cx * sy * sz, sx * sz - cx * sy * cz, 0},
-                           {cx * cz - sx * sy * sz, -sx * sy * cz - cx * sz, 0},
-                           {-cy * cz, cy * sz, sy},
-                           {-sx * sy * cz, sx * sy * sz, sx * cy},
-                           {cx * sy * cz, -cx * sy * sz, -cx * cy},
-                           {sy * sz, sy * cz, 0},
-                           {-sx * cy * sz, -sx * cy * cz, 0},
-                           {cx * cy * sz, cx * cy * cz, 0},
-                           {-cy * cz, cy * sz, 0},
-                           {-cx * sz - sx * sy * cz, -cx * cz + sx * sy * sz, 0},
-                           {-sx * sz + cx * sy * cz, -cx * sy * sz - sx * cz, 0}};
-  for (int a = 0; a < 8; a++)
-    for (int d = 0; d < 3; d++) { t.jd[a][d] = J[a][d]; t.jf[a][d] = (float)J[a][d]; }
-  for (int a = 0; a < 15; a++)
-    for (int d = 0; d < 3; d++) { t.hd[a][d] = H[a][d]; t.hf[a][d] = (float)H[a][d]; }
+inline int ndt_blocks(int n) { return std::max(1, std::min(1024, div_up(n, kNdtBlock))); }
+
+inline NdtPassParams pass_params(const float* T, const NdtConsts& c, bool hess) {
+  NdtPassParams P;
+  memcpy(P.T, T, sizeof(P.T));
+  P.d1 = (float)c.gd1; P.d2 = (float)c.gd2;
+  P.gd1 = c.gd1; P.gd2 = c.gd2;
+  P.compute_hessian = hess ? 1 : 0;
+  return P;
 }
 
-// Translation<float> * AngleAxis<float>(roll,X) * AngleAxis<float>(pitch,Y) * AngleAxis<float>(yaw,Z), fp32 products
-void pose_to_matrix_f(const double p[6], float T[16]) {
-  const float a = (float)p[3], b = (float)p[4], c = (float)p[5];
-  const float ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b), cc = std::cos(c), sc = std::sin(c);
-  const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca};
-  const float Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb};
-  const float Rz[9] = {cc, -sc, 0, sc, cc, 0, 0, 0, 1};
-  float M[9], R[9];
-  for (int r = 0; r < 3; r++)
-    for (int s = 0; s < 3; s++) M[3 * r + s] = Rx[3 * r] * Ry[s] + Rx[3 * r + 1] * Ry[3 + s] + Rx[3 * r + 2] * Ry[6 + s];
-  for (int r = 0; r < 3; r++)
-    for (int s = 0; s < 3; s++) R[3 * r + s] = M[3 * r] * Rz[s] + M[3 * r + 1] * Rz[3 + s] + M[3 * r + 2] * Rz[6 + s];
-  for (int r = 0; r < 3; r++) {
-    for (int s = 0; s < 3; s++) T[4 * r + s] = R[3 * r + s];
-    T[4 * r + 3] = (float)p[r];
-  }
-  T[12] = T[13] = T[14] = 0.f;
-  T[15] = 1.f;
-}
-
-// Matrix3f::eulerAngles(0,1,2), fp32
-void euler_angles_012(const float T[16], float res[3]) {
-  auto co = [&](int r, int c) { return T[4 * r + c]; };
-  res[0] = std::atan2(co(1, 2), co(2, 2));
-  const float c2 = std::sqrt(co(0, 0) * co(0, 0) + co(0, 1) * co(0, 1));
-  if (res[0] > 0.f) {
-    res[0] -= (float)M_PI;
-    res[1] = std::atan2(-co(0, 2), -c2);
-  } else {
-    res[1] = std::atan2(-co(0, 2), c2);
-  }
-  const float s1 = std::sin(res[0]), c1 = std::cos(res[0]);
-  res[2] = std::atan2(s1 * co(2, 0) - c1 * co(1, 0), c1 * co(1, 1) - s1 * co(2, 1));
-  for (int d = 0; d < 3; d++) res[d] = -res[d];
-}
-
+// one pair: answer a request with one launch and a 224-byte read-back
 struct NdtRun {
   hipStream_t s;
   NdtTarget& t;
   const float4* src;
   int n;
-  double gd1, gd2;
-  NdtAngles ang;  // tables of the last derivative pass (computeHessian reuses them)
-  float T[16];
+  NdtConsts c;
 
-  void gauss(const mi355_ndt_params& p) {
-    const double c1 = 10 * (1 - p.outlier_ratio);
-    const double c2 = p.outlier_ratio / std::pow(p.resolution, 3);
-    const double d3 = -std::log(c2);
-    gd1 = -std::log(c1 + c2) - d3;
-    gd2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / gd1);
-  }
   void prepare() {
-    t.blocks = std::max(1, std::min(1024, div_up(n, kNdtBlock)));
+    t.blocks = ndt_blocks(n);
     t.partials.ensure((size_t)t.blocks * 32);
     t.sums.ensure(32);
     t.h_sums.ensure(32);
   }
-  NdtPassParams pass(bool hess) const {
-    NdtPassParams P;
-    memcpy(P.T, T, sizeof(T));
-    P.d1 = (float)gd1; P.d2 = (float)gd2;
-    P.gd1 = gd1; P.gd2 = gd2;
-    P.compute_hessian = hess ? 1 : 0;
-    return P;
-  }
-  void fetch() {
+  const double* answer(int request, const float* T, const NdtAngles& ang) {
+    const NdtPassParams P = pass_params(T, c, request == NDT_REQ_DERIV_HESS);
+    if (request == NDT_REQ_HESS64)
+      hipLaunchKernelGGL(k_ndt_hessian64, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_d.p, t.table.p, t.meta.p, ang, P, t.partials.p);
+    else
+      hipLaunchKernelGGL(k_ndt_derivatives, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_f.p, t.table.p, t.meta.p, ang, P, t.partials.p);
     hipLaunchKernelGGL(k_ndt_reduce, dim3(1), dim3(64), 0, s, t.partials.p, t.blocks, t.sums.p);
     MI_LAUNCH_CHECK();
     MI_HIP(hipMemcpyAsync(t.h_sums.p, t.sums.p, kNdtAcc * sizeof(double), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
-  }
-  static void unpack_hessian(const double* a, double* H) {
-    int k = 7;
-    for (int i = 0; i < 6; i++)
-      for (int j = i; j < 6; j++) { H[6 * i + j] = a[k]; H[6 * j + i] = a[k]; k++; }
-  }
-  // computeDerivatives at pose p with transform matrix T (already set)
-  double derivatives(const double p[6], double* grad, double* hess, bool compute_hessian) {
-    angle_tables(p, ang);
-    hipLaunchKernelGGL(k_ndt_derivatives, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_f.p, t.table.p, t.meta.p, ang, pass(compute_hessian),
-                       t.partials.p);
-    fetch();
-    for (int k = 0; k < 6; k++) grad[k] = t.h_sums.p[1 + k];
-    if (compute_hessian) unpack_hessian(t.h_sums.p, hess);
-    return t.h_sums.p[0];
-  }
-  void hessian64(double* hess) {
-    hipLaunchKernelGGL(k_ndt_hessian64, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_d.p, t.table.p, t.meta.p, ang, pass(true), t.partials.p);
-    fetch();
-    unpack_hessian(t.h_sums.p, hess);
+    return t.h_sums.p;
   }
 };
 
-inline double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
-inline double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
-
-bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {
-  if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
-  if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
-  if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
-  return true;
-}
-
-double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
-  auto cubic = [](double a0, double f0, double g0, double a1, double f1, double g1) {  // minimiser of the cubic through (a0,f0,g0),(a1,f1,g1)
-    const double z = 3 * (f1 - f0) / (a1 - a0) - g1 - g0;
-    const double w = std::sqrt(z * z - g1 * g0);
-    return a0 + (a1 - a0) * (w - g0 - z) / (g1 - g0 + 2 * w);
-  };
-  if (f_t > f_l) {
-    const double a_c = cubic(a_l, f_l, g_l, a_t, f_t, g_t);
-    const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
-    return (std::fabs(a_c - a_l) < std::fabs(a_q - a_l)) ? a_c : 0.5 * (a_q + a_c);
-  }
-  if (g_t * g_l < 0) {
-    const double a_c = cubic(a_l, f_l, g_l, a_t, f_t, g_t);
-    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-    return (std::fabs(a_c - a_t) >= std::fabs(a_s - a_t)) ? a_c : a_s;
-  }
-  if (std::fabs(g_t) <= std::fabs(g_l)) {
-    const double a_c = cubic(a_l, f_l, g_l, a_t, f_t, g_t);
-    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
-    const double nxt = (std::fabs(a_c - a_t) < std::fabs(a_s - a_t)) ? a_c : a_s;
-    return (a_t > a_l) ? std::min(a_t + 0.66 * (a_u - a_t), nxt) : std::max(a_t + 0.66 * (a_u - a_t), nxt);
-  }
-  return cubic(a_u, f_u, g_u, a_t, f_t, g_t);
+void state_to_result(const NdtPairState& st, mi355_result* out) {
+  memset(out, 0, sizeof(*out));
+  memcpy(out->T, st.T, sizeof(st.T));
+  out->converged = st.converged ? 1 : 0;
+  out->iterations = st.nr_iterations;
+  out->error = st.score;
+  memcpy(out->H, st.hess, sizeof(st.hess));
+  out->trans_probability = st.trans_probability;
+  out->n_source = st.n;
 }
 
 }  // namespace
 
 void ndt_derivatives(hipStream_t s, Workspace&, NdtTarget& t, const float4* d_src, size_t n, const mi355_ndt_params& p, const double* p6, double* score,
                      double* grad6, double* hess36, bool hessian_fp64) {
-  NdtRun run{s, t, d_src, (int)n};
-  run.gauss(p);
+  NdtRun run{s, t, d_src, (int)n, ndt_consts(p)};
   run.prepare();
-  pose_to_matrix_f(p6, run.T);
-  *score = run.derivatives(p6, grad6, hess36, true);
-  if (hessian_fp64) run.hessian64(hess36);
+  float T[16];
+  NdtAngles ang;
+  ndt_pose_to_matrix_f(p6, T);
+  ndt_angle_tables(p6, ang);
+  const double* sums = run.answer(NDT_REQ_DERIV_HESS, T, ang);
+  *score = sums[0];
+  for (int k = 0; k < 6; k++) grad6[k] = sums[1 + k];
+  ndt_unpack_hessian(sums, hess36);
+  if (hessian_fp64) ndt_unpack_hessian(run.answer(NDT_REQ_HESS64, T, ang), hess36);
 }
 
 void ndt_align(hipStream_t s, Workspace&, NdtTarget& t, const float4* d_src, size_t n, const mi355_ndt_params& p, const float* guess16,
                mi355_result* out) {
-  NdtRun run{s, t, d_src, (int)n};
-  run.gauss(p);
+  NdtRun run{s, t, d_src, (int)n, ndt_consts(p)};
   run.prepare();
-  memcpy(run.T, guess16, sizeof(run.T));  // transformPointCloud(output, output, guess): the first pass uses the guess matrix itself
-  int nr_iterations = 0;
-  bool converged = false;
-  double pv[6], delta_p[6], grad[6], hess[36];
-  float eul[3];
-  euler_angles_012(guess16, eul);
-  pv[0] = guess16[3]; pv[1] = guess16[7]; pv[2] = guess16[11];
-  pv[3] = eul[0]; pv[4] = eul[1]; pv[5] = eul[2];
-  float final_T[16];
-  memcpy(final_T, guess16, sizeof(final_T));
-  double score = run.derivatives(pv, grad, hess, true);
-  double trans_probability = 0;
-  bool early = false;
-  while (!converged) {
-    double ng[6];
-    for (int k = 0; k < 6; k++) ng[k] = -grad[k];
-    svd6_solve_sym(hess, ng, delta_p);
-    double nrm = 0;
-    for (int k = 0; k < 6; k++) nrm += delta_p[k] * delta_p[k];
-    nrm = std::sqrt(nrm);
-    if (nrm == 0 || nrm != nrm) {
-      trans_probability = score / (double)n;
-      converged = nrm == nrm;
-      early = true;
-      break;
-    }
-    for (int k = 0; k < 6; k++) delta_p[k] /= nrm;
-    // ---- computeStepLengthMT ----
-    double* dir = delta_p;
-    const double step_init = nrm, step_max = p.step_size, step_min = p.transformation_epsilon / 2;
-    const double phi_0 = -score;
-    double d_phi_0 = 0;
-    for (int k = 0; k < 6; k++) d_phi_0 -= grad[k] * dir[k];
-    double a_t = 0;
-    bool do_search = true;
-    if (d_phi_0 >= 0) {
-      if (d_phi_0 == 0) do_search = false;
-      else {
-        d_phi_0 *= -1;
-        for (int k = 0; k < 6; k++) dir[k] *= -1;
-      }
-    }
-    if (do_search) {
-      const int max_step_iterations = 10;
-      int step_iterations = 0;
-      const double mu = 1.e-4, nu = 0.9;
-      double a_l = 0, a_u = 0;
-      double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
-      double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
-      bool interval_converged = p.legacy_mt_skip ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
-      bool open_interval = true;
-      a_t = std::max(std::min(step_init, step_max), step_min);
-      double x_t[6];
-      for (int k = 0; k < 6; k++) x_t[k] = pv[k] + dir[k] * a_t;
-      pose_to_matrix_f(x_t, run.T);
-      memcpy(final_T, run.T, sizeof(final_T));
-      score = run.derivatives(x_t, grad, hess, true);
-      double phi_t = -score, d_phi_t = 0;
-      for (int k = 0; k < 6; k++) d_phi_t -= grad[k] * dir[k];
-      double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu), d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-      while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        a_t = open_interval ? trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t) : trial_value(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        a_t = std::max(std::min(a_t, step_max), step_min);
-        for (int k = 0; k < 6; k++) x_t[k] = pv[k] + dir[k] * a_t;
-        pose_to_matrix_f(x_t, run.T);
-        memcpy(final_T, run.T, sizeof(final_T));
-        score = run.derivatives(x_t, grad, hess, false);
-        phi_t = -score;
-        d_phi_t = 0;
-        for (int k = 0; k < 6; k++) d_phi_t -= grad[k] * dir[k];
-        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
-        d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
-        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-          open_interval = false;
-          f_l = f_l + phi_0 - mu * d_phi_0 * a_l; g_l = g_l + mu * d_phi_0;
-          f_u = f_u + phi_0 - mu * d_phi_0 * a_u; g_u = g_u + mu * d_phi_0;
-        }
-        interval_converged = open_interval ? update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t)
-                                           : update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
-        step_iterations++;
-      }
-      if (step_iterations) run.hessian64(hess);
-    }
-    const double step = do_search ? a_t : 0.0;
-    for (int k = 0; k < 6; k++) { delta_p[k] *= step; pv[k] += delta_p[k]; }
-    if (nr_iterations > p.max_iterations || (nr_iterations && (std::fabs(step) < p.transformation_epsilon))) converged = true;
-    nr_iterations++;
+  NdtPairState st;
+  ndt_begin(st, guess16, (int)n);
+  while (st.request != NDT_REQ_NONE) ndt_advance(st, run.answer(st.request, st.T, st.ang), run.c);
+  state_to_result(st, out);
+}
+
+// ---- batch: P pairs, every pair's More-Thuente state in HBM -------------------------------------------------------------
+struct NdtTargetRef {
+  const NdtLeafF* leaf_f;
+  const NdtLeafD* leaf_d;
+  const HashSlot* table;
+  const NdtGridMeta* meta;
+};
+
+struct NdtBatch {
+  int P = 0, U = 0;
+  std::vector<NdtTarget*> targets;
+  std::vector<NdtTargetRef> h_refs;
+  DevBuf<NdtTargetRef> refs;
+  DevBuf<NdtPairState> states;
+  DevBuf<int> tgt_of_src, counts, n_active;
+  DevBuf<float> guesses;
+  DevBuf<double> partials;
+  PinnedBuf<int> h_active;
+  std::vector<NdtPairState> h_states;
+  std::vector<int> h_map, h_counts;
+  std::vector<float> h_guess;
+  int rounds = 0;  // evaluation rounds of the last align (diagnostics)
+  ~NdtBatch() {
+    for (auto* t : targets) ndt_target_destroy(t);
   }
-  if (!early) trans_probability = score / (double)n;
-  memset(out, 0, sizeof(*out));
-  memcpy(out->T, final_T, sizeof(final_T));
-  out->converged = converged ? 1 : 0;
-  out->iterations = nr_iterations;
-  out->error = score;
-  memcpy(out->H, hess, sizeof(hess));
-  out->trans_probability = trans_probability;
+};
+
+NdtBatch* ndt_batch_create(int P, int U) {
+  auto* b = new NdtBatch();
+  b->P = P;
+  b->U = U;
+  b->targets.assign((size_t)U, nullptr);
+  for (auto& t : b->targets) t = ndt_target_create();
+  b->h_refs.resize((size_t)U);
+  b->refs.ensure((size_t)U);
+  b->states.ensure((size_t)P);
+  b->tgt_of_src.ensure((size_t)P);
+  b->counts.ensure((size_t)P);
+  b->guesses.ensure((size_t)P * 16);
+  b->n_active.ensure(1);
+  b->h_active.ensure(1);
+  return b;
+}
+void ndt_batch_destroy(NdtBatch* b) { delete b; }
+size_t ndt_batch_num_cells(NdtBatch& b, int u) { return ndt_num_cells(*b.targets[(size_t)u]); }
+int ndt_batch_rounds(const NdtBatch& b) { return b.rounds; }
+
+void ndt_batch_set_target(hipStream_t s, Workspace& ws, NdtBatch& b, int u, const float4* d_pts, size_t n, const mi355_ndt_params& p) {
+  NdtTarget& t = *b.targets[(size_t)u];
+  ndt_build_target(s, ws, t, d_pts, n, p);
+  b.h_refs[(size_t)u] = NdtTargetRef{t.leaf_f.p, t.leaf_d.p, t.table.p, t.meta.p};
+}
+
+__global__ void k_ndt_batch_begin(NdtPairState* __restrict__ states, const float* __restrict__ guesses, const int* __restrict__ counts, int P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float g[16];
+  for (int k = 0; k < 16; k++) g[k] = guesses[16 * p + k];
+  ndt_begin(states[p], g, counts[p]);
+}
+
+__device__ __forceinline__ int ndt_blocks_dev(int n) { return max(1, min(1024, (n + kNdtBlock - 1) / kNdtBlock)); }
+
+// computeDerivatives of every pair that asked for it (blocks of the other pairs leave at once).  grid = xcd_grid(G, P): the
+// blocks of one pair share an XCD, so its target's leaves and hash table are fetched into ONE L2.
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_batch_derivatives(const float4* __restrict__ src, size_t src_cap,
+                                                                     const NdtTargetRef* __restrict__ targets, const int* __restrict__ tgt_of_src,
+                                                                     const NdtPairState* __restrict__ states, NdtConsts c, int P, int G,
+                                                                     double* __restrict__ partials) {
+  __shared__ double smem[4 * kNdtAcc];
+  int pair, bx;
+  if (!xcd_item_chunk(G, P, pair, bx)) return;
+  const NdtPairState& st = states[pair];
+  const int req = st.request;
+  if (req != NDT_REQ_DERIV_HESS && req != NDT_REQ_DERIV) return;
+  const int n = st.n, nb = ndt_blocks_dev(n);
+  if (bx >= nb) return;
+  NdtPassParams Pp;
+  for (int k = 0; k < 16; k++) Pp.T[k] = st.T[k];
+  Pp.d1 = (float)c.gd1; Pp.d2 = (float)c.gd2;
+  Pp.gd1 = c.gd1; Pp.gd2 = c.gd2;
+  Pp.compute_hessian = req == NDT_REQ_DERIV_HESS;
+  const NdtTargetRef tr = targets[tgt_of_src[pair]];
+  const NdtGridMeta m = *tr.meta;
+  ndt_derivatives_body(src + (size_t)pair * src_cap, n, tr.leaf_f, tr.table, m, st.ang, Pp, bx, nb, partials + ((size_t)pair * G + bx) * 32, smem);
+}
+
+__global__ __launch_bounds__(kNdtBlock) void k_ndt_batch_hessian64(const float4* __restrict__ src, size_t src_cap,
+                                                                   const NdtTargetRef* __restrict__ targets, const int* __restrict__ tgt_of_src,
+                                                                   const NdtPairState* __restrict__ states, NdtConsts c, int P, int G,
+                                                                   double* __restrict__ partials) {
+  __shared__ double smem[4 * kNdtAcc];
+  int pair, bx;
+  if (!xcd_item_chunk(G, P, pair, bx)) return;
+  const NdtPairState& st = states[pair];
+  if (st.request != NDT_REQ_HESS64) return;
+  const int n = st.n, nb = ndt_blocks_dev(n);
+  if (bx >= nb) return;
+  NdtPassParams Pp;
+  for (int k = 0; k < 16; k++) Pp.T[k] = st.T[k];
+  Pp.d1 = (float)c.gd1; Pp.d2 = (float)c.gd2;
+  Pp.gd1 = c.gd1; Pp.gd2 = c.gd2;
+  Pp.compute_hessian = 1;
+  const NdtTargetRef tr = targets[tgt_of_src[pair]];
+  const NdtGridMeta m = *tr.meta;
+  ndt_hessian64_body(src + (size_t)pair * src_cap, n, tr.leaf_d, tr.table, m, st.ang, Pp, bx, nb, partials + ((size_t)pair * G + bx) * 32, smem);
+}
+
+// One wave per pair: lanes 0..27 add the pair's block partials in block order (k_ndt_reduce's order), lane 0 advances the
+// pair's state machine to its next request.  n_active (optional) counts the pairs still asking.
+__global__ __launch_bounds__(64) void k_ndt_batch_advance(NdtPairState* __restrict__ states, const double* __restrict__ partials, NdtConsts c, int P,
+                                                          int G, int* __restrict__ n_active) {
+  __shared__ double sums[32];
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  NdtPairState& st = states[pair];
+  if (st.request == NDT_REQ_NONE) return;
+  const int nb = ndt_blocks_dev(st.n);
+  if (lane < kNdtAcc) {
+    double s = 0;
+    for (int g = 0; g < nb; g++) s += partials[((size_t)pair * G + g) * 32 + lane];
+    sums[lane] = s;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    ndt_advance(st, sums, c);
+    if (n_active && st.request != NDT_REQ_NONE) atomicAdd(n_active, 1);
+  }
+}
+
+// src: [P][src_cap] points (any order), h_counts: points per source.  Blocks until every pair is done (the host polls the
+// number of unfinished pairs every few rounds); results stay in b.h_states.
+void ndt_batch_align(hipStream_t s, NdtBatch& b, const float4* d_src, size_t src_cap, const int* h_counts, const int* tgt_of_src_host,
+                     const float* guesses_host, const mi355_ndt_params& p) {
+  const int P = b.P;
+  const NdtConsts c = ndt_consts(p);
+  b.h_map.resize((size_t)P);
+  b.h_counts.assign(h_counts, h_counts + P);
+  b.h_guess.resize((size_t)P * 16);
+  int G = 1;
+  for (int i = 0; i < P; i++) {
+    const int u = tgt_of_src_host ? tgt_of_src_host[i] : i;
+    if (u < 0 || u >= b.U) throw ArgError(MI355_EINVAL, "tgt_of_src entry out of range");
+    b.h_map[(size_t)i] = u;
+    G = std::max(G, ndt_blocks(h_counts[i]));
+    for (int k = 0; k < 16; k++) b.h_guess[(size_t)i * 16 + k] = guesses_host ? guesses_host[(size_t)i * 16 + k] : ((k % 5 == 0) ? 1.f : 0.f);
+  }
+  b.partials.ensure((size_t)P * G * 32);
+  MI_HIP(hipMemcpyAsync(b.refs.p, b.h_refs.data(), (size_t)b.U * sizeof(NdtTargetRef), hipMemcpyHostToDevice, s));
+  MI_HIP(hipMemcpyAsync(b.tgt_of_src.p, b.h_map.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, s));
+  MI_HIP(hipMemcpyAsync(b.counts.p, b.h_counts.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, s));
+  MI_HIP(hipMemcpyAsync(b.guesses.p, b.h_guess.data(), (size_t)P * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_ndt_batch_begin, dim3(div_up(P, 64)), dim3(64), 0, s, b.states.p, b.guesses.p, b.counts.p, P);
+  // every request is one round; a Newton iteration is 1 round with the legacy line search (the default), up to 12 without
+  const int per_iter = p.legacy_mt_skip ? 1 : (kNdtMaxStepIterations + 2);
+  const long max_rounds = 1 + (long)(p.max_iterations + 2) * per_iter;
+  const int chunk = 4;
+  const dim3 grid(xcd_grid(G, P));
+  b.rounds = 0;
+  for (long r = 0; r < max_rounds;) {
+    MI_HIP(hipMemsetAsync(b.n_active.p, 0, sizeof(int), s));
+    for (int k = 0; k < chunk; k++, r++) {
+      hipLaunchKernelGGL(k_ndt_batch_derivatives, grid, dim3(kNdtBlock), 0, s, d_src, src_cap, b.refs.p, b.tgt_of_src.p, b.states.p, c, P, G,
+                         b.partials.p);
+      if (!p.legacy_mt_skip)  // computeHessian is only ever requested after a refined line search
+        hipLaunchKernelGGL(k_ndt_batch_hessian64, grid, dim3(kNdtBlock), 0, s, d_src, src_cap, b.refs.p, b.tgt_of_src.p, b.states.p, c, P, G,
+                           b.partials.p);
+      hipLaunchKernelGGL(k_ndt_batch_advance, dim3(P), dim3(64), 0, s, b.states.p, b.partials.p, c, P, G, (k == chunk - 1) ? b.n_active.p : nullptr);
+    }
+    MI_LAUNCH_CHECK();
+    b.rounds = (int)r;
+    MI_HIP(hipMemcpyAsync(b.h_active.p, b.n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (*b.h_active.p == 0) break;
+  }
+  b.h_states.resize((size_t)P);
+  MI_HIP(hipMemcpyAsync(b.h_states.data(), b.states.p, (size_t)P * sizeof(NdtPairState), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void ndt_batch_results(NdtBatch& b, mi355_result* out, float* T16_all) {
+  for (int i = 0; i < b.P; i++) {
+    const NdtPairState& st = b.h_states[(size_t)i];
+    if (out) {
+      state_to_result(st, &out[i]);
+      // a pair cut off by the round budget (it cannot happen within max_iterations) reports what it has, not converged
+      if (st.request != NDT_REQ_NONE) out[i].converged = 0;
+    }
+    if (T16_all) memcpy(T16_all + (size_t)i * 16, st.T, 16 * sizeof(float));
+  }
 }
 
 }  // namespace mi355

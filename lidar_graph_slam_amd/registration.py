@@ -262,13 +262,21 @@ class IterativeClosestPoint(_Registration):
 
 
 class BatchRegistration:
-    """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one GICP per pair."""
+    """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one registration per pair —
+    FAST_GICP (default) or NDT_OMP, the two engines GraphBasedSLAM::get_registration offers besides ICP
+    (graph_based_slam.cpp:101-152)."""
 
-    def __init__(self, n_sources: int, n_targets: int, capacity: int, ctx: Context | None = None, **params):
+    def __init__(self, n_sources: int, n_targets: int, capacity: int, ctx: Context | None = None, method: str = "FAST_GICP", **params):
         self.ctx = ctx or default_context()
-        self.params = L.gicp_params(**params)
+        if method == "FAST_GICP":
+            self.params, code = L.gicp_params(**params), L.METHOD_FAST_GICP
+        elif method == "NDT_OMP":
+            self.params, code = L.ndt_params(**params), L.METHOD_NDT_OMP
+        else:
+            raise L.Mi355Error(L.EINVAL, f"batch registration method {method!r} (FAST_GICP or NDT_OMP)")
+        self.method = method
         self.n_sources, self.n_targets, self.capacity = int(n_sources), int(n_targets), int(capacity)
-        self.handle = self.ctx._lib.mi355_batch_create(self.ctx.handle, L.METHOD_FAST_GICP, C.byref(self.params), self.n_sources, self.n_targets,
+        self.handle = self.ctx._lib.mi355_batch_create(self.ctx.handle, code, C.byref(self.params), self.n_sources, self.n_targets,
                                                        self.capacity)
         if not self.handle:
             raise L.Mi355Error(L.EINVAL, self.ctx._lib.mi355_last_error(self.ctx.handle).decode())

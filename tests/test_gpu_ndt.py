@@ -83,3 +83,69 @@ def test_align(R, medium_pair):
     dt, dr = synth.pose_error(reg.getFinalTransformation(), ref1["T"])
     assert reg.hasConverged() and dt <= 0.01 and dr <= 2e-3, (dt, dr)
     assert abs(reg.getTransformationProbability() - ref1["trans_probability"]) < 0.05 * abs(ref1["trans_probability"])
+
+
+@pytest.mark.parametrize("legacy", [1, 0])
+def test_batch_matches_single_and_oracle(R, small_pair, legacy):
+    """Batch mode with NDT_OMP (graph_based_slam.cpp:101-119 offers it for loop candidates): every pair's Newton /
+    More-Thuente state advances on the device.  Ragged sources, two targets, guesses; both line-search variants (with
+    legacy = 0 the interval refinement and the fp64 computeHessian requests run on the device too)."""
+    s, t, T = small_pair
+    cap = max(len(s), len(t)) + 7
+    nS, nT = 6, 2
+    srcs = np.zeros((nS, cap, 4), np.float32)
+    tgts = np.zeros((nT, cap, 4), np.float32)
+    shifts = [np.eye(4, dtype=np.float32), synth.se3(0.2, -0.1, 0, 0, 0, 0.01).astype(np.float32)]
+    nt, ns = [], []
+    for j in range(nT):
+        tj = O.transform(t, shifts[j])
+        tgts[j, : len(tj)] = tj
+        nt.append(len(tj))
+    for i in range(nS):
+        si = s[: len(s) - 13 * i]
+        srcs[i, : len(si)] = si
+        ns.append(len(si))
+    ns[5] = 0  # an empty source: no derivatives, reported as the reference reports a zero Newton step
+    tgt_of_src = [0, 1, 0, 1, 1, 0]
+    guesses = np.tile(np.eye(4, dtype=np.float32), (nS, 1, 1))
+    guesses[2] = synth.se3(0.3, 0.05, 0, 0, 0, 0.01)
+    guesses[3] = synth.se3(0.5, -0.1, 0, 0, 0, -0.01)
+    kw = dict(resolution=2.0, step_size=0.1, transformation_epsilon=0.01, max_iterations=64, legacy_mt_skip=legacy)
+    b = R.BatchRegistration(nS, nT, cap, method="NDT_OMP", **kw)
+    b.set_targets(tgts, nt)
+    b.set_sources(srcs, ns)
+    b.align(tgt_of_src, guesses=guesses, with_fitness=True)
+    res, fit = b.results(with_fitness=True)
+    single = R.NormalDistributionsTransform(**kw)
+    for i in range(nS - 1):
+        si, ti = srcs[i, : ns[i]], tgts[tgt_of_src[i], : nt[tgt_of_src[i]]]
+        single.setInputTarget(ti)
+        single.setInputSource(si)
+        single.align(guesses[i])
+        ref = O.ndt_align(si, ti, O.ndt_params(**kw), guess=guesses[i])
+        r = res[i]
+        assert r["converged"] and single.hasConverged() and ref["converged"], i
+        # same state machine, same per-point maths: the batch differs from the single path only in the summation order of
+        # the points (Morton-sorted vs caller order) and in device vs host libm for the 6 angles
+        dt, dr = synth.pose_error(r["T"], single.getFinalTransformation())
+        assert dt <= 2e-3 and dr <= 5e-4, (i, dt, dr)
+        assert abs(r["iterations"] - single._result["iterations"]) <= 1, (i, r["iterations"], single._result["iterations"])
+        dt, dr = synth.pose_error(r["T"], ref["T"])
+        assert dt <= 0.01 and dr <= 2e-3, (i, dt, dr)  # the convergence band of test_align
+        assert abs(r["trans_probability"] - ref["trans_probability"]) < 0.05 * abs(ref["trans_probability"])
+        assert r["n_source"] == ns[i] and r["n_target"] == nt[tgt_of_src[i]]
+        np.testing.assert_allclose(fit[i], O.fitness(si, ti, r["T"]), rtol=1e-9)
+    assert res[5]["iterations"] == 0 and res[5]["n_source"] == 0
+    # a second align on the same object (new guesses) reuses the targets' leaves
+    b.align(tgt_of_src, with_fitness=False)
+    res2 = b.results()
+    dt, dr = synth.pose_error(res2[0]["T"], res[0]["T"])
+    assert dt == 0 and dr == 0  # pairs 0, 1, 4 had the identity guess already: bit-identical rerun
+    b.close()
+
+
+def test_batch_rejects_other_methods(R):
+    from lidar_graph_slam_amd import _lib as L
+
+    with pytest.raises(L.Mi355Error):
+        R.BatchRegistration(2, 2, 128, method="ICP")
