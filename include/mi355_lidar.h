@@ -203,6 +203,9 @@ mi355_cloud* mi355_cloud_concat(mi355_ctx* ctx, mi355_cloud* const* clouds, cons
 /* fast_gicp's calculate_covariances for a cloud that has not been a registration source (key frame #0 of the odometry node is
  * the first TARGET): computed once, kept with the cloud. */
 int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k_correspondences, int regularization_method);
+/* PointsPreFiltering's chain (points_prefiltering.cpp:66-100; VoxelGrid alone = graph_based_slam.cpp:311-313) on a
+ * device-resident cloud: a NEW device cloud, nothing crosses PCIe but the resulting point count. */
+mi355_cloud* mi355_cloud_prefilter(mi355_cloud* cloud, const mi355_prefilter_params* params);
 /* setInputSource / setInputTarget from a device cloud.  FAST_GICP: a source cloud without covariances gets them computed and
  * cached (same k / regularisation as the registration object); a target cloud that carries covariances uses them instead
  * of recomputing over the union (carry_covariances above), one that does not gets them computed as mi355_reg_set_target does. */

@@ -121,7 +121,7 @@ EXPORTS = [
     "mi355_reg_create", "mi355_reg_destroy", "mi355_reg_set_params", "mi355_reg_set_target", "mi355_reg_set_source", "mi355_reg_align",
     "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
     "mi355_cloud_upload", "mi355_cloud_destroy", "mi355_cloud_size", "mi355_cloud_has_covariances", "mi355_cloud_download", "mi355_cloud_transform",
-    "mi355_cloud_concat", "mi355_cloud_compute_covariances", "mi355_reg_set_source_cloud", "mi355_reg_set_target_cloud",
+    "mi355_cloud_concat", "mi355_cloud_compute_covariances", "mi355_cloud_prefilter", "mi355_reg_set_source_cloud", "mi355_reg_set_target_cloud",
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
     "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
@@ -150,6 +150,9 @@ class LoopClosureParams(C.Structure):
         ("transformation_epsilon", C.c_double),
         ("max_correspondence_distance", C.c_double),
         ("correspondence_randomness", C.c_int),
+        ("registration_method", C.c_int),
+        ("step_size", C.c_double),
+        ("ndt_resolution", C.c_double),
     ]
 
 
@@ -250,6 +253,8 @@ def lib():
         L.mi355_cloud_concat.restype = C.c_void_p
         L.mi355_cloud_concat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.mi355_cloud_compute_covariances.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mi355_cloud_prefilter.restype = C.c_void_p
+        L.mi355_cloud_prefilter.argtypes = [C.c_void_p, C.POINTER(PrefilterParams)]
         L.mi355_reg_set_source_cloud.argtypes = [C.c_void_p, C.c_void_p]
         L.mi355_reg_set_target_cloud.argtypes = [C.c_void_p, C.c_void_p]
         L.mi355_batch_set_targets_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]

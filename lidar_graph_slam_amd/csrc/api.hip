@@ -84,6 +84,7 @@ struct FilterScratch {
   Uploader up;
   DevBuf<float4> a, b;
   DevBuf<int> na, nb;
+  PinnedBuf<int> h_n;
   CloudSet set;
   DevBuf<int> idx;
   DevBuf<float> f;
@@ -777,6 +778,37 @@ extern "C" mi355_cloud* mi355_cloud_transform(mi355_cloud* cloud, const float T1
   if (!cloud || !T16) return nullptr;
   mi355_cloud* one[1] = {cloud};
   return mi355_cloud_concat(cloud->ctx, one, T16, 1, cloud->has_cov ? 1 : 0);
+}
+
+extern "C" mi355_cloud* mi355_cloud_prefilter(mi355_cloud* cloud, const mi355_prefilter_params* p) {
+  if (!cloud || !p) return nullptr;
+  mi355_ctx* ctx = cloud->ctx;
+  mi355_cloud* out = nullptr;
+  const int rc = guarded(ctx, [&] {
+    MI_HIP(hipSetDevice(ctx->device));
+    out = new mi355_cloud();
+    out->ctx = ctx;
+    if (cloud->n == 0) return;
+    FilterScratch& fs = extras(ctx)->fs;
+    fs.na.ensure(1);
+    fs.h_n.ensure(1);
+    *fs.h_n.p = (int)cloud->n;
+    MI_HIP(hipMemcpyAsync(fs.na.p, fs.h_n.p, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    const float4* res;
+    const int* nres;
+    run_prefilter(ctx->stream, fs.ws, fs.set, ctx->grid_cell, *p, 1, cloud->n, cloud->pts.p, fs.na.p, fs.ws.stage_a, fs.ws.stage_b, fs.ws.count_a,
+                  fs.ws.count_b, &res, &nres);
+    MI_HIP(hipMemcpyAsync(fs.h_n.p, nres, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    out->n = (size_t)*fs.h_n.p;
+    out->pts.ensure(std::max<size_t>(out->n, 1));
+    if (out->n) MI_HIP(hipMemcpyAsync(out->pts.p, res, out->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  });
+  if (rc != MI355_OK) {
+    delete out;
+    return nullptr;
+  }
+  return out;
 }
 
 extern "C" int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k, int method) {

@@ -38,6 +38,7 @@ int LoopClosureCore::candidate(int query) const {
 }
 
 LoopClosureCore::~LoopClosureCore() {
+  icp_.reset();
   if (batch_) mi355_batch_destroy(batch_);
   key_frames_.clear();  // device clouds go before the context
 }
@@ -102,39 +103,71 @@ std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) 
   }
   const int S = (int)source.size(), U = (int)uniq.size();
 
-  mi355_gicp_params gp;
-  mi355_gicp_default_params(&gp);  // fast_gicp defaults, then the setters of :92-96
-  gp.k_correspondences = params_.correspondence_randomness;
-  gp.max_iterations = params_.max_iteration;
-  gp.transformation_epsilon = params_.transformation_epsilon;
-  gp.max_correspondence_distance = params_.max_correspondence_distance;
-  if (!batch_ || S > batch_S_ || U > batch_U_ || cap > batch_cap_) {  // grow-only
-    if (batch_) mi355_batch_destroy(batch_);
-    batch_S_ = std::max(S, batch_S_); batch_U_ = std::max(U, batch_U_); batch_cap_ = std::max(cap, batch_cap_);
-    batch_ = mi355_batch_create(ctx_->get(), MI355_METHOD_FAST_GICP, &gp, batch_S_, batch_U_, batch_cap_);
-    if (!batch_) {
-      batch_S_ = batch_U_ = 0;
-      batch_cap_ = 0;
-      throw Error(MI355_EHIP, mi355_last_error(ctx_->get()));
+  std::vector<mi355_result> res((size_t)std::max(S, batch_S_));
+  std::vector<double> fit((size_t)std::max(S, batch_S_));
+  const mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
+  if (params_.registration_method == MI355_METHOD_ICP) {
+    // pcl::IterativeClosestPoint, one candidate at a time as the reference does (:315-321), everything device-resident
+    if (!icp_) {
+      icp_.reset(new IterativeClosestPoint(*ctx_));
+      icp_->setMaxCorrespondenceDistance(30);  // :145-149
+      icp_->setMaximumIterations(100);
+      icp_->setTransformationEpsilon(1e-8);
+      icp_->setEuclideanFitnessEpsilon(1e-6);
+      icp_->setRANSACIterations(0);
     }
+    std::vector<DeviceCloud::Ptr> filtered((size_t)U);
+    for (int u = 0; u < U; u++) filtered[(size_t)u] = submap[(size_t)u]->prefiltered(pf);
+    for (int s = 0; s < S; s++) {
+      const size_t u = (size_t)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
+      icp_->setInputTarget(filtered[u]);
+      icp_->setInputSource(source[(size_t)s]);
+      icp_->align(identity4());
+      res[(size_t)s] = icp_->result();
+      res[(size_t)s].n_target = (int)filtered[u]->size();
+      fit[(size_t)s] = icp_->getFitnessScore();
+    }
+  } else {
+    mi355_gicp_params gp;
+    mi355_gicp_default_params(&gp);  // fast_gicp defaults, then the setters of :92-96
+    gp.k_correspondences = params_.correspondence_randomness;
+    gp.max_iterations = params_.max_iteration;
+    gp.transformation_epsilon = params_.transformation_epsilon;
+    gp.max_correspondence_distance = params_.max_correspondence_distance;
+    mi355_ndt_params np;
+    mi355_ndt_default_params(&np);   // :108-116
+    np.transformation_epsilon = params_.transformation_epsilon;
+    np.step_size = params_.step_size;
+    np.resolution = params_.ndt_resolution;
+    np.max_iterations = params_.max_iteration;
+    const bool ndt = params_.registration_method == MI355_METHOD_NDT_OMP;
+    if (!batch_ || S > batch_S_ || U > batch_U_ || cap > batch_cap_) {  // grow-only
+      if (batch_) mi355_batch_destroy(batch_);
+      batch_S_ = std::max(S, batch_S_); batch_U_ = std::max(U, batch_U_); batch_cap_ = std::max(cap, batch_cap_);
+      batch_ = mi355_batch_create(ctx_->get(), params_.registration_method, ndt ? (const void*)&np : (const void*)&gp, batch_S_, batch_U_, batch_cap_);
+      if (!batch_) {
+        batch_S_ = batch_U_ = 0;
+        batch_cap_ = 0;
+        throw Error(MI355_EHIP, mi355_last_error(ctx_->get()));
+      }
+      res.resize((size_t)batch_S_);
+      fit.resize((size_t)batch_S_);
+    }
+    mi355_batch* b = batch_;
+    // unused slots of the persistent batch get an empty cloud
+    PointCloud none;
+    DeviceCloud::Ptr empty = DeviceCloud::upload(*ctx_, none);
+    std::vector<mi355_cloud*> th((size_t)batch_U_, empty->get()), sh((size_t)batch_S_, empty->get());
+    for (int u = 0; u < U; u++) th[(size_t)u] = submap[(size_t)u]->get();
+    for (int s2 = 0; s2 < S; s2++) sh[(size_t)s2] = source[(size_t)s2]->get();
+    ctx_->check(mi355_batch_set_targets_clouds(b, th.data(), &pf));
+    ctx_->check(mi355_batch_set_sources_clouds(b, sh.data(), nullptr));
+    std::vector<int> tgt_of_src((size_t)batch_S_, 0);
+    for (int s = 0; s < S; s++)
+      tgt_of_src[(size_t)s] = (int)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
+    ctx_->check(mi355_batch_align(b, tgt_of_src.data(), nullptr /* align(*output): identity guess, :318 */, /*with_fitness=*/1));
+    ctx_->check(mi355_batch_results(b, res.data(), fit.data()));
   }
-  mi355_batch* b = batch_;
-  // unused slots of the persistent batch get an empty cloud
-  PointCloud none;
-  DeviceCloud::Ptr empty = DeviceCloud::upload(*ctx_, none);
-  std::vector<mi355_cloud*> th((size_t)batch_U_, empty->get()), sh((size_t)batch_S_, empty->get());
-  for (int u = 0; u < U; u++) th[(size_t)u] = submap[(size_t)u]->get();
-  for (int s2 = 0; s2 < S; s2++) sh[(size_t)s2] = source[(size_t)s2]->get();
-  mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
-  ctx_->check(mi355_batch_set_targets_clouds(b, th.data(), &pf));
-  ctx_->check(mi355_batch_set_sources_clouds(b, sh.data(), nullptr));
-  std::vector<int> tgt_of_src((size_t)batch_S_, 0);
-  for (int s = 0; s < S; s++)
-    tgt_of_src[(size_t)s] = (int)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
-  ctx_->check(mi355_batch_align(b, tgt_of_src.data(), nullptr /* align(*output): identity guess, :318 */, /*with_fitness=*/1));
-  std::vector<mi355_result> res((size_t)batch_S_);
-  std::vector<double> fit((size_t)batch_S_);
-  ctx_->check(mi355_batch_results(b, res.data(), fit.data()));
 
   for (int s = 0; s < S; s++) {
     LoopResult& r = out[src_of[(size_t)s]];
@@ -208,10 +241,15 @@ extern "C" void mi355_loop_closure_default_params(mi355_loop_closure_params* p) 
   p->transformation_epsilon = d.transformation_epsilon;
   p->max_correspondence_distance = d.max_correspondence_distance;
   p->correspondence_randomness = d.correspondence_randomness;
+  p->registration_method = d.registration_method;
+  p->step_size = d.step_size;
+  p->ndt_resolution = d.ndt_resolution;
 }
 
 extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi355_loop_closure_params* p) {
   if (!p || p->search_key_frame_num < 0 || !(p->submap_leaf >= 0.f)) return nullptr;
+  if (p->registration_method != MI355_METHOD_FAST_GICP && p->registration_method != MI355_METHOD_NDT_OMP && p->registration_method != MI355_METHOD_ICP)
+    return nullptr;  // "GICP" (pclomp BFGS) is not built; unknown strings leave the reference with a null registration too (:153)
   mi355::LoopClosureParams lp;
   lp.search_key_frame_num = p->search_key_frame_num;
   lp.score_threshold = p->score_threshold;
@@ -222,6 +260,9 @@ extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi
   lp.transformation_epsilon = p->transformation_epsilon;
   lp.max_correspondence_distance = p->max_correspondence_distance;
   lp.correspondence_randomness = p->correspondence_randomness;
+  lp.registration_method = p->registration_method;
+  lp.step_size = p->step_size;
+  lp.ndt_resolution = p->ndt_resolution;
   auto* h = new mi355_loop_closure();
   h->core.reset(new mi355::LoopClosureCore(device_id, lp));
   return h;

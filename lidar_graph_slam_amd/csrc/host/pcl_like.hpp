@@ -99,6 +99,8 @@ class DeviceCloud {
   size_t size() const { return mi355_cloud_size(h_); }
   bool has_covariances() const { return mi355_cloud_has_covariances(h_) != 0; }
   void compute_covariances(int k, int method) { ctx_.check(mi355_cloud_compute_covariances(h_, k, method)); }
+  // points_prefiltering.cpp:66-100 on the device (VoxelGrid alone: graph_based_slam.cpp:311-313)
+  Ptr prefiltered(const mi355_prefilter_params& pf) const { return wrap(ctx_, mi355_cloud_prefilter(h_, &pf)); }
   void download(PointCloud& out) const {
     std::vector<float> packed(4 * std::max<size_t>(size(), 1));
     ctx_.check(mi355_cloud_download(h_, packed.data(), packed.size() / 4));
@@ -275,6 +277,20 @@ class NormalDistributionsTransform : public Registration {  // pclomp::NormalDis
  protected:
   const void* params_ptr() const override { return &p_; }
   mi355_ndt_params p_;
+};
+
+class IterativeClosestPoint : public Registration {  // pcl::IterativeClosestPoint<PointXYZI, PointXYZI>
+ public:
+  explicit IterativeClosestPoint(Context& ctx) : Registration(ctx, MI355_METHOD_ICP, nullptr) { mi355_icp_default_params(&p_); }
+  void setMaxCorrespondenceDistance(double d) { p_.max_correspondence_distance = d; dirty_ = true; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; dirty_ = true; }
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; dirty_ = true; }
+  void setEuclideanFitnessEpsilon(double e) { p_.euclidean_fitness_epsilon = e; dirty_ = true; }
+  void setRANSACIterations(int n) { p_.ransac_iterations = n; dirty_ = true; }  // only 0 is built (graph_based_slam.cpp:149)
+
+ protected:
+  const void* params_ptr() const override { return &p_; }
+  mi355_icp_params p_;
 };
 
 }  // namespace mi355

@@ -215,6 +215,21 @@ __global__ __launch_bounds__(256) void k_ndt_bounds(const float4* __restrict__ p
 void ndt_build_target(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_pts, size_t n, const mi355_ndt_params& p) {
   if (!(p.resolution > 0)) throw ArgError(MI355_EINVAL, "ndt resolution must be positive");
   t.n_pts = n;
+  if (n == 0) {  // an empty target (an unused slot of a batch): no voxel exists, every lookup falls outside the grid
+    t.leaf_f.ensure(1); t.leaf_d.ensure(1); t.leaf_key.ensure(1);
+    t.slots = 16;
+    t.table.ensure(t.slots);
+    t.meta.ensure(1);
+    NdtGridMeta m{};
+    for (int d = 0; d < 3; d++) { m.min_b[d] = 0; m.max_b[d] = -1; m.div_b[d] = 0; }
+    m.inv_leaf = 1.0f / (float)p.resolution;
+    m.hshift = 28; m.hmask = 15; m.n_leaves = 0;
+    t.h_meta = m;
+    hipLaunchKernelGGL(k_ndt_table_clear, dim3(1), dim3(256), 0, s, t.table.p, t.slots);
+    MI_HIP(hipMemcpyAsync(t.meta.p, &t.h_meta, sizeof(NdtGridMeta), hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+    return;
+  }
   ws_reserve(ws, 1, n);
   t.leaf_f.ensure(n); t.leaf_d.ensure(n); t.leaf_key.ensure(n);
   size_t slots = 16;

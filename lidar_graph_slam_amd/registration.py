@@ -41,6 +41,11 @@ class DeviceCloud:
         T = np.ascontiguousarray(np.asarray(Ts, dtype=np.float32).reshape(len(clouds), 16))
         return DeviceCloud(ctx._lib.mi355_cloud_concat(ctx.handle, hs, T.ctypes.data, len(clouds), 1 if carry_covariances else 0), ctx)
 
+    def prefiltered(self, min_distance=0.0, leaf_size=0.0, mean_k=0, stddev_mul=0.0):
+        """PointsPreFiltering's chain on the device: a new DeviceCloud (VoxelGrid alone = graph_based_slam.cpp:311-313)."""
+        pf = L.PrefilterParams(float(min_distance), float(leaf_size), int(mean_k), float(stddev_mul))
+        return DeviceCloud(self.ctx._lib.mi355_cloud_prefilter(self.handle, C.byref(pf)), self.ctx)
+
     def compute_covariances(self, k=20, method=L.REG_PLANE):
         self.ctx.check(self.ctx._lib.mi355_cloud_compute_covariances(self.handle, int(k), int(method)))
 

@@ -74,3 +74,17 @@ def test_source_covariances_are_computed_once_and_cached(small_pair):
     ref = O.gicp_align(s, t, O.gicp_params(max_iterations=8, force_iterations=1))
     dt, dr = synth.pose_error(T1, ref["T"])
     assert dt <= 1e-3 and dr <= 1e-4
+
+
+def test_prefilter_of_a_device_cloud_is_bit_equal_to_the_oracle(medium_pair):
+    """mi355_cloud_prefilter: the sub-map VoxelGrid of graph_based_slam.cpp:311-313 (and the whole points_prefiltering chain)
+    without leaving the device."""
+    from lidar_graph_slam_amd.registration import DeviceCloud
+
+    src, _, _ = medium_pair
+    d = DeviceCloud.upload(src)
+    np.testing.assert_array_equal(d.prefiltered(leaf_size=0.5).download(), O.voxel_grid(src, 0.5)[0])
+    np.testing.assert_array_equal(d.prefiltered(min_distance=1.0, leaf_size=0.2).download(), O.voxel_grid(O.distance_filter(src, 1.0), 0.2)[0])
+    np.testing.assert_array_equal(d.prefiltered(min_distance=1.0).download(), O.distance_filter(src, 1.0))
+    empty = DeviceCloud.upload(np.zeros((0, 4), np.float32)).prefiltered(leaf_size=0.5)
+    assert len(empty) == 0

@@ -18,12 +18,16 @@ def _out_and_back(n_out=16, spacing=2.5):
     return poses
 
 
-def test_batched_loop_closure_matches_restatement():
+@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP", "ICP"])
+def test_batched_loop_closure_matches_restatement(method):
+    """All three engines GraphBasedSLAM::get_registration can build here (graph_based_slam.cpp:74-155; "ICP" is the yaml's
+    default): FAST_GICP and NDT_OMP register every candidate in one batch, ICP pair by pair on the device-resident clouds."""
     from lidar_graph_slam_amd.loop_closure import LoopClosure
 
     scene = synth.Scene(1234)
     truth = _out_and_back()
-    kw = dict(search_key_frame_num=2, search_for_candidate_threshold=6.0, accumulate_distance_threshold=50.0, max_iteration=30)
+    kw = dict(search_key_frame_num=2, search_for_candidate_threshold=6.0, accumulate_distance_threshold=50.0, max_iteration=30,
+              registration_method=method)
     lc, ref = LoopClosure(**kw), RefLoopClosure(**kw)
     accum = 0.0
     for i, T in enumerate(truth):
@@ -48,13 +52,15 @@ def test_batched_loop_closure_matches_restatement():
         assert g["target_points"] == w["target_points"]  # same sub-map after the 0.5 m VoxelGrid
         assert g["converged"] == w["converged"] and g["accepted"] == w["accepted"]
         dt, dr = synth.pose_error(g["T"], w["T"])
-        assert dt < 0.02 and dr < 4e-3, (g["query_id"], dt, dr)  # both stop inside the 0.01 m / 2e-3 rad convergence band
+        assert dt < 0.02 and dr < 4e-3, (method, g["query_id"], dt, dr)  # both stop inside the 0.01 m / 2e-3 rad convergence band
         # the fitness the GPU reports is the reference's getFitnessScore at the GPU's own pose
         np.testing.assert_allclose(g["fitness"], O.fitness(w["source"], w["target"], g["T"]), rtol=1e-6)
         # the correction undoes the drift: the corrected pose is the true one
         corrected = g["T"].astype(np.float64) @ (synth.se3(0.25, -0.15, 0.0, 0.0, 0.0, 0.01) @ truth[g["query_id"]])
         dt, dr = synth.pose_error(corrected, truth[g["query_id"]])
-        assert dt < 0.05 and dr < 5e-3, (dt, dr)
+        # (the oracle lands on the same poses, see above; NDT with 1 m cells on 11 k-point key frames and point-to-point ICP are coarser)
+        tol_t, tol_r = (0.05, 5e-3) if method == "FAST_GICP" else (0.12, 1.5e-2)
+        assert dt < tol_t and dr < tol_r, (method, dt, dr)
         bt, br = synth.pose_error(g["between"], w["between"])
         assert bt < 0.03 and br < 5e-3
     assert n_registered >= 4

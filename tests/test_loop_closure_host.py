@@ -13,6 +13,15 @@ def test_default_params_match_reference_yaml():
     # graph_based_slam.param.yaml:4,6-8,12,14,21,23 and the leaf of graph_based_slam.cpp:61
     assert (p.search_key_frame_num, p.score_threshold, p.search_for_candidate_threshold, p.accumulate_distance_threshold) == (20, 0.3, 15.0, 100.0)
     assert (p.submap_leaf, p.max_iteration, p.transformation_epsilon, p.max_correspondence_distance, p.correspondence_randomness) == (0.5, 100, 0.01, 2.0, 20)
+    # yaml:9 registration_method "ICP", yaml:17-18 step_size / ndt_resolution
+    assert (p.registration_method, p.step_size, p.ndt_resolution) == (L.METHOD_ICP, 0.1, 1.0)
+
+
+def test_unbuilt_registration_method_is_refused():
+    import pytest
+
+    with pytest.raises(L.Mi355Error):
+        LoopClosure(registration_method="GICP")  # pclomp's BFGS variant (graph_based_slam.cpp:120-141) is not built
 
 
 def test_candidate_gate_matches_restatement():
