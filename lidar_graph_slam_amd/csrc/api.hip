@@ -20,6 +20,9 @@ const Tuning& tuning() {
     auto getf = [](const char* name, float& dst) { if (const char* e = getenv(name)) { const float f = (float)atof(e); if (f > 0.f) dst = f; } };
     geti("MI355_BLOCKS_PER_PAIR", v.blocks_per_pair);
     geti("MI355_PPT", v.corr_ppt);
+    geti("MI355_CORR_TILES", v.corr_tiles);
+    geti("MI355_CORR_STATS", v.corr_stats);
+    getf("MI355_CORR_R1", v.corr_r1);
     geti("MI355_BLOCKS_LIN", v.blocks_lin);
     geti("MI355_LIN_PPT", v.lin_ppt);
     geti("MI355_KNN_TILES", v.knn_tiles);
@@ -1200,6 +1203,7 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
       }
     } else {
       gicp_align(b->stream(), b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
+      if (tuning().corr_stats) gicp_corr_stats_print(b->stream(), b->gb);
       if (b->with_fitness) gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
     }
     b->aligned = true;

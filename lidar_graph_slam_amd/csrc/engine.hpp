@@ -129,6 +129,7 @@ struct GicpBatch {
   std::vector<int> h_map;
   std::vector<float> h_guess, h_fit_T;
   int ppt = 1;              // points per thread and pass in k_gicp_correspond (Tuning::corr_ppt)
+  DevBuf<unsigned long long> corr_stats;  // Tuning::corr_stats: counters of k_gicp_correspond_tile (tuning aid), else unallocated
 };
 void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units);
 void gicp_alloc_fitness_only(GicpBatch& gb, int S, size_t cap);  // for gicp_fitness with host poses only
@@ -137,6 +138,7 @@ void gicp_fitness_values(hipStream_t s, GicpBatch& gb, double* fitness_out);
 // Enqueue the full LM optimisation of every pair.  guesses_host: S x 16 floats or nullptr.
 void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
                 const float* guesses_host);
+void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb);  // Tuning::corr_stats only
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
                   const float* T16_host_all);
 void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, mi355_result* out, double* fitness_out);

@@ -77,6 +77,10 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.h_active.ensure(1);
   gb.fit_partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * 2);
   gb.fitness.ensure((size_t)S * 2);
+  if (tn.corr_stats) {
+    gb.corr_stats.ensure(8);
+    MI_HIP(hipMemset(gb.corr_stats.p, 0, 8 * sizeof(unsigned long long)));
+  }
 }
 
 // What gicp_fitness alone needs (a batch that registers with another method still scores its pairs with it).
@@ -161,6 +165,7 @@ struct NnState {
   float explored2;
   bool complete;  // explored2 covers what the result needs
 };
+constexpr double kMarginStep = 0.03;  // a pair tracks margins once its last accepted step moved it by less than this (m / rad)
 constexpr int kLaneLevelCap = 2;  // per-lane searches stop at the 4 x base-cell level (2 m cells by default: shells r <= 1 there cover the 2 m range of
                                   // the reference configuration); capping at level 1 was measured: 16-40 % of the lanes then go to the cooperative
                                   // search in the first iterations, which serialises them — iteration 0 took 11.1 ms instead of 7.8 ms at 1 024 pairs
@@ -355,7 +360,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
                                                                 const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
-                                                                float4* __restrict__ qsearch, float max_corr_d2, int G, int S) {
+                                                                float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
+                                                                int tiles_took_the_moving_pairs) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ int queue[kLinTile];
   __shared__ int qcount;
@@ -363,12 +369,16 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
   if (!st->active) return;
+  // margins only pay once the updates are small enough to stay inside them (cm); before that every point is searched again:
+  // k_gicp_correspond_tile does that for whole tiles at once (the first iterations), this kernel with the plain 1-NN search
+  // A pair k_gicp_correspond_tile has just been through: only what it left behind (NaN margin: ties between its keys, boxes it
+  // could not scan) is searched here, with margins like everything else it produced.
+  const bool tile_pair = !(st->last_step < kMarginStep) && tiles_took_the_moving_pairs;
+  const bool track_margin = st->last_step < kMarginStep || tile_pair;
   const int t = tgt_of_src[pair];
   const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
   const int n = scount[pair];
   const Pose x0 = st->x0;
-  // margins only pay once the updates are small enough to stay inside them (cm); before that use the cheap 1-NN search
-  const bool track_margin = st->last_step < 0.03;
   float Tf[12];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
       const float moved = sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z));
       // NaN margin (never searched) -> search.  The margin also covers "still within max_corr" (search_point), so a point
       // that passes this test needs neither its correspondence index nor its correspondent: 32 B per point in steady state.
-      const bool need_search = !(moved < qs.w);
+      const bool need_search = tile_pair ? (qs.w != qs.w) : !(moved < qs.w);
       if (!finite_q) {
         corr[so + i] = -1;
       } else if (need_search) {
@@ -436,6 +446,224 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
       }
     }
     __syncthreads();  // correspondences written by other threads of this block are visible from here on
+  }
+}
+
+// ---- the same for a pair whose pose still moves by more than any margin absorbs: every point is searched, by TILES -------
+// One wave takes 64 consecutive source points (Morton order: a compact patch, and so is its rigid transform), gathers the
+// target points of the cells around the patch into LDS once and every lane scans that list for its own query — the scheme
+// of k_knn_cov_tile (tile.hpp) with a 2-element network.  A per-lane walk pays one dependent, divergent load per candidate
+// and per lane; here a candidate costs one coalesced global load per WAVE and, per lane, one LDS broadcast + 9 VALU ops:
+// the squared distance (fma form) with its low kCorrOrdBits mantissa bits replaced by the candidate's position in the list
+// is ONE 32-bit key; v_min_u32 keeps the smallest key, v_med3_u32 the runner-up, no branch, no index bookkeeping.
+//   round 1: radius r1 (most points have their correspondent within a few decimetres);
+//   round 2: the lanes that found nothing there, radius = the full reach, skipping the box round 1 has seen;
+//   a patch that straddles a jump of the Morton curve (its box then holds thousands of target points) is split into four
+//   16-lane parts that go through the rounds one after the other.
+// The candidate list is a kCorrCand-entry LDS ring that is scanned and reused whenever it fills up, so no box is too big.
+// Exactness: the keys order candidates by distance up to 2^kCorrOrdBits ulps; a lane whose two smallest keys fall into the
+// same or adjacent buckets (a tie or a near-tie: lattice clouds) repeats its search per lane, with exact distances and the
+// lowest-caller-index tie rule.  The nearest's exact distance is recomputed with dist2f, the runner-up enters the margin as
+// the lower edge of its bucket, so every margin is at most what the per-lane search would have granted.
+constexpr int kCorrOrdBits = 9;
+constexpr int kCorrCand = 1 << kCorrOrdBits;
+constexpr uint32_t kCorrOrdMask = (uint32_t)kCorrCand - 1u;
+constexpr uint32_t kCorrEmpty = 0xFFFFFFFFu;
+constexpr int kCorrSplitPoints = 2048;   // a 64-lane tile whose round-1 cells hold more points than this is split
+
+struct CorrBest {
+  uint32_t k1, k2;  // smallest and second smallest key
+  int j1;           // sorted target index behind k1
+};
+
+__device__ __forceinline__ void corr_scan(const float4* __restrict__ cand, int n, float qx, float qy, float qz, CorrBest& b) {
+  const uint32_t before = b.k1;
+  uint32_t k1 = b.k1, k2 = b.k2;
+#pragma unroll 8
+  for (int c = 0; c < n; c++) {
+    const float4 p = cand[c];  // the same address in every lane: an LDS broadcast
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const uint32_t key = (__float_as_uint(dd) & ~kCorrOrdMask) | (uint32_t)c;
+    k2 = max(min(k1, k2), min(max(k1, k2), key));  // median(k1, k2, key) -> v_med3_u32: the new runner-up
+    k1 = min(k1, key);
+  }
+  if (k1 != before) b.j1 = __float_as_int(cand[k1 & kCorrOrdMask].w);
+  b.k1 = k1;
+  b.k2 = k2;
+}
+
+// Gather the points of `cells` inside `nb` (and outside `ob`) through the LDS ring, scanning whenever it is full.
+__device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCells& cells_in, const TileBox& nb, const TileBox& ob, bool has_old,
+                                                 float4* cand, float qx, float qy, float qz, CorrBest& best) {
+  const int lane = lane_id();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned long long cells = __ballot(cells_in.ce > cells_in.cs);
+  int j = 0, e = 0;
+  auto advance = [&]() -> bool {
+    j += kWave;
+    if (j < e) return true;
+    if (!cells) return false;
+    const int cl = __builtin_ctzll(cells);
+    cells &= cells - 1;
+    j = __builtin_amdgcn_readlane(cells_in.cs, cl);
+    e = __builtin_amdgcn_readlane(cells_in.ce, cl);
+    return true;
+  };
+  int n = 0;
+  for (;;) {
+    int jb[kGatherDepth];
+    bool have[kGatherDepth];
+    float4 p[kGatherDepth];
+#pragma unroll
+    for (int u = 0; u < kGatherDepth; u++) {
+      have[u] = advance();
+      jb[u] = j;
+      p[u] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+      if (have[u] && j + lane < e) p[u] = g.pts[j + lane];
+    }
+    if (!have[0]) break;
+#pragma unroll
+    for (int u = 0; u < kGatherDepth; u++) {
+      if (!have[u]) break;
+      const bool in = in_box(nb, p[u].x, p[u].y, p[u].z) && !(has_old && in_box(ob, p[u].x, p[u].y, p[u].z));
+      const unsigned long long mask = __ballot(in);
+      const int cnt = __popcll(mask);
+      if (n + cnt > kCorrCand) {  // ring full: every lane scans what is there, then it is reused
+        corr_scan(cand, n, qx, qy, qz, best);
+        n = 0;
+      }
+      if (in) cand[n + __popcll(mask & below)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(jb[u] + lane));
+      n += cnt;
+    }
+    if (!have[kGatherDepth - 1]) break;
+  }
+  corr_scan(cand, n, qx, qy, qz, best);
+}
+
+// upper bound of the distance behind a key (upper edge of its bucket + the fma form's rounding)
+__device__ __forceinline__ float corr_key_ub(uint32_t k) { return __uint_as_float((k | kCorrOrdMask) + 2u); }
+
+// The two rounds for the lanes of `act` (wave-uniform control flow).  explored2 = the squared radius inside which the lane
+// has seen every target point; 0 = nothing could be scanned.
+__device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float qx, float qy, float qz, const TileBox& nb, const TileCells& cells,
+                                            float R1_2, float reach, float reach2, bool one_round, float4* cand, CorrBest& best, float& explored2,
+                                            unsigned long long* stats) {
+  bool seen = false;
+  if (cells.ok) {
+    // everything in the box counts (round 2 skips this box), but only what lies within R1 is known to be complete
+    CorrBest b = best;
+    corr_gather_scan(g, cells, nb, nb, false, cand, qx, qy, qz, b);
+    if (act) { best = b; explored2 = R1_2; }
+    seen = true;
+  }
+  const bool found1 = best.k1 != kCorrEmpty && corr_key_ub(best.k1) <= R1_2;
+  const bool act2 = act && !(seen && (one_round || found1));
+  const unsigned long long m2 = __ballot(act2);
+  if (stats && lane_id() == 0) {  // tuning aid (MI355_CORR_STATS)
+    atomicAdd(&stats[0], 1ull);
+    atomicAdd(&stats[1], (unsigned long long)cells.total);
+    if (m2) { atomicAdd(&stats[3], 1ull); atomicAdd(&stats[4], (unsigned long long)__popcll(m2)); }
+  }
+  if (!m2) return;
+  const TileBox box2 = tile_bounds(act2, qx, qy, qz);
+  const TileBox nb2 = grow(box2, reach + tile_eps(box2, reach));
+  const TileCells cells2 = tile_cells(g, nb2, 0x7fffffff);
+  if (stats && lane_id() == 0) atomicAdd(&stats[5], (unsigned long long)cells2.total);
+  if (!cells2.ok) return;
+  CorrBest b = best;
+  corr_gather_scan(g, cells2, nb2, nb, seen, cand, qx, qy, qz, b);
+  if (act2) { best = b; explored2 = reach2; }
+}
+
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond_tile(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
+                                                                     const float4* __restrict__ tpts, const int* __restrict__ torig,
+                                                                     const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta,
+                                                                     size_t tcap, size_t tslots, const int* __restrict__ tgt_of_src,
+                                                                     const GicpPairState* __restrict__ state, int* __restrict__ corr,
+                                                                     float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S,
+                                                                     unsigned long long* __restrict__ stats) {
+  __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand];
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
+  const GicpPairState* st = state + pair;
+  if (!st->active || st->last_step < kMarginStep) return;
+  const int t = tgt_of_src[pair];
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
+  const int n = scount[pair];
+  const Pose x0 = st->x0;
+  float Tf[12];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) Tf[4 * r + c] = (float)x0.R[3 * r + c];
+    Tf[4 * r + 3] = (float)x0.t[r];
+  }
+  const size_t so = (size_t)pair * scap;
+  const int lane = lane_id();
+  float4* cand = cand_all[wave_id()];
+  const float reach2 = search_reach2(g, max_corr_d2, true);
+  const float reach = sqrtf(reach2);
+  const bool one_round = !(r1 < reach);
+  const float R1 = one_round ? reach : r1, R1_2 = one_round ? reach2 : r1 * r1;
+  constexpr int kWavesPerBlock = kGicpBlock / kWave;
+  for (int tile = bx * kWavesPerBlock + wave_id(); tile * kWave < n; tile += G * kWavesPerBlock) {
+    const int i = tile * kWave + lane;
+    const bool valid = i < n;
+    const float4 p = spts[so + (valid ? i : tile * kWave)];
+    const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+    const bool finite_q = valid && isfinite(qx) && isfinite(qy) && isfinite(qz);
+    if (valid && !finite_q) corr[so + i] = -1;
+    // a point whose last search left a margin it has not used up keeps its correspondence (far-field points mostly: nothing
+    // within reach, and that stays so while the pose moves by decimetres)
+    const float4 qs = qsearch[so + (valid ? i : tile * kWave)];
+    const bool act = finite_q && !(sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z)) < qs.w);
+    if (!__ballot(act)) continue;
+    CorrBest best{kCorrEmpty, kCorrEmpty, -1};
+    float explored2 = 0.f;
+    {
+      const TileBox box = tile_bounds(act, qx, qy, qz);
+      const TileBox nb = grow(box, R1 + tile_eps(box, reach));
+      const TileCells cells = tile_cells(g, nb, 0x7fffffff);
+      if (cells.total <= kCorrSplitPoints) {
+        corr_rounds(g, act, qx, qy, qz, nb, cells, R1_2, reach, reach2, one_round, cand, best, explored2, stats);
+      } else {
+        // a patch across a jump of the Morton curve: its box is mostly empty space between compact parts
+        for (int part = 0; part < 4; part++) {
+          const bool pact = act && (lane >> 4) == part;
+          if (!__ballot(pact)) continue;
+          const TileBox pbox = tile_bounds(pact, qx, qy, qz);
+          const TileBox pnb = grow(pbox, R1 + tile_eps(pbox, reach));
+          const TileCells pcells = tile_cells(g, pnb, 0x7fffffff);
+          corr_rounds(g, pact, qx, qy, qz, pnb, pcells, R1_2, reach, reach2, one_round, cand, best, explored2, stats);
+        }
+      }
+    }
+    // what the keys could not decide (a tie or near-tie of the two smallest, a box that could not be scanned) is left to the
+    // per-lane search of k_gicp_correspond, which runs next: NaN margin = "not searched"
+    const bool near_tie = best.k2 != kCorrEmpty && ((best.k2 >> kCorrOrdBits) - (best.k1 >> kCorrOrdBits)) <= 1u;
+    const bool left = act && (explored2 == 0.f || near_tie);
+    if (stats) {
+      const unsigned long long mleft = __ballot(left);
+      if (lane == 0) atomicAdd(&stats[7], (unsigned long long)__popcll(mleft));
+    }
+    if (left) {
+      corr[so + i] = -1;
+      qsearch[so + i] = make_float4(qx, qy, qz, __uint_as_float(0x7fc00000u));
+    } else if (act) {
+      NnState stt{INFINITY, -1, INFINITY, explored2, true};
+      if (best.k1 != kCorrEmpty) {
+        const float4 w = g.pts[best.j1];
+        stt.d1 = dist2f(qx, qy, qz, w.x, w.y, w.z);
+        stt.j1 = best.j1;
+        if (best.k2 != kCorrEmpty) stt.d2nd = __uint_as_float(((best.k2 >> kCorrOrdBits) - 1u) << kCorrOrdBits);  // lower edge, one bucket of slack
+      }
+      int j;
+      float margin;
+      finish_search(stt, max_corr_d2, true, j, margin);
+      corr[so + i] = j;
+      qsearch[so + i] = make_float4(qx, qy, qz, margin);
+    }
   }
 }
 
@@ -811,15 +1039,21 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
   return P;
 }
 
-static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P) {
+static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P, int iteration) {
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
   const int lin_ppt = tuning().lin_ppt;
   auto kl = lin_ppt == 1 ? k_gicp_linearize<1> : (lin_ppt == 2 ? k_gicp_linearize<2> : k_gicp_linearize<4>);
   {
     TimedLaunch tl(KF_CORRESPOND, s);
+    const Tuning& tn = tuning();
+    const bool tiles = iteration < tn.corr_tiles;
+    if (tiles)
+      hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
+                         tgt.pts.p, tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p,
+                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p);
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                        tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                       gb.blocks_per_pair, gb.S);
+                       gb.blocks_per_pair, gb.S, tiles ? 1 : 0);
   }
   TimedLaunch tl(KF_LINEARIZE, s);
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
@@ -849,7 +1083,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
   const int G = gb.blocks_lin;
   const int check_every = p.force_iterations ? 0 : 4;
   for (int it = 0; it < p.max_iterations; it++) {
-    launch_linearize(s, gb, src, tgt, P);
+    launch_linearize(s, gb, src, tgt, P, it);
     {
       TimedLaunch tl(KF_SOLVE_DECIDE, s);
       hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P);
@@ -919,6 +1153,18 @@ __global__ void k_fitness_final(const double* __restrict__ fit_partials, double*
   for (int g = 0; g < G; g++) { s += fit_partials[((size_t)p * G + g) * 2]; c += fit_partials[((size_t)p * G + g) * 2 + 1]; }
   fitness[2 * p] = s;
   fitness[2 * p + 1] = c;
+}
+
+void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb) {
+  if (!gb.corr_stats.p) return;
+  unsigned long long h[8];
+  MI_HIP(hipMemcpyAsync(h, gb.corr_stats.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  MI_HIP(hipMemsetAsync(gb.corr_stats.p, 0, sizeof(h), s));
+  const double t = (double)std::max(1ull, h[0]);
+  fprintf(stderr, "[mi355] correspondence tiles (parts): %llu, %.0f points in round-1 cells each; round 2: %llu of them, %.1f lanes, "
+                  "%.0f points in cells each; %llu lanes to the per-lane search\n",
+          h[0], (double)h[1] / t, h[3], (double)h[4] / (double)std::max(1ull, h[3]), (double)h[5] / (double)std::max(1ull, h[3]), h[7]);
 }
 
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
@@ -993,7 +1239,28 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
   GicpDevParams P = dev_params(p);
   P.optimizer = MI355_OPT_LM;
-  launch_linearize(s, gb, src, tgt, P);
+  // this entry point exists for the parity tests: run BOTH correspondence searches from scratch (the per-lane walk first, then
+  // the tile kernel as iteration 0 of an alignment does) and insist that they agree, so that the caller's comparison with the
+  // oracle pins both
+  std::vector<int> lane_corr;
+  if (tuning().corr_tiles) {
+    launch_linearize(s, gb, src, tgt, P, 1 << 30);
+    lane_corr.resize(gb.cap);
+    MI_HIP(hipMemcpyAsync(lane_corr.data(), gb.corr.p, gb.cap * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, gb.cap * sizeof(int), s));
+    MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
+  }
+  launch_linearize(s, gb, src, tgt, P, 0);
+  if (!lane_corr.empty()) {
+    std::vector<int> tile_corr(gb.cap);
+    int ns = 0;
+    MI_HIP(hipMemcpyAsync(tile_corr.data(), gb.corr.p, gb.cap * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(&ns, src.count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < ns; i++)
+      if (tile_corr[(size_t)i] != lane_corr[(size_t)i]) throw ArgError(MI355_ESTATE, "tile and per-lane correspondence searches disagree");
+  }
   hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P);
   MI_LAUNCH_CHECK();
   GicpPairState st;
