@@ -469,7 +469,6 @@ constexpr int kCorrOrdBits = 9;
 constexpr int kCorrCand = 1 << kCorrOrdBits;
 constexpr uint32_t kCorrOrdMask = (uint32_t)kCorrCand - 1u;
 constexpr uint32_t kCorrEmpty = 0xFFFFFFFFu;
-constexpr int kCorrSplitPoints = 2048;   // a 64-lane tile whose round-1 cells hold more points than this is split
 
 struct CorrBest {
   uint32_t k1, k2;  // smallest and second smallest key
@@ -545,10 +544,14 @@ __device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCe
 __device__ __forceinline__ float corr_key_ub(uint32_t k) { return __uint_as_float((k | kCorrOrdMask) + 2u); }
 
 // The two rounds for the lanes of `act` (wave-uniform control flow).  explored2 = the squared radius inside which the lane
-// has seen every target point; 0 = nothing could be scanned.
-__device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float qx, float qy, float qz, const TileBox& nb, const TileCells& cells,
-                                            float R1_2, float reach, float reach2, bool one_round, float4* cand, CorrBest& best, float& explored2,
-                                            unsigned long long* stats) {
+// has seen every target point; 0 = not decided here (left to the per-lane search).
+// A round cannot run only when its box needs more than 64 cells at the top level of the hash (it never does for radii of metres).
+constexpr int kCorrSplitPoints = 2048;  // a 64-lane patch whose round-1 cells hold more points than this is split into quarters
+__device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float qx, float qy, float qz, float R1, float R1_2, float reach, float reach2,
+                                            bool one_round, float4* cand, CorrBest& best, float& explored2, unsigned long long* stats) {
+  const TileBox box = tile_bounds(act, qx, qy, qz);
+  const TileBox nb = grow(box, R1 + tile_eps(box, reach));
+  const TileCells cells = tile_cells(g, nb, 0x7fffffff);
   bool seen = false;
   if (cells.ok) {
     // everything in the box counts (round 2 skips this box), but only what lies within R1 is known to be complete
@@ -563,14 +566,21 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
   if (stats && lane_id() == 0) {  // tuning aid (MI355_CORR_STATS)
     atomicAdd(&stats[0], 1ull);
     atomicAdd(&stats[1], (unsigned long long)cells.total);
+    if (!cells.ok) atomicAdd(&stats[2], 1ull);
     if (m2) { atomicAdd(&stats[3], 1ull); atomicAdd(&stats[4], (unsigned long long)__popcll(m2)); }
   }
   if (!m2) return;
   const TileBox box2 = tile_bounds(act2, qx, qy, qz);
   const TileBox nb2 = grow(box2, reach + tile_eps(box2, reach));
   const TileCells cells2 = tile_cells(g, nb2, 0x7fffffff);
-  if (stats && lane_id() == 0) atomicAdd(&stats[5], (unsigned long long)cells2.total);
-  if (!cells2.ok) return;
+  if (stats && lane_id() == 0) {
+    atomicAdd(&stats[5], (unsigned long long)cells2.total);
+    if (!cells2.ok) atomicAdd(&stats[6], 1ull);
+  }
+  if (!cells2.ok) {
+    if (act2) explored2 = 0.f;  // what round 1 found beyond R1 proves nothing
+    return;
+  }
   CorrBest b = best;
   corr_gather_scan(g, cells2, nb2, nb, seen, cand, qx, qy, qz, b);
   if (act2) { best = b; explored2 = reach2; }
@@ -622,21 +632,15 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond_tile(const float
     CorrBest best{kCorrEmpty, kCorrEmpty, -1};
     float explored2 = 0.f;
     {
+      // a patch across a jump of the Morton curve is mostly empty space between compact parts: its quarters go through the
+      // rounds one after the other
       const TileBox box = tile_bounds(act, qx, qy, qz);
-      const TileBox nb = grow(box, R1 + tile_eps(box, reach));
-      const TileCells cells = tile_cells(g, nb, 0x7fffffff);
-      if (cells.total <= kCorrSplitPoints) {
-        corr_rounds(g, act, qx, qy, qz, nb, cells, R1_2, reach, reach2, one_round, cand, best, explored2, stats);
-      } else {
-        // a patch across a jump of the Morton curve: its box is mostly empty space between compact parts
-        for (int part = 0; part < 4; part++) {
-          const bool pact = act && (lane >> 4) == part;
-          if (!__ballot(pact)) continue;
-          const TileBox pbox = tile_bounds(pact, qx, qy, qz);
-          const TileBox pnb = grow(pbox, R1 + tile_eps(pbox, reach));
-          const TileCells pcells = tile_cells(g, pnb, 0x7fffffff);
-          corr_rounds(g, pact, qx, qy, qz, pnb, pcells, R1_2, reach, reach2, one_round, cand, best, explored2, stats);
-        }
+      const TileCells probe = tile_cells(g, grow(box, R1 + tile_eps(box, reach)), kCorrSplitPoints);
+      const int parts = probe.ok ? 1 : 4;
+      for (int part = 0; part < parts; part++) {
+        const bool pact = act && (parts == 1 || (lane >> 4) == part);
+        if (!__ballot(pact)) continue;
+        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats);
       }
     }
     // what the keys could not decide (a tie or near-tie of the two smallest, a box that could not be scanned) is left to the
@@ -1039,14 +1043,18 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
   return P;
 }
 
-static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P, int iteration) {
+// tile_search: -1 = by iteration and batch size, 0 / 1 = never / always (gicp_linearize_once)
+static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P, int iteration,
+                             int tile_search = -1) {
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
   const int lin_ppt = tuning().lin_ppt;
   auto kl = lin_ppt == 1 ? k_gicp_linearize<1> : (lin_ppt == 2 ? k_gicp_linearize<2> : k_gicp_linearize<4>);
   {
     TimedLaunch tl(KF_CORRESPOND, s);
     const Tuning& tn = tuning();
-    const bool tiles = iteration < tn.corr_tiles;
+    // a handful of pairs cannot fill the chip with tiles: their few hundred waves would each wait out their own gathers, and a
+    // lone pair is usually a scan against a dense multi-key-frame sub-map, where the per-lane walk wins anyway
+    const bool tiles = tile_search >= 0 ? tile_search != 0 : (iteration < tn.corr_tiles && gb.S >= 8);
     if (tiles)
       hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
                          tgt.pts.p, tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p,
@@ -1162,9 +1170,9 @@ void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb) {
   MI_HIP(hipStreamSynchronize(s));
   MI_HIP(hipMemsetAsync(gb.corr_stats.p, 0, sizeof(h), s));
   const double t = (double)std::max(1ull, h[0]);
-  fprintf(stderr, "[mi355] correspondence tiles (parts): %llu, %.0f points in round-1 cells each; round 2: %llu of them, %.1f lanes, "
-                  "%.0f points in cells each; %llu lanes to the per-lane search\n",
-          h[0], (double)h[1] / t, h[3], (double)h[4] / (double)std::max(1ull, h[3]), (double)h[5] / (double)std::max(1ull, h[3]), h[7]);
+  fprintf(stderr, "[mi355] correspondence tiles: %llu, %.0f points in round-1 cells each (%llu not run); round 2: %llu of them, %.1f lanes, "
+                  "%.0f points in cells each (%llu not run); %llu lanes to the per-lane search\n",
+          h[0], (double)h[1] / t, h[2], h[3], (double)h[4] / (double)std::max(1ull, h[3]), (double)h[5] / (double)std::max(1ull, h[3]), h[6], h[7]);
 }
 
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
@@ -1244,14 +1252,14 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   // oracle pins both
   std::vector<int> lane_corr;
   if (tuning().corr_tiles) {
-    launch_linearize(s, gb, src, tgt, P, 1 << 30);
+    launch_linearize(s, gb, src, tgt, P, 0, /*tile_search=*/0);
     lane_corr.resize(gb.cap);
     MI_HIP(hipMemcpyAsync(lane_corr.data(), gb.corr.p, gb.cap * sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
     MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, gb.cap * sizeof(int), s));
     MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
   }
-  launch_linearize(s, gb, src, tgt, P, 0);
+  launch_linearize(s, gb, src, tgt, P, 0, /*tile_search=*/tuning().corr_tiles ? 1 : 0);
   if (!lane_corr.empty()) {
     std::vector<int> tile_corr(gb.cap);
     int ns = 0;
