@@ -4,9 +4,9 @@
 // segments [c*cap, c*cap + count[c]) of shared arrays, with the per-cloud point count living in device memory, so
 // that a whole pipeline (filter -> sort -> index -> covariances -> LM iterations) is enqueued without one host
 // synchronisation.  A single registration object is simply a batch of one.
-//   pts   float4 (x,y,z,intensity)  16 B/pt   sorted by NN-grid cell key (x fastest)
+//   pts   float4 (x,y,z,intensity)  16 B/pt   sorted by the Morton code of the NN-grid base cell
 //   orig  int32                      4 B/pt   index of the point in the caller's order
-//   cov   2 x float4 (xx,xy,xz,yy | yz,zz,0,0) 32 B/pt (24 B algorithmic)
+//   cov   Cov6 = 6 floats (xx,xy,xz,yy,yz,zz)  24 B/pt, unpadded (one dwordx4 + one dwordx2 load)
 //   table HashSlot{key,start,end,-} 16 B/slot open-addressing voxel hash: (level, Morton cell key) -> point range
 #pragma once
 #include <stdint.h>
