@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--n-azimuth", type=int, default=1024, help="1024 = 65 536 rays per scan")
     ap.add_argument("--capacity", type=int, default=65536)
     ap.add_argument("--max-iterations", type=int, default=64)
+    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "NDT_OMP"], help="registration engine of the batch (graph_based_slam.cpp:80-119)")
     ap.add_argument("--min-good", type=float, default=0.9, help="fail unless this fraction of the pairs lands within 5 cm / 5 mrad of the truth")
     args = ap.parse_args()
 
@@ -110,21 +111,24 @@ def main():
     cap = max(args.capacity, 5 * 20000 if args.n_azimuth >= 1024 else 0)
     t0 = time.perf_counter()
     out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, cap, rank=rank, world=world, ctx=ctx,
-                                      target_prefilter=loop_batch.voxel_prefilter(0.5), max_iterations=args.max_iterations)
+                                      target_prefilter=loop_batch.voxel_prefilter(0.5), method=args.method,
+                                      **(dict(max_iterations=args.max_iterations) if args.method == "FAST_GICP"
+                                         else dict(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01)))
     t_total = time.perf_counter() - t0
     if rank == 0:
         from lidar_graph_slam_amd import synth as S_
         errs = np.array([S_.pose_error(out["T"][p], true_pose(p) @ np.linalg.inv(graph_pose(p))) for p in range(n)])
         accepted = out["converged"] & (out["fitness"] < 0.3)  # graph_based_slam.cpp:321-328
-        good = (errs[:, 0] < 0.05) & (errs[:, 1] < 5e-3)
+        # NDT with 1 m cells lands within decimetres (the oracle does the same, tests/test_gpu_fullsize.py): a wider gate for it
+        good = (errs[:, 0] < 0.05) & (errs[:, 1] < 5e-3) if args.method == "FAST_GICP" else (errs[:, 0] < 0.30) & (errs[:, 1] < 2e-2)
         line = {
             "config": "BASELINE configs[4]: loop-closure batch, candidates sharded by sub-map over the ranks, results all-gathered",
             "n_gpus": world, "backend": backend if world > 1 else "single process", "collective_ranks": dist.get_world_size() if world > 1 else 1,
-            "candidates": n, "submaps": S, "all_reported": bool(out["reported"].all()),
+            "method": args.method, "candidates": n, "submaps": S, "all_reported": bool(out["reported"].all()),
             "pairs_per_s_registration": round(n / max(out["seconds_register"], 1e-9), 1),
             "seconds_register_max_over_ranks": round(out["seconds_register"], 3), "seconds_gather": round(out["seconds_gather"], 4),
             "seconds_total_incl_synthesis": round(t_total, 1),
-            "accepted(fitness<0.3)": int(accepted.sum()), "within_5cm_of_truth": int(good.sum()),
+            "accepted(fitness<0.3)": int(accepted.sum()), "within_5cm_of_truth" if args.method == "FAST_GICP" else "within_30cm_of_truth": int(good.sum()),
             "median_pose_err_m": round(float(np.median(errs[:, 0])), 4), "max_pose_err_m_of_accepted": round(float(errs[accepted, 0].max()), 4) if accepted.any() else None,
             "mean_iterations": round(float(out["iterations"].mean()), 1),
         }

@@ -19,10 +19,11 @@ RESULT_COLUMNS = ("T[16]", "fitness", "converged", "iterations", "status", "n_so
 
 
 def register_sharded(tgt_of_src, load_source, load_target, capacity: int, *, rank: int = 0, world: int = 1, ctx=None, group=None,
-                     source_prefilter=None, target_prefilter=None, **gicp_params):
+                     source_prefilter=None, target_prefilter=None, method: str = "FAST_GICP", **params):
     """Register pair p = (source p, sub-map tgt_of_src[p]) for every p, sharded by sub-map over `world` ranks.
 
     load_source(p) / load_target(t) -> float32 [n, 4] packed clouds (n <= capacity), called only for what this rank owns.
+    method: "FAST_GICP" or "NDT_OMP" (graph_based_slam.cpp:80-119), params: that engine's (mi355_gicp_params / mi355_ndt_params).
     Returns a dict, identical on every rank: T [n,4,4] float32, fitness, converged, iterations, status, n_source, n_target
     (arrays over ALL pairs), plus this rank's timings: shard sizes, seconds of registration (max over ranks) and of the gather."""
     from .registration import BatchRegistration
@@ -51,7 +52,7 @@ def register_sharded(tgt_of_src, load_source, load_target, capacity: int, *, ran
                 raise ValueError(f"candidate {p}: {len(c)} points exceed the batch capacity {capacity}")
             sr[k, : len(c)] = c
             ns[k] = len(c)
-        b = BatchRegistration(len(mine), len(targets), capacity, ctx=ctx, **gicp_params)
+        b = BatchRegistration(len(mine), len(targets), capacity, ctx=ctx, method=method, **params)
         t0 = time.perf_counter()
         b.set_targets(tg, nt, target_prefilter)
         b.set_sources(sr, ns, source_prefilter)

@@ -144,11 +144,14 @@ def test_config4_stream_tracks_the_ground_truth(street_stream, method, reuse):
     assert o["target_points"] > 150_000  # 20 key frames in the window
 
 
-def test_config5_per_gpu_share_of_the_loop_closure_batch():
+@pytest.mark.parametrize("method,n", [("FAST_GICP", 512), ("NDT_OMP", 128)])
+def test_config5_per_gpu_share_of_the_loop_closure_batch(method, n):
+    """FAST_GICP: the 512-candidate per-GPU share of BASELINE configs[4].  NDT_OMP (graph_based_slam.cpp:101-119, 1.0 m cells as
+    graph_based_slam.param.yaml:18): the same candidates through the batched NDT, every pair's More-Thuente state on the device."""
     from lidar_graph_slam_amd import loop_batch
     from lidar_graph_slam_amd.filters import PointsPreFiltering
 
-    S, n, casts = 8, 512, 8
+    S, casts = 8, 8
     scene = synth.street(20.0 * S + 20.0)
     pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
     rng = np.random.default_rng(5)
@@ -184,16 +187,24 @@ def test_config5_per_gpu_share_of_the_loop_closure_batch():
             submaps[s] = np.concatenate(parts, axis=0)
         return submaps[s]
 
-    out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, 100_000, target_prefilter=loop_batch.voxel_prefilter(0.5), max_iterations=64)
+    kw = dict(max_iterations=64) if method == "FAST_GICP" else dict(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01)
+    out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, 100_000, target_prefilter=loop_batch.voxel_prefilter(0.5), method=method, **kw)
     assert out["reported"].all() and (out["status"] == 0).all()
     errs = np.array([synth.pose_error(out["T"][p], true_pose(p) @ np.linalg.inv(graph_pose(p))) for p in range(n)])
     accepted = out["converged"] & (out["fitness"] < 0.3)  # graph_based_slam.cpp:321-328
-    assert accepted.sum() >= 0.98 * n and (errs[accepted, 0] < 0.05).mean() > 0.98, (accepted.sum(), np.median(errs[:, 0]))
+    if method == "FAST_GICP":
+        assert accepted.sum() >= 0.98 * n and (errs[accepted, 0] < 0.05).mean() > 0.98, (accepted.sum(), np.median(errs[:, 0]))
+    else:  # NDT with 1 m cells from up to 1.5 m / 4 deg off: coarser, and some candidates stay in a neighbouring basin — like the oracle
+        assert accepted.sum() >= 0.9 * n and np.median(errs[accepted, 0]) < 0.10, (accepted.sum(), np.median(errs[:, 0]))
     # a sample against the oracle: same voxel-filtered sub-map, same candidate, identity guess (graph_based_slam.cpp:311-322)
-    for p in (0, 77, 203, 511):
+    for p in (0, 77, 203, 511) if n > 511 else (0, 37, 77, 127):
         t = O.voxel_grid(load_target(int(tgt_of_src[p])), 0.5)[0]
         assert out["n_target"][p] == len(t)
-        ref = O.gicp_align(load_source(p), t, O.gicp_params(max_iterations=64))
+        if method == "FAST_GICP":
+            ref = O.gicp_align(load_source(p), t, O.gicp_params(max_iterations=64))
+        else:
+            ref = O.ndt_align(load_source(p), t, O.ndt_params(**kw))
+            assert abs(int(out["iterations"][p]) - ref["iterations"]) <= 2, (p, out["iterations"][p], ref["iterations"])
         dt, dr = synth.pose_error(out["T"][p], ref["T"])
-        assert dt <= 0.012 and dr <= 2.5e-3, (p, dt, dr)  # both stop inside the convergence band
+        assert dt <= 0.012 and dr <= 2.5e-3, (method, p, dt, dr)  # both stop inside the convergence band
         np.testing.assert_allclose(out["fitness"][p], O.fitness(load_source(p), t, out["T"][p]), rtol=1e-6)
