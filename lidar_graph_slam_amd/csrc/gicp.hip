@@ -165,7 +165,6 @@ struct NnState {
   float explored2;
   bool complete;  // explored2 covers what the result needs
 };
-constexpr double kMarginStep = 0.03;  // a pair tracks margins once its last accepted step moved it by less than this (m / rad)
 constexpr int kLaneLevelCap = 2;  // per-lane searches stop at the 4 x base-cell level (2 m cells by default: shells r <= 1 there cover the 2 m range of
                                   // the reference configuration); capping at level 1 was measured: 16-40 % of the lanes then go to the cooperative
                                   // search in the first iterations, which serialises them — iteration 0 took 11.1 ms instead of 7.8 ms at 1 024 pairs
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                 float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
-                                                                int tiles_took_the_moving_pairs) {
+                                                                int tiles_took_the_moving_pairs, double margin_step) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ int queue[kLinTile];
   __shared__ int qcount;
@@ -373,8 +372,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __
   // k_gicp_correspond_tile does that for whole tiles at once (the first iterations), this kernel with the plain 1-NN search
   // A pair k_gicp_correspond_tile has just been through: only what it left behind (NaN margin: ties between its keys, boxes it
   // could not scan) is searched here, with margins like everything else it produced.
-  const bool tile_pair = !(st->last_step < kMarginStep) && tiles_took_the_moving_pairs;
-  const bool track_margin = st->last_step < kMarginStep || tile_pair;
+  const bool tile_pair = !(st->last_step < margin_step) && tiles_took_the_moving_pairs;
+  const bool track_margin = st->last_step < margin_step || tile_pair;
   const int t = tgt_of_src[pair];
   const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
   const int n = scount[pair];
@@ -592,12 +591,12 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond_tile(const float
                                                                      size_t tcap, size_t tslots, const int* __restrict__ tgt_of_src,
                                                                      const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                      float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S,
-                                                                     unsigned long long* __restrict__ stats) {
+                                                                     unsigned long long* __restrict__ stats, double margin_step) {
   __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand];
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
-  if (!st->active || st->last_step < kMarginStep) return;
+  if (!st->active || st->last_step < margin_step) return;
   const int t = tgt_of_src[pair];
   const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
   const int n = scount[pair];
@@ -1058,10 +1057,10 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     if (tiles)
       hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
                          tgt.pts.p, tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p,
-                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p);
+                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p, (double)tn.margin_step);
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                        tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                       gb.blocks_per_pair, gb.S, tiles ? 1 : 0);
+                       gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step);
   }
   TimedLaunch tl(KF_LINEARIZE, s);
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
