@@ -41,7 +41,9 @@ typedef struct mi355_cloud_view {
 
 /* registration_method of lidar_scan_matcher.param.yaml:4 / lidar_scan_matcher.cpp:37,55 */
 enum { MI355_METHOD_FAST_GICP = 0, MI355_METHOD_NDT_OMP = 1,
-       MI355_METHOD_ICP = 2 /* pcl::IterativeClosestPoint: the back end's default (graph_based_slam.param.yaml:9, cpp:142-151) */ };
+       MI355_METHOD_ICP = 2, /* pcl::IterativeClosestPoint: the back end's default (graph_based_slam.param.yaml:9, cpp:142-151) */
+       MI355_METHOD_GICP = 3 /* pclomp::GeneralizedIterativeClosestPoint, PCL 1.8's BFGS GICP (lidar_scan_matcher.cpp:73-96,
+                                graph_based_slam.cpp:120-141) */ };
 /* fast_gicp::RegularizationMethod (default PLANE) */
 enum { MI355_REG_NONE = 0, MI355_REG_MIN_EIG = 1, MI355_REG_NORMALIZED_MIN_EIG = 2, MI355_REG_PLANE = 3, MI355_REG_FROBENIUS = 4 };
 /* fast_gicp::LSQ_OPTIMIZER_TYPE (default LevenbergMarquardt) */
@@ -89,6 +91,19 @@ typedef struct mi355_icp_params {
   int ransac_iterations;              /* setRANSACIterations(0): only 0 (no outlier rejector) is built */
 } mi355_icp_params;
 
+/* pclomp::GeneralizedIterativeClosestPoint as the nodes configure it (lidar_scan_matcher.cpp:84-93,
+ * graph_based_slam.cpp:131-138); what they do not set keeps PCL's default. */
+typedef struct mi355_gicp_bfgs_params {
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance(correspondence_distance): kept iff d2 < max^2 */
+  int max_iterations;                 /* setMaximumIterations: outer (re-correspondence) iterations */
+  int max_optimizer_iterations;       /* setMaximumOptimizerIterations(max_optimizer_iteration -> 20): BFGS steps per outer iteration */
+  double transformation_epsilon;      /* setTransformationEpsilon: converged when every translation entry moved less than this ... */
+  double rotation_epsilon;            /* ... and every rotation entry less than this (PCL default 2e-3) */
+  double euclidean_fitness_epsilon;   /* setEuclideanFitnessEpsilon: stored, not used by GICP's own convergence test (as upstream) */
+  int k_correspondences;              /* PCL default 20: neighbours of a covariance (singular values replaced by 1, 1, 1e-3) */
+  int ransac_iterations;              /* setRANSACIterations(0): only 0 is built */
+} mi355_gicp_bfgs_params;
+
 /* points_prefiltering parameters — points_prefiltering.launch.xml:2-13. */
 typedef struct mi355_prefilter_params {
   double min_distance;   /* min_distance_cloud 1.0; <= 0 disables the distance filter (points_prefiltering.cpp:102-112) */
@@ -119,6 +134,7 @@ void mi355_gicp_default_params(mi355_gicp_params* p);
 void mi355_ndt_default_params(mi355_ndt_params* p);
 void mi355_prefilter_default_params(mi355_prefilter_params* p);
 void mi355_icp_default_params(mi355_icp_params* p);
+void mi355_gicp_bfgs_default_params(mi355_gicp_bfgs_params* p);
 
 /* ---- context ------------------------------------------------------------------------------------------- */
 mi355_ctx* mi355_create(int device_id);

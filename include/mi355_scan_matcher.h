@@ -14,7 +14,7 @@ extern "C" {
 typedef struct mi355_scan_matcher mi355_scan_matcher;
 
 typedef struct mi355_scan_matcher_params {
-  int registration_method;            /* MI355_METHOD_FAST_GICP | MI355_METHOD_NDT_OMP (yaml:4; lidar_scan_matcher.cpp:34-72) */
+  int registration_method;            /* MI355_METHOD_FAST_GICP | MI355_METHOD_NDT_OMP | MI355_METHOD_GICP (yaml:4; lidar_scan_matcher.cpp:34-96) */
   double displacement;                /* yaml:5 -> 1.0: key-frame distance gate (cpp:183) */
   int max_scan_accumulate_num;        /* yaml:6 -> 20: key frames in the sliding sub-map (cpp:199) */
   int max_iteration;                  /* yaml:9 -> 64 */
@@ -28,6 +28,8 @@ typedef struct mi355_scan_matcher_params {
                                          (C' = R C R^T); 0: recomputed over the merged sub-map at every key frame,
                                          as fast_gicp does (lidar_scan_matcher.cpp:212 -> setInputTarget).  The sub-map itself is
                                          assembled on the device either way. */
+  double correspondence_distance;     /* yaml:22 -> 5.0 ("GICP": setMaxCorrespondenceDistance, cpp:88) */
+  int max_optimizer_iteration;        /* yaml:25 -> 20  ("GICP": setMaximumOptimizerIterations, cpp:91) */
 } mi355_scan_matcher_params;
 
 typedef struct mi355_scan_output {

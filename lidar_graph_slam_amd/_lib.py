@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355_lidar.so")
 _LIB = None
 
-METHOD_FAST_GICP, METHOD_NDT_OMP, METHOD_ICP = 0, 1, 2
+METHOD_FAST_GICP, METHOD_NDT_OMP, METHOD_ICP, METHOD_GICP = 0, 1, 2, 3
 REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)
 OPT_LM, OPT_GN = 0, 1
 OK, EINVAL, EHIP, ECAPACITY, ESTATE = 0, -1, -2, -3, -4
@@ -59,6 +59,12 @@ class NdtParams(C.Structure):
         ("legacy_mt_skip", C.c_int),
         ("num_threads", C.c_int),
     ]
+
+
+class GicpBfgsParams(C.Structure):
+    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iterations", C.c_int), ("max_optimizer_iterations", C.c_int),
+                ("transformation_epsilon", C.c_double), ("rotation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
+                ("k_correspondences", C.c_int), ("ransac_iterations", C.c_int)]
 
 
 class IcpParams(C.Structure):
@@ -114,7 +120,7 @@ class Result(C.Structure):
 
 # every symbol include/mi355_lidar.h declares (tests/test_abi.py checks the library exports each one)
 EXPORTS = [
-    "mi355_gicp_default_params", "mi355_ndt_default_params", "mi355_prefilter_default_params", "mi355_icp_default_params",
+    "mi355_gicp_default_params", "mi355_ndt_default_params", "mi355_prefilter_default_params", "mi355_icp_default_params", "mi355_gicp_bfgs_default_params",
     "mi355_create", "mi355_destroy", "mi355_last_error", "mi355_set_stream", "mi355_synchronize", "mi355_set_grid_cell", "mi355_device_info",
     "mi355_distance_filter", "mi355_voxel_grid", "mi355_sor", "mi355_prefilter", "mi355_transform",
     "mi355_knn", "mi355_covariances",
@@ -153,6 +159,8 @@ class LoopClosureParams(C.Structure):
         ("registration_method", C.c_int),
         ("step_size", C.c_double),
         ("ndt_resolution", C.c_double),
+        ("correspondence_distance", C.c_double),
+        ("max_optimizer_iteration", C.c_int),
     ]
 
 
@@ -183,6 +191,8 @@ class ScanMatcherParams(C.Structure):
         ("max_correspondence_distance", C.c_double),
         ("correspondence_randomness", C.c_int),
         ("reuse_key_frame_covariances", C.c_int),
+        ("correspondence_distance", C.c_double),
+        ("max_optimizer_iteration", C.c_int),
     ]
 
 
@@ -312,6 +322,16 @@ def gicp_params(**kw) -> GicpParams:
 def ndt_params(**kw) -> NdtParams:
     p = NdtParams()
     lib().mi355_ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def gicp_bfgs_params(**kw) -> GicpBfgsParams:
+    p = GicpBfgsParams()
+    lib().mi355_gicp_bfgs_default_params(C.byref(p))
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)

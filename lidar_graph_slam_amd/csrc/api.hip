@@ -104,6 +104,8 @@ struct mi355_reg {
   mi355_ndt_params np;
   mi355_icp_params ip;
   IcpScratch icp;
+  mi355_gicp_bfgs_params bp;  // MI355_METHOD_GICP
+  BfgsScratch bfgs;
   Workspace ws;
   Uploader up;
   DevBuf<float4> stage_src, stage_tgt;
@@ -204,6 +206,18 @@ extern "C" void mi355_ndt_default_params(mi355_ndt_params* p) {
   p->legacy_mt_skip = 1;
   p->num_threads = 0;
 }
+extern "C" void mi355_gicp_bfgs_default_params(mi355_gicp_bfgs_params* p) {  // lidar_scan_matcher.param.yaml / graph_based_slam.param.yaml "GICP" block
+  if (!p) return;
+  p->max_correspondence_distance = 2.0;
+  p->max_iterations = 64;
+  p->max_optimizer_iterations = 20;
+  p->transformation_epsilon = 0.01;
+  p->rotation_epsilon = 2e-3;
+  p->euclidean_fitness_epsilon = 1e-8;
+  p->k_correspondences = 20;
+  p->ransac_iterations = 0;
+}
+
 extern "C" void mi355_icp_default_params(mi355_icp_params* p) {  // graph_based_slam.cpp:146-150
   p->max_correspondence_distance = 30.0;
   p->max_iterations = 100;
@@ -484,19 +498,37 @@ extern "C" int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, in
   });
 }
 
+// FAST_GICP and the BFGS GICP prepare their clouds the same way (voxel hash + PLANE-regularised k-NN covariances)
+static bool needs_covariances(int method) { return method == MI355_METHOD_FAST_GICP || method == MI355_METHOD_GICP; }
+static void adopt_bfgs_params(mi355_reg* r) {  // the covariance path reads gp
+  r->gp.k_correspondences = r->bp.k_correspondences;
+  r->gp.regularization_method = MI355_REG_PLANE;
+}
+
 // ---- registration object -------------------------------------------------------------------------------------------
 extern "C" mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* params) {
-  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP)) return nullptr;
+  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP && method != MI355_METHOD_GICP))
+    return nullptr;
   auto* r = new mi355_reg();
   r->ctx = ctx;
   r->method = method;
   mi355_gicp_default_params(&r->gp);
   mi355_ndt_default_params(&r->np);
   mi355_icp_default_params(&r->ip);
+  mi355_gicp_bfgs_default_params(&r->bp);
   if (params) {
     if (method == MI355_METHOD_FAST_GICP) r->gp = *(const mi355_gicp_params*)params;
     else if (method == MI355_METHOD_NDT_OMP) r->np = *(const mi355_ndt_params*)params;
+    else if (method == MI355_METHOD_GICP) r->bp = *(const mi355_gicp_bfgs_params*)params;
     else r->ip = *(const mi355_icp_params*)params;
+  }
+  if (method == MI355_METHOD_GICP) {
+    if (r->bp.ransac_iterations != 0 || r->bp.k_correspondences < 1) {
+      ctx->err = "GICP: only setRANSACIterations(0) is built; k_correspondences must be positive";
+      delete r;
+      return nullptr;
+    }
+    adopt_bfgs_params(r);
   }
   if (method == MI355_METHOD_ICP && r->ip.ransac_iterations != 0) {
     ctx->err = "ICP: only setRANSACIterations(0) (graph_based_slam.cpp:150) is built";
@@ -527,6 +559,16 @@ extern "C" int mi355_reg_set_params(mi355_reg* reg, const void* params) {
       reg->ctx->err = "ICP: only setRANSACIterations(0) (graph_based_slam.cpp:150) is built";
       return MI355_EINVAL;
     }
+  } else if (reg->method == MI355_METHOD_GICP) {
+    const int old_k = reg->bp.k_correspondences;
+    const mi355_gicp_bfgs_params nb = *(const mi355_gicp_bfgs_params*)params;
+    if (nb.ransac_iterations != 0 || nb.k_correspondences < 1) {
+      reg->ctx->err = "GICP: only setRANSACIterations(0) is built; k_correspondences must be positive";
+      return MI355_EINVAL;
+    }
+    reg->bp = nb;
+    adopt_bfgs_params(reg);
+    if (old_k != nb.k_correspondences) { reg->src.has_cov = false; reg->tgt.has_cov = false; }
   } else {
     // pclomp re-initialises its voxel grid only when the grid itself changes (setResolution and friends), and does so from
     // the target it already holds: the other setters (iterations, epsilon, step size, threads) leave the target alone
@@ -565,7 +607,7 @@ extern "C" int mi355_reg_set_target(mi355_reg* reg, const mi355_cloud_view* clou
     reg->has_tgt = false;
     reg->aligned = false;
     if (reg->n_tgt == 0) throw ArgError(MI355_EINVAL, "empty target cloud");
-    if (reg->method == MI355_METHOD_FAST_GICP) {
+    if (needs_covariances(reg->method)) {
       if ((size_t)reg->gp.k_correspondences > reg->n_tgt) throw ArgError(MI355_EINVAL, "target has fewer points than k_correspondences");
       reg->tgt.alloc(1, reg->n_tgt);
       build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
@@ -594,7 +636,7 @@ extern "C" int mi355_reg_set_source(mi355_reg* reg, const mi355_cloud_view* clou
     if (reg->n_src == 0) throw ArgError(MI355_EINVAL, "empty source cloud");
     reg->src.alloc(1, reg->n_src);
     build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
-    if (reg->method == MI355_METHOD_FAST_GICP) {
+    if (needs_covariances(reg->method)) {
       if ((size_t)reg->gp.k_correspondences > reg->n_src) throw ArgError(MI355_EINVAL, "source has fewer points than k_correspondences");
       compute_covariances(ctx->stream, reg->src, reg->gp.k_correspondences, reg->gp.regularization_method);
     }
@@ -607,7 +649,7 @@ static void reg_require(mi355_reg* reg) {
   if (!reg->has_tgt) throw ArgError(MI355_ESTATE, "setInputTarget has not been called");
   if (!reg->has_src) throw ArgError(MI355_ESTATE, "setInputSource has not been called");
   MI_HIP(hipSetDevice(reg->ctx->device));
-  if (reg->method == MI355_METHOD_FAST_GICP) {
+  if (needs_covariances(reg->method)) {
     if (!reg->src.has_cov) compute_covariances(reg->ctx->stream, reg->src, reg->gp.k_correspondences, reg->gp.regularization_method);
     if (!reg->tgt.has_cov) compute_covariances(reg->ctx->stream, reg->tgt, reg->gp.k_correspondences, reg->gp.regularization_method);
   }
@@ -621,6 +663,11 @@ extern "C" int mi355_reg_align(mi355_reg* reg, const float guess16[16], mi355_re
     if (reg->method == MI355_METHOD_FAST_GICP) {
       gicp_align(ctx->stream, reg->gb, reg->src, reg->tgt, reg->gp, nullptr, guess16);
       gicp_results(ctx->stream, reg->gb, reg->src, reg->tgt, result, nullptr);
+    } else if (reg->method == MI355_METHOD_GICP) {
+      float I[16];
+      for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
+      gicp_bfgs_align(ctx->stream, reg->bfgs, reg->src, reg->tgt, reg->n_src, reg->bp, guess16 ? guess16 : I, result);
+      result->n_target = (int)reg->n_tgt;
     } else if (reg->method == MI355_METHOD_ICP) {
       float I[16];
       for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
@@ -945,7 +992,7 @@ extern "C" int mi355_reg_set_source_cloud(mi355_reg* reg, mi355_cloud* cloud) {
     if (reg->n_src == 0) throw ArgError(MI355_EINVAL, "empty source cloud");
     reg->src.alloc(1, reg->n_src);
     build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
-    if (reg->method == MI355_METHOD_FAST_GICP) {
+    if (needs_covariances(reg->method)) {
       if ((size_t)reg->gp.k_correspondences > reg->n_src) throw ArgError(MI355_EINVAL, "source has fewer points than k_correspondences");
       const bool cached = cloud->has_cov && cloud->cov_k == reg->gp.k_correspondences && cloud->cov_method == reg->gp.regularization_method;
       if (cached) {
@@ -973,7 +1020,7 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
     reg->has_tgt = false;
     reg->aligned = false;
     if (reg->n_tgt == 0) throw ArgError(MI355_EINVAL, "empty target cloud");
-    if (reg->method == MI355_METHOD_FAST_GICP) {
+    if (needs_covariances(reg->method)) {
       if ((size_t)reg->gp.k_correspondences > reg->n_tgt) throw ArgError(MI355_EINVAL, "target has fewer points than k_correspondences");
       reg->tgt.alloc(1, reg->n_tgt);
       build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);

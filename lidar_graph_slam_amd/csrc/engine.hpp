@@ -156,6 +156,17 @@ struct IcpScratch {
 void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4* d_src, size_t n, const mi355_icp_params& p, const float* guess16,
                mi355_result* out);
 
+// ---- gicp_bfgs.hip ---------------------------------------------------------------------------------------------
+struct BfgsScratch {
+  DevBuf<int> corr;          // [n] correspondent (sorted target index) of every sorted source point, -1: none in range
+  DevBuf<double> mahal;      // [n][6] fp64 Mahalanobis matrices of the current outer iteration
+  DevBuf<double> partials, sums;
+  PinnedBuf<double> h_sums;
+};
+// pclomp::GeneralizedIterativeClosestPoint::align: built source and target sets with PLANE covariances
+void gicp_bfgs_align(hipStream_t s, BfgsScratch& sc, const CloudSet& src, const CloudSet& tgt, size_t n_src, const mi355_gicp_bfgs_params& p,
+                     const float* guess16, mi355_result* out);
+
 // ---- ndt.hip -------------------------------------------------------------------------------------------------
 struct NdtTarget;
 struct NdtState;

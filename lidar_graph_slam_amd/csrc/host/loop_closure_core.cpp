@@ -38,7 +38,7 @@ int LoopClosureCore::candidate(int query) const {
 }
 
 LoopClosureCore::~LoopClosureCore() {
-  icp_.reset();
+  pairwise_.reset();
   if (batch_) mi355_batch_destroy(batch_);
   key_frames_.clear();  // device clouds go before the context
 }
@@ -106,26 +106,36 @@ std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) 
   std::vector<mi355_result> res((size_t)std::max(S, batch_S_));
   std::vector<double> fit((size_t)std::max(S, batch_S_));
   const mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
-  if (params_.registration_method == MI355_METHOD_ICP) {
-    // pcl::IterativeClosestPoint, one candidate at a time as the reference does (:315-321), everything device-resident
-    if (!icp_) {
-      icp_.reset(new IterativeClosestPoint(*ctx_));
-      icp_->setMaxCorrespondenceDistance(30);  // :145-149
-      icp_->setMaximumIterations(100);
-      icp_->setTransformationEpsilon(1e-8);
-      icp_->setEuclideanFitnessEpsilon(1e-6);
-      icp_->setRANSACIterations(0);
+  if (params_.registration_method == MI355_METHOD_ICP || params_.registration_method == MI355_METHOD_GICP) {
+    // one candidate at a time as the reference does (:315-321), everything device-resident
+    if (!pairwise_ && params_.registration_method == MI355_METHOD_ICP) {
+      auto icp = std::make_shared<IterativeClosestPoint>(*ctx_);
+      icp->setMaxCorrespondenceDistance(30);  // :145-149
+      icp->setMaximumIterations(100);
+      icp->setTransformationEpsilon(1e-8);
+      icp->setEuclideanFitnessEpsilon(1e-6);
+      icp->setRANSACIterations(0);
+      pairwise_ = icp;
+    } else if (!pairwise_) {
+      auto gicp = std::make_shared<GeneralizedIterativeClosestPoint>(*ctx_);
+      gicp->setMaxCorrespondenceDistance(params_.correspondence_distance);  // :133-138
+      gicp->setMaximumIterations(params_.max_iteration);
+      gicp->setMaximumOptimizerIterations(params_.max_optimizer_iteration);
+      gicp->setTransformationEpsilon(params_.transformation_epsilon);
+      gicp->setEuclideanFitnessEpsilon(params_.euclidean_fitness_epsilon);
+      gicp->setRANSACIterations(0);
+      pairwise_ = gicp;
     }
     std::vector<DeviceCloud::Ptr> filtered((size_t)U);
     for (int u = 0; u < U; u++) filtered[(size_t)u] = submap[(size_t)u]->prefiltered(pf);
     for (int s = 0; s < S; s++) {
       const size_t u = (size_t)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
-      icp_->setInputTarget(filtered[u]);
-      icp_->setInputSource(source[(size_t)s]);
-      icp_->align(identity4());
-      res[(size_t)s] = icp_->result();
+      pairwise_->setInputTarget(filtered[u]);
+      pairwise_->setInputSource(source[(size_t)s]);
+      pairwise_->align(identity4());
+      res[(size_t)s] = pairwise_->result();
       res[(size_t)s].n_target = (int)filtered[u]->size();
-      fit[(size_t)s] = icp_->getFitnessScore();
+      fit[(size_t)s] = pairwise_->getFitnessScore();
     }
   } else {
     mi355_gicp_params gp;
@@ -244,12 +254,15 @@ extern "C" void mi355_loop_closure_default_params(mi355_loop_closure_params* p) 
   p->registration_method = d.registration_method;
   p->step_size = d.step_size;
   p->ndt_resolution = d.ndt_resolution;
+  p->correspondence_distance = d.correspondence_distance;
+  p->max_optimizer_iteration = d.max_optimizer_iteration;
 }
 
 extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi355_loop_closure_params* p) {
   if (!p || p->search_key_frame_num < 0 || !(p->submap_leaf >= 0.f)) return nullptr;
-  if (p->registration_method != MI355_METHOD_FAST_GICP && p->registration_method != MI355_METHOD_NDT_OMP && p->registration_method != MI355_METHOD_ICP)
-    return nullptr;  // "GICP" (pclomp BFGS) is not built; unknown strings leave the reference with a null registration too (:153)
+  if (p->registration_method != MI355_METHOD_FAST_GICP && p->registration_method != MI355_METHOD_NDT_OMP && p->registration_method != MI355_METHOD_ICP &&
+      p->registration_method != MI355_METHOD_GICP)
+    return nullptr;  // unknown strings leave the reference with a null registration too (:153)
   mi355::LoopClosureParams lp;
   lp.search_key_frame_num = p->search_key_frame_num;
   lp.score_threshold = p->score_threshold;
@@ -263,6 +276,8 @@ extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi
   lp.registration_method = p->registration_method;
   lp.step_size = p->step_size;
   lp.ndt_resolution = p->ndt_resolution;
+  lp.correspondence_distance = p->correspondence_distance;
+  lp.max_optimizer_iteration = p->max_optimizer_iteration;
   auto* h = new mi355_loop_closure();
   h->core.reset(new mi355::LoopClosureCore(device_id, lp));
   return h;

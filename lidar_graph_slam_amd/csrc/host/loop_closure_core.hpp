@@ -23,11 +23,14 @@ struct LoopClosureParams {  // graph_based_slam.param.yaml:3-23; sub-map leaf ha
   int correspondence_randomness = 20;
   // get_registration (:74-155): "FAST_GICP" and "NDT_OMP" register all candidates in one batch; "ICP" — the yaml's default
   // (graph_based_slam.param.yaml:9), pcl::IterativeClosestPoint with the values hard-coded at :145-149 — runs pair by pair
-  // on the device-resident clouds (its Horn fit is a 4x4 eigenproblem on the host per iteration).  "GICP" (pclomp's BFGS
-  // variant) is not built.
+  // on the device-resident clouds (its Horn fit is a 4x4 eigenproblem on the host per iteration), and so does "GICP"
+  // (pclomp's BFGS GICP, :120-141: the quasi-Newton steps are host logic).
   int registration_method = MI355_METHOD_ICP;
   double step_size = 0.1;        // yaml:17 (NDT_OMP)
   double ndt_resolution = 1.0;   // yaml:18
+  double correspondence_distance = 2.0;    // yaml:26 (GICP)
+  int max_optimizer_iteration = 20;        // yaml:23
+  double euclidean_fitness_epsilon = 1e-8; // yaml:27
 };
 
 struct LoopResult {
@@ -61,7 +64,7 @@ class LoopClosureCore {
   // the batch object outlives close(): its buffers (tens of GB at 512 candidates) are allocated once and grown only when a
   // call needs more sources, sub-maps or capacity
   mi355_batch* batch_ = nullptr;
-  std::shared_ptr<IterativeClosestPoint> icp_;  // registration_method == ICP
+  std::shared_ptr<Registration> pairwise_;  // registration_method == ICP or GICP: one candidate at a time
   int batch_S_ = 0, batch_U_ = 0;
   size_t batch_cap_ = 0;
 };

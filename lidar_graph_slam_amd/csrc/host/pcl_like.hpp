@@ -279,6 +279,26 @@ class NormalDistributionsTransform : public Registration {  // pclomp::NormalDis
   mi355_ndt_params p_;
 };
 
+class GeneralizedIterativeClosestPoint : public Registration {  // pclomp::GeneralizedIterativeClosestPoint<PointXYZI, PointXYZI>
+ public:
+  explicit GeneralizedIterativeClosestPoint(Context& ctx) : Registration(ctx, MI355_METHOD_GICP, nullptr) { mi355_gicp_bfgs_default_params(&p_); }
+  void setMaxCorrespondenceDistance(double d) { p_.max_correspondence_distance = d; dirty_ = true; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; dirty_ = true; }
+  void setMaximumOptimizerIterations(int n) { p_.max_optimizer_iterations = n; dirty_ = true; }
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; dirty_ = true; }
+  void setRotationEpsilon(double e) { p_.rotation_epsilon = e; dirty_ = true; }
+  void setEuclideanFitnessEpsilon(double e) { p_.euclidean_fitness_epsilon = e; dirty_ = true; }
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; dirty_ = true; }
+  void setRANSACIterations(int n) { p_.ransac_iterations = n; dirty_ = true; }  // only 0 is built
+  void setUseReciprocalCorrespondences(bool on) {  // a pcl::Registration flag GICP's computeTransformation never reads
+    if (on) throw Error(MI355_EINVAL, "reciprocal correspondences are not built (the nodes set false)");
+  }
+
+ protected:
+  const void* params_ptr() const override { return &p_; }
+  mi355_gicp_bfgs_params p_;
+};
+
 class IterativeClosestPoint : public Registration {  // pcl::IterativeClosestPoint<PointXYZI, PointXYZI>
  public:
   explicit IterativeClosestPoint(Context& ctx) : Registration(ctx, MI355_METHOD_ICP, nullptr) { mi355_icp_default_params(&p_); }

@@ -24,9 +24,20 @@ ScanMatcherCore::ScanMatcherCore(Context& ctx, const ScanMatcherParams& p) : ctx
     ndt->setNeighborhoodSearchMethod(DIRECT7);
     if (0 < p.omp_num_thread) ndt->setNumThreads(p.omp_num_thread);
     registration_ = ndt;
+  } else if (p.registration_method == "GICP") {  // :73-96
+    auto gicp = std::make_shared<GeneralizedIterativeClosestPoint>(ctx);
+    gicp->setMaxCorrespondenceDistance(p.correspondence_distance);
+    gicp->setMaximumIterations(p.max_iteration);
+    gicp->setUseReciprocalCorrespondences(p.use_reciprocal_correspondences);
+    gicp->setMaximumOptimizerIterations(p.max_optimizer_iteration);
+    gicp->setTransformationEpsilon(p.transformation_epsilon);
+    gicp->setEuclideanFitnessEpsilon(p.euclidean_fitness_epsilon);
+    gicp->setCorrespondenceRandomness(p.correspondence_randomness);
+    registration_ = gicp;
+    gicp_ = true;  // same PLANE k-NN covariances as FAST_GICP: a key frame's can be carried into the sub-map
   } else {
     // the reference leaves registration_ null and crashes at the first callback (:97); fail at construction instead
-    throw Error(MI355_EINVAL, "registration_method must be FAST_GICP or NDT_OMP (GICP: pclomp's BFGS GICP is not on the hot path)");
+    throw Error(MI355_EINVAL, "registration_method must be FAST_GICP, NDT_OMP or GICP");
   }
 }
 
@@ -126,7 +137,10 @@ extern "C" mi355_scan_matcher* mi355_scan_matcher_create(int device_id, const mi
   try {
     h->ctx.reset(new mi355::Context(device_id));
     mi355::ScanMatcherParams sp;
-    sp.registration_method = p->registration_method == MI355_METHOD_FAST_GICP ? "FAST_GICP" : (p->registration_method == MI355_METHOD_NDT_OMP ? "NDT_OMP" : "?");
+    sp.registration_method = p->registration_method == MI355_METHOD_FAST_GICP ? "FAST_GICP"
+                             : (p->registration_method == MI355_METHOD_NDT_OMP ? "NDT_OMP" : (p->registration_method == MI355_METHOD_GICP ? "GICP" : "?"));
+    sp.correspondence_distance = p->correspondence_distance;
+    sp.max_optimizer_iteration = p->max_optimizer_iteration;
     sp.displacement = p->displacement;
     sp.max_scan_accumulate_num = p->max_scan_accumulate_num;
     sp.max_iteration = p->max_iteration;

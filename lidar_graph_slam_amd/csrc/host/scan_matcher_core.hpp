@@ -90,6 +90,11 @@ struct ScanMatcherParams {  // lidar_scan_matcher.param.yaml:3-19
   double ndt_resolution = 2.0;
   double max_correspondence_distance = 2.0;
   int correspondence_randomness = 20;
+  // "GICP" block of the yaml (:21-26): pclomp's BFGS GICP
+  double correspondence_distance = 5.0;
+  double euclidean_fitness_epsilon = 1e-8;
+  int max_optimizer_iteration = 20;
+  bool use_reciprocal_correspondences = false;
   // a key frame's k-NN covariances are computed once (when the scan is registered) and ROTATED into every
   // sub-map it is part of (C' = R C R^T) instead of being recomputed over the ~3 x 10^5-point union at every key frame.
   // false = the reference's arithmetic: fast_gicp recomputes them over the merged sub-map (its neighbourhoods then also

@@ -266,6 +266,34 @@ class IterativeClosestPoint(_Registration):
         self._set(ransac_iterations=int(n))
 
 
+class GeneralizedIterativeClosestPoint(_Registration):
+    """pclomp::GeneralizedIterativeClosestPoint<PointXYZI,PointXYZI> — registration_method "GICP" of both nodes
+    (lidar_scan_matcher.cpp:73-96, graph_based_slam.cpp:120-141): PCL 1.8's GICP, a BFGS minimisation per re-correspondence."""
+
+    _method = L.METHOD_GICP
+
+    def __init__(self, ctx: Context | None = None, **params):
+        super().__init__(L.gicp_bfgs_params(**params), ctx)
+
+    def setMaxCorrespondenceDistance(self, d):
+        self._set(max_correspondence_distance=float(d))
+
+    def setMaximumOptimizerIterations(self, n):
+        self._set(max_optimizer_iterations=int(n))
+
+    def setRotationEpsilon(self, e):
+        self._set(rotation_epsilon=float(e))
+
+    def setEuclideanFitnessEpsilon(self, e):
+        self._set(euclidean_fitness_epsilon=float(e))
+
+    def setRANSACIterations(self, n):
+        self._set(ransac_iterations=int(n))
+
+    def setCorrespondenceRandomness(self, k):
+        self._set(k_correspondences=int(k))
+
+
 class BatchRegistration:
     """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one registration per pair —
     FAST_GICP (default) or NDT_OMP, the two engines GraphBasedSLAM::get_registration offers besides ICP

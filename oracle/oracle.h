@@ -122,6 +122,24 @@ void orc_icp_default_params(orc_icp_params* p);
 int orc_rigid_from_sums(const double* sums17, double* T16);
 int orc_icp_align(const float* src, size_t n, const float* tgt, size_t m, const orc_icp_params* p, const float* guess16, orc_result* r);
 
+/* ---- pclomp::GeneralizedIterativeClosestPoint ("GICP": lidar_scan_matcher.cpp:73-96, graph_based_slam.cpp:120-141) ---- */
+typedef struct orc_gicp_bfgs_params {
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance (yaml correspondence_distance -> 2.0) */
+  int max_iterations;                 /* setMaximumIterations */
+  int max_optimizer_iterations;       /* setMaximumOptimizerIterations (yaml max_optimizer_iteration -> 20) */
+  double transformation_epsilon;      /* setTransformationEpsilon (0.01) */
+  double rotation_epsilon;            /* PCL default 2e-3 */
+  int k_correspondences;              /* PCL default 20 */
+  double gicp_epsilon;                /* PCL default 1e-3 (the PLANE regularisation's small singular value; fixed) */
+  int num_threads;
+} orc_gicp_bfgs_params;
+void orc_gicp_bfgs_default_params(orc_gicp_bfgs_params* p);
+int orc_gicp_bfgs_align(const float* src, size_t n, const float* tgt, size_t m, const orc_gicp_bfgs_params* p, const float* guess16, orc_result* r);
+/* cost and gradient of the inner problem for given correspondences (isrc/itgt, m of them), Mahalanobis matrices indexed by
+ * SOURCE point (n_src x 9), base transformation and state x = (tx, ty, tz, roll, pitch, yaw) */
+int orc_gicp_bfgs_cost(const float* src, const float* tgt, const int* isrc, const int* itgt, int m, const double* mahal9_by_src, size_t n_src,
+                       const float* base16, const double* x6, double* f, double* g6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,3 +306,48 @@ def icp_align(src, tgt, params: IcpParams | None = None, guess=None):
                              _p(g, C.c_float), C.byref(r))
     assert rc == 0, rc
     return _result(r)
+
+
+class GicpBfgsParams(C.Structure):
+    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iterations", C.c_int), ("max_optimizer_iterations", C.c_int),
+                ("transformation_epsilon", C.c_double), ("rotation_epsilon", C.c_double), ("k_correspondences", C.c_int),
+                ("gicp_epsilon", C.c_double), ("num_threads", C.c_int)]
+
+
+def gicp_bfgs_params(**kw) -> GicpBfgsParams:
+    p = GicpBfgsParams()
+    lib().orc_gicp_bfgs_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def gicp_bfgs_align(src, tgt, params: GicpBfgsParams | None = None, guess=None):
+    """pclomp::GeneralizedIterativeClosestPoint::align ("GICP", lidar_scan_matcher.cpp:73-96)."""
+    src, tgt = _f4(src), _f4(tgt)
+    params = params or gicp_bfgs_params()
+    g = np.eye(4, dtype=np.float32) if guess is None else np.ascontiguousarray(guess, dtype=np.float32)
+    g = g.reshape(16)
+    r = Result()
+    rc = lib().orc_gicp_bfgs_align(_p(src, C.c_float), C.c_size_t(len(src)), _p(tgt, C.c_float), C.c_size_t(len(tgt)), C.byref(params),
+                                   _p(g, C.c_float), C.byref(r))
+    assert rc == 0, rc
+    return _result(r)
+
+
+def gicp_bfgs_cost(src, tgt, isrc, itgt, mahal_by_src, base, x6):
+    """(f, gradient[6]) of the inner BFGS problem for given correspondences."""
+    src, tgt = _f4(src), _f4(tgt)
+    isrc = np.ascontiguousarray(isrc, dtype=np.int32)
+    itgt = np.ascontiguousarray(itgt, dtype=np.int32)
+    M = np.ascontiguousarray(mahal_by_src, dtype=np.float64).reshape(len(src), 9)
+    b = np.ascontiguousarray(base, dtype=np.float32).reshape(16)
+    x = np.ascontiguousarray(x6, dtype=np.float64).reshape(6)
+    f = C.c_double(0)
+    g = np.empty(6)
+    rc = lib().orc_gicp_bfgs_cost(_p(src, C.c_float), _p(tgt, C.c_float), _p(isrc, C.c_int), _p(itgt, C.c_int), C.c_int(len(isrc)),
+                                  _p(M, C.c_double), C.c_size_t(len(src)), _p(b, C.c_float), _p(x, C.c_double), C.byref(f), _p(g, C.c_double))
+    assert rc == 0, rc
+    return f.value, g

@@ -65,6 +65,10 @@ def main():
     out.update(ndt_T=rn["T"], ndt_iterations=rn["iterations"])
     rm = O.ndt_align(v, tv, O.ndt_params(resolution=2.0, legacy_mt_skip=0))  # PCL >= 1.10: More-Thuente iterates
     out.update(ndt_T_mt=rm["T"], ndt_iterations_mt=rm["iterations"])
+    # ---- "GICP" (pclomp's BFGS GICP): the first outer iteration (one full BFGS minimisation), and the converged pose
+    b1 = O.gicp_bfgs_align(v, tv, O.gicp_bfgs_params(max_iterations=1))
+    bc = O.gicp_bfgs_align(v, tv)
+    out.update(bfgs_T_1=b1["T"], bfgs_cost_1=b1["error"], bfgs_T=bc["T"], bfgs_iterations=bc["iterations"])
     path = os.path.join(ROOT, "tests", "golden", "golden_small.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; src", v.shape, "tgt", tv.shape, "gicp err vs truth", synth.pose_error(r["T"], T_gt))

@@ -10,9 +10,11 @@ from ref_scan_matcher import matrix_to_pose, pose_to_matrix
 class RefLoopClosure:
     def __init__(self, search_key_frame_num=20, score_threshold=0.3, search_for_candidate_threshold=15.0, accumulate_distance_threshold=100.0,
                  submap_leaf=0.5, max_iteration=100, transformation_epsilon=0.01, max_correspondence_distance=2.0, correspondence_randomness=20,
-                 registration_method="ICP", step_size=0.1, ndt_resolution=1.0):
+                 registration_method="ICP", step_size=0.1, ndt_resolution=1.0, correspondence_distance=2.0, max_optimizer_iteration=20):
         self.method = registration_method
         self.np = O.ndt_params(resolution=ndt_resolution, step_size=step_size, transformation_epsilon=transformation_epsilon, max_iterations=max_iteration)
+        self.bp = O.gicp_bfgs_params(max_correspondence_distance=correspondence_distance, max_iterations=max_iteration,
+                                     max_optimizer_iterations=max_optimizer_iteration, transformation_epsilon=transformation_epsilon)
         self.ip = O.icp_params()  # graph_based_slam.cpp:145-149: 30 m, 100 iterations, 1e-8, 1e-6, no RANSAC
         self.n, self.score, self.cand_r, self.accum = search_key_frame_num, score_threshold, search_for_candidate_threshold, accumulate_distance_threshold
         self.leaf = submap_leaf
@@ -52,6 +54,8 @@ class RefLoopClosure:
             r = O.gicp_align(source, target, self.gp)
         elif self.method == "NDT_OMP":
             r = O.ndt_align(source, target, self.np)
+        elif self.method == "GICP":
+            r = O.gicp_bfgs_align(source, target, self.bp)
         else:
             r = O.icp_align(source, target, self.ip)
         fitness = O.fitness(source, target, r["T"])

@@ -28,6 +28,9 @@ def test_oracle_reproduces_golden(golden):
     r = O.gicp_align(G["voxel"], G["tgt_voxel"], O.gicp_params(max_iterations=8, force_iterations=1))
     dt, dr = synth.pose_error(r["T"], G["gicp_T"])
     assert dt < 1e-6 and dr < 1e-6
+    b1 = O.gicp_bfgs_align(G["voxel"], G["tgt_voxel"], O.gicp_bfgs_params(max_iterations=1))
+    np.testing.assert_allclose(b1["T"], G["bfgs_T_1"], atol=1e-6)
+    np.testing.assert_allclose(b1["error"], float(G["bfgs_cost_1"]), rtol=1e-6)
     sc, g, Hn = O.ndt_derivatives(G["voxel"], G["tgt_voxel"], G["ndt_p6"], O.ndt_params(resolution=2.0))
     np.testing.assert_allclose(sc, G["ndt_score"], rtol=1e-6)
     np.testing.assert_allclose(g, G["ndt_grad"], rtol=1e-5, atol=1e-5 * np.abs(G["ndt_grad"]).max())
@@ -83,3 +86,10 @@ def test_hip_path_reproduces_golden(golden):
     ndt_mt.align()
     dt, dr = synth.pose_error(ndt_mt.getFinalTransformation(), G["ndt_T_mt"])
     assert dt <= 0.01 and dr <= 2e-3, (dt, dr)
+    bf = R.GeneralizedIterativeClosestPoint(max_iterations=1)  # "GICP": one outer iteration = one full BFGS minimisation
+    bf.setInputTarget(G["tgt_voxel"])
+    bf.setInputSource(G["voxel"])
+    bf.align()
+    dt, dr = synth.pose_error(bf.getFinalTransformation(), G["bfgs_T_1"])
+    assert dt <= 5e-3 and dr <= 5e-4, (dt, dr)
+    assert abs(bf._result["error"] - float(G["bfgs_cost_1"])) <= 2e-3 * float(G["bfgs_cost_1"])

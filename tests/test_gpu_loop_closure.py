@@ -18,10 +18,11 @@ def _out_and_back(n_out=16, spacing=2.5):
     return poses
 
 
-@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP", "ICP"])
+@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP", "ICP", "GICP"])
 def test_batched_loop_closure_matches_restatement(method):
-    """All three engines GraphBasedSLAM::get_registration can build here (graph_based_slam.cpp:74-155; "ICP" is the yaml's
-    default): FAST_GICP and NDT_OMP register every candidate in one batch, ICP pair by pair on the device-resident clouds."""
+    """All four engines of GraphBasedSLAM::get_registration (graph_based_slam.cpp:74-155; "ICP" is the yaml's default):
+    FAST_GICP and NDT_OMP register every candidate in one batch, ICP and pclomp's BFGS GICP pair by pair on the device-resident
+    clouds."""
     from lidar_graph_slam_amd.loop_closure import LoopClosure
 
     scene = synth.Scene(1234)
@@ -59,7 +60,7 @@ def test_batched_loop_closure_matches_restatement(method):
         corrected = g["T"].astype(np.float64) @ (synth.se3(0.25, -0.15, 0.0, 0.0, 0.0, 0.01) @ truth[g["query_id"]])
         dt, dr = synth.pose_error(corrected, truth[g["query_id"]])
         # (the oracle lands on the same poses, see above; NDT with 1 m cells on 11 k-point key frames and point-to-point ICP are coarser)
-        tol_t, tol_r = (0.05, 5e-3) if method == "FAST_GICP" else (0.12, 1.5e-2)
+        tol_t, tol_r = (0.05, 5e-3) if method in ("FAST_GICP", "GICP") else (0.12, 1.5e-2)
         assert dt < tol_t and dr < tol_r, (method, dt, dr)
         bt, br = synth.pose_error(g["between"], w["between"])
         assert bt < 0.03 and br < 5e-3

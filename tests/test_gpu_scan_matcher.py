@@ -64,4 +64,4 @@ def test_unknown_method_fails_at_construction():
     from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
 
     with pytest.raises(L.Mi355Error):
-        LidarScanMatcher(registration_method="GICP")
+        LidarScanMatcher(registration_method="GICP_OMP")
