@@ -185,4 +185,35 @@ class NormalDistributionsTransform : public RegistrationBase<MI355_METHOD_NDT_OM
   double trans_probability_ = 0;
 };
 
+// replaces `new pcl::IterativeClosestPoint<PointType, PointType>` (graph_based_slam.cpp:143-144: the back end's default engine)
+class IterativeClosestPoint : public RegistrationBase<MI355_METHOD_ICP, mi355_icp_params> {
+ public:
+  using Ptr = pcl::shared_ptr<IterativeClosestPoint>;
+  explicit IterativeClosestPoint(int device_id = 0) : RegistrationBase(device_id) { mi355_icp_default_params(&p_); reg_name_ = "mi355::ICP"; }
+  void setMaxCorrespondenceDistance(double d) { p_.max_correspondence_distance = d; corr_dist_threshold_ = d; dirty_ = true; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; max_iterations_ = n; dirty_ = true; }
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; transformation_epsilon_ = e; dirty_ = true; }
+  void setEuclideanFitnessEpsilon(double e) { p_.euclidean_fitness_epsilon = e; euclidean_fitness_epsilon_ = e; dirty_ = true; }
+  void setRANSACIterations(int n) { p_.ransac_iterations = n; ransac_iterations_ = n; dirty_ = true; }  // only 0 is built
+};
+
+// replaces `new pclomp::GeneralizedIterativeClosestPoint<PointType, PointType>` (lidar_scan_matcher.cpp:74-75, graph_based_slam.cpp:122-123)
+class GeneralizedIterativeClosestPoint : public RegistrationBase<MI355_METHOD_GICP, mi355_gicp_bfgs_params> {
+ public:
+  using Ptr = pcl::shared_ptr<GeneralizedIterativeClosestPoint>;
+  explicit GeneralizedIterativeClosestPoint(int device_id = 0) : RegistrationBase(device_id) {
+    mi355_gicp_bfgs_default_params(&p_);
+    reg_name_ = "mi355::GICP";
+  }
+  void setMaxCorrespondenceDistance(double d) { p_.max_correspondence_distance = d; corr_dist_threshold_ = d; dirty_ = true; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; max_iterations_ = n; dirty_ = true; }
+  void setMaximumOptimizerIterations(int n) { p_.max_optimizer_iterations = n; dirty_ = true; }
+  void setTransformationEpsilon(double e) { p_.transformation_epsilon = e; transformation_epsilon_ = e; dirty_ = true; }
+  void setRotationEpsilon(double e) { p_.rotation_epsilon = e; dirty_ = true; }
+  void setEuclideanFitnessEpsilon(double e) { p_.euclidean_fitness_epsilon = e; euclidean_fitness_epsilon_ = e; dirty_ = true; }
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; dirty_ = true; }
+  void setRANSACIterations(int n) { p_.ransac_iterations = n; ransac_iterations_ = n; dirty_ = true; }  // only 0 is built
+  void setUseReciprocalCorrespondences(bool) {}  // a base-class flag GICP's computeTransformation never reads; the nodes set false
+};
+
 }  // namespace mi355_pcl

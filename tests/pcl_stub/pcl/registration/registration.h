@@ -36,7 +36,8 @@ class Registration {
   PointCloudSourceConstPtr input_;
   PointCloudTargetConstPtr target_;
   Matrix4 final_transformation_;
-  double transformation_epsilon_ = 0, corr_dist_threshold_ = 0;
+  double transformation_epsilon_ = 0, corr_dist_threshold_ = 0, euclidean_fitness_epsilon_ = 0;
+  int ransac_iterations_ = 0;
   bool converged_ = false, target_cloud_updated_ = true, force_no_recompute_ = false;
 };
 }  // namespace pcl

@@ -32,6 +32,25 @@ double use(pcl::PointCloud<PointType>::Ptr target, pcl::PointCloud<PointType>::P
     ndt->setNumThreads(4);
     (void)ndt->getTransformationProbability();
   }
+  {  // lidar_scan_matcher.cpp:73-96, graph_based_slam.cpp:120-141
+    mi355_pcl::GeneralizedIterativeClosestPoint::Ptr gicp(new mi355_pcl::GeneralizedIterativeClosestPoint());
+    gicp->setMaxCorrespondenceDistance(5.0);
+    gicp->setMaximumIterations(64);
+    gicp->setUseReciprocalCorrespondences(false);
+    gicp->setMaximumOptimizerIterations(20);
+    gicp->setTransformationEpsilon(0.01);
+    gicp->setEuclideanFitnessEpsilon(1e-8);
+    gicp->setCorrespondenceRandomness(20);
+    gicp->setRANSACIterations(0);
+  }
+  {  // graph_based_slam.cpp:142-151
+    mi355_pcl::IterativeClosestPoint::Ptr icp(new mi355_pcl::IterativeClosestPoint());
+    icp->setMaxCorrespondenceDistance(30);
+    icp->setMaximumIterations(100);
+    icp->setTransformationEpsilon(1e-8);
+    icp->setEuclideanFitnessEpsilon(1e-6);
+    icp->setRANSACIterations(0);
+  }
   registration_->setInputTarget(target);
   registration_->setInputSource(source);
   pcl::PointCloud<PointType> out;
