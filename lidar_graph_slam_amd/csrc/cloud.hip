@@ -359,12 +359,16 @@ __device__ __forceinline__ void covariance_of(int k, int method, Cov6* o, P&& po
 // fallback queue and are done by k_knn_hard + k_cov_from_knn.  A tile whose own box is too large (it straddles a jump of
 // the Morton curve, or lies in the sparse far field) is split into halves, processed one after the other by the whole wave.
 constexpr int kOrdBits = 10;
-constexpr int kTileMaxCand = 1 << kOrdBits;  // candidates per tile segment (list positions)
-constexpr uint32_t kOrdMask = kTileMaxCand - 1;
+constexpr int kTileMaxCand = 768;            // candidates per tile segment (list positions; at most 2^kOrdBits)
+constexpr uint32_t kOrdMask = (1u << kOrdBits) - 1u;
 constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
 constexpr int kSubQ = 8;                     // lanes (queries) per sub-tile
 constexpr int kNSub = kWave / kSubQ;
-constexpr int kSubCap = 220;                 // candidates per sub-tile list (16 KB tile list + 3.5 KB of lists per wave: 8 waves per CU)
+// candidates per sub-tile list.  12 KB tile list + 7.5 KB of sub-lists per wave = 8 waves per CU, the same footprint as
+// the first split (1 024 + 8 x 220): measured at 1 024 clouds, lists that overflow are what sends most points to k_knn_hard —
+// 220 entries: 2.65 % handed over, tile kernel 11.3 ms + hard 3.9 ms per launch; 476 entries with a 768-entry tile list:
+// 1.08 %, 10.9 ms + 1.8 ms (604 / 640: 1.27 %, 11.1 + 2.0; 348 / 1 024: 1.24 %, 12.4 + 2.0).
+constexpr int kSubCap = 476;
 constexpr int kSubRow = kSubCap + 4;         // row pitch: the 4-way unrolled rank loop may read (and ignore) up to 3 entries past the end
 
 // min / max over the aligned group of kSubQ lanes a lane belongs to (same value in all lanes of the group)
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   const int lane = lane_id();
   const int mysub = lane / kSubQ, sublane = lane % kSubQ;
   const unsigned long long below = (1ull << lane) - 1ull;
+  for (int z = lane; z < kNSub * kSubRow; z += kWave) (&sub[0][0])[z] = 0;
   for (;;) {
   int tile = 0;
   if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
@@ -585,8 +590,9 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           const int cnt = to - from;
 #pragma unroll 4
           for (int t = 0; t < trip; t++) {
-            // rows are padded: reading past `to` stays inside the array, and a stale offset stays inside cand[]
-            const uint32_t off = (uint32_t)mine[t] & (uint32_t)((kTileMaxCand - 1) << 4);
+            // rows are padded: reading past `to` stays inside the array; what is found there is an offset this wave stored earlier
+            // or the zero the rows start with, i.e. always inside cand[]
+            const uint32_t off = (uint32_t)mine[t];
             const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + off);
             const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
             keys.insert((t < cnt) ? ((d & ~kOrdMask) | (off >> 4)) : SmallestKeys<K + 2>::kEmpty);
