@@ -14,9 +14,9 @@ SERIAL = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", 
 P = os.path.join(ROOT, "profiles")
 
 NOTES = {
-    "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles, 8-lane sub-tile candidate lists (476 entries) in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); VALU-bound",
+    "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles, 16-lane sub-tile candidate lists in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); VALU-bound",
     "k_gicp_correspond": "F3, incremental and exact: tiles in the first two iterations, margins afterwards (DESIGN §4.3); latency-bound walks of the voxel hash",
-    "k_knn_hard": "the 1.1 % of the points the tiles hand over (far field, ties), one wave per query",
+    "k_knn_hard": "the 1.0 % of the points the tiles hand over (far field, ties), one wave per query",
     "sort_pairs(k_sort_*)": "in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
     "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order), head thread walks its run 4 loads deep",
     "k_gicp_linearize": "F4, streaming: 80 algorithmic B per source point",

@@ -344,9 +344,9 @@ __device__ __forceinline__ void covariance_of(int k, int method, Cov6* o, P&& po
 
 // Steps 1+2, fast path: k-NN and covariance of every point by the wave-cooperative tile search (tile.hpp).  One wave =
 // 64 consecutive points of the Morton-sorted cloud.  The points of the grown tile box are gathered into LDS once; every
-// group of kSubQ consecutive lanes (a SUB-TILE: 8 points that are neighbours on the Morton curve) then gets its own list of
+// group of kSubQ consecutive lanes (a SUB-TILE: 16 points that are neighbours in the kd order of the tile) then gets its own list of
 // the candidates inside ITS grown bounding box, and a lane ranks only its sub-tile's list through a (k+2)-deep key network
-// — about 110 candidates for k = 20 instead of the ~385 of the whole tile, which is what bounded the first version of
+// — well under half of the ~385 candidates of the whole tile for k = 20, which is what bounded the first version of
 // this kernel (VALU-bound on 64 lanes x 385 candidates x 23 v_med3).  A key is the squared distance with the candidate's
 // position in the tile list in the low kOrdBits mantissa bits, so the k smallest keys ARE the neighbour list and the
 // covariance is computed straight from the LDS copies of those points.  The box radius starts from the tile's own point
@@ -362,13 +362,14 @@ constexpr int kOrdBits = 10;
 constexpr int kTileMaxCand = 768;            // candidates per tile segment (list positions; at most 2^kOrdBits)
 constexpr uint32_t kOrdMask = (1u << kOrdBits) - 1u;
 constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
-constexpr int kSubQ = 8;                     // lanes (queries) per sub-tile
+constexpr int kSubQ = 16;                    // lanes (queries) per sub-tile (8: 10.9 + 1.8 ms per launch, 16: 10.7 + 1.7 ms, 4: 12.3 + 2.5 ms)
 constexpr int kNSub = kWave / kSubQ;
 // candidates per sub-tile list.  12 KB tile list + 7.5 KB of sub-lists per wave = 8 waves per CU, the same footprint as
 // the first split (1 024 + 8 x 220): measured at 1 024 clouds, lists that overflow are what sends most points to k_knn_hard —
 // 220 entries: 2.65 % handed over, tile kernel 11.3 ms + hard 3.9 ms per launch; 476 entries with a 768-entry tile list:
-// 1.08 %, 10.9 ms + 1.8 ms (604 / 640: 1.27 %, 11.1 + 2.0; 348 / 1 024: 1.24 %, 12.4 + 2.0).
-constexpr int kSubCap = 476;
+// 1.08 %, 10.9 ms + 1.8 ms (604 / 640: 1.27 %, 11.1 + 2.0; 348 / 1 024: 1.24 %, 12.4 + 2.0).  (Those with 8-lane sub-tiles; the
+// 16-lane sub-tiles in the tree have 4 lists of 764: 1.01 %.)
+constexpr int kSubCap = 764;
 constexpr int kSubRow = kSubCap + 4;         // row pitch: the 4-way unrolled rank loop may read (and ignore) up to 3 entries past the end
 
 // min / max over the aligned group of kSubQ lanes a lane belongs to (same value in all lanes of the group)
@@ -418,7 +419,7 @@ __device__ __forceinline__ int segment_longest_axis(float x, float y, float z) {
   return (ex >= ey && ex >= ez) ? 0 : ((ey >= ez) ? 1 : 2);
 }
 // kd order of the 64 queries of a tile: split at the median along the longest axis, three levels deep, so that every aligned
-// group of 8 lanes (a sub-tile) and every aligned half / quarter (what a tile is split into when its box is too big) is
+// group of 8 / 16 lanes (a sub-tile) and every aligned half / quarter (what a tile is split into when its box is too big) is
 // spatially compact.  64 consecutive points of the Morton curve are NOT: the curve jumps, and one ragged group of 8 sets
 // the trip count of the whole wave's ranking loop (measured: mean sub-list 77 candidates, longest 182).
 __device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int& i) {
