@@ -15,7 +15,8 @@ P = os.path.join(ROOT, "profiles")
 
 NOTES = {
     "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles, 16-lane sub-tile candidate lists in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); VALU-bound",
-    "k_gicp_correspond": "F3, incremental and exact: tiles in the first two iterations, margins afterwards (DESIGN §4.3); latency-bound walks of the voxel hash",
+    "k_gicp_correspond": "F3, incremental and exact: per-lane walks of the voxel hash, margins (DESIGN §4.3); latency-bound",
+    "k_gicp_correspond_tile": "F3 for the first two iterations, when every point moves: 64-point tiles, packed distance/ordinal keys",
     "k_knn_hard": "the 1.0 % of the points the tiles hand over (far field, ties), one wave per query",
     "sort_pairs(k_sort_*)": "in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
     "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order), head thread walks its run 4 loads deep",
@@ -31,7 +32,7 @@ def load(name):
 
 
 def main():
-    b, tr, hi, i2, p128, tj = (load(n) for n in ("bench_default", "bench_under_trace", "bench_hostinputs", "bench_inflight2", "bench_128pairs", "traffic"))
+    b, tr, hi, one, i3, p128, tj = (load(n) for n in ("bench_default", "bench_under_trace", "bench_hostinputs", "bench_single_batch", "bench_inflight3", "bench_128pairs", "traffic"))
     ser = json.load(open(SERIAL)) if os.path.exists(SERIAL) else None
     rows = list(csv.DictReader(open(os.path.join(P, f"{R}_kernel_stats_bench_default.csv"))))
     tot_ns = sum(float(x["TotalDurationNs"]) for x in rows)
@@ -41,8 +42,9 @@ def main():
     top = rows[0]
     out = f"""# profiles/ — round 2 (MI355X, gfx950, ROCm 7.2)
 
-Everything here comes from ONE command family on a fresh 1-GPU box — `python bench.py` (defaults: {pairs} pairs/step, 20 timed
-steps, 5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel 0.2 m, k = 20, exactly 20 LM iterations) — run by
+Everything here comes from ONE command family on a fresh 1-GPU box — `python bench.py` (defaults: {pairs} pairs per step = per
+batch, {b['config'].get('batches_in_flight', 1)} batches in flight on two HIP streams, 20 timed steps, 5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel
+0.2 m, k = 20, exactly 20 LM iterations) — run by
 `benchmarks/collect_evidence.sh {R}` and distilled by `benchmarks/summarize_evidence.py` / `write_profiles_readme.py`.
 The `r01_*` files are round 1's, kept for the history.
 
@@ -53,19 +55,22 @@ The `r01_*` files are round 1's, kept for the history.
 | `{R}_pmc_fetch_write.csv` | per-kernel HBM traffic from two separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE …` / `--pmc WRITE_SIZE …` of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` |
 | `{R}_traffic.json` | the `{tj['kernel']}` row of the above (FETCH_SIZE × 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), read by `bench.py` into `roofline.traffic` |
 | `{R}_bench_hostinputs.json` | `python bench.py --host-inputs`: HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
-| `{R}_bench_inflight2.json` | `python bench.py --inflight 2`: two batch objects on two streams used alternately |
+| `{R}_bench_single_batch.json` | `python bench.py --inflight 1 --pairs 1024`: ONE batch object of 1 024 pairs (the same memory), nothing pipelined — round 1's protocol |
+| `{R}_bench_inflight3.json` | `python bench.py --inflight 3`: three batches of {pairs} in flight |
+| `{R}_bench_serial_streams.json` | `--inflight 1 --pairs 1024` with `MI355_BATCH_SIDE_STREAMS=0`: every kernel by itself |
 | `{R}_bench_128pairs.json` | `python bench.py --pairs 128` |
 | `{R}_other_configs.txt` | `python benchmarks/other_configs.py --scans 200`: the BASELINE configs that are not the bench line |
 
 ## The roofline block, recomputed from these files
 
-* dominant kernel family = the one with the largest total duration in the timed region: **`{dom}`** — also the top row of
+* dominant kernel family = the one with the largest isolated duration × launches per step: **`{dom}`** — also the top row of
   `{R}_kernel_stats_bench_default.csv` (`{top['Name'].split('(')[0].replace('void ', '')}`, {100 * float(top['TotalDurationNs']) / tot_ns:.1f} % of the kernel time).
 * algorithmic bytes per launch = 40 B per cloud point (16 B point read + 24 B covariance written, SURVEY §8d) × Σ points of the
   {pairs} clouds of a launch = **{rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB**;
 * mean launch duration: **{rf['avg_launch_ms']:.2f} ms** from HIP events on the launching stream inside `bench.py` ({rf['launches']} launches);
   **{float(top['AverageNs']) / 1e6:.2f} ms** in the rocprofv3 kernel trace of the same command ({top['Calls']} launches) — they agree.  Both are durations
-  WHILE THE OTHER PREPARATION STREAM RUNS (targets and sources are indexed concurrently, two `{dom}` launches overlap);
+  WHILE THE KERNEL SHARES THE GPU (the other preparation stream and the other batch's LM iterations run at the same time); by itself
+  — `roofline.isolated`, two extra steps of one batch after the timed region — a launch takes **{rf['isolated']['avg_launch_ms']:.2f} ms = {100 * rf['isolated']['frac']:.2f} % of HBM peak**;
 * achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound, the
   HBM roofline is simply the wrong ceiling for it, and the bench says so instead of picking a flattering kernel;
 * PMC traffic per launch: FETCH_SIZE {tj['fetch_size_kb_raw'] / 1e3:.0f} MB raw × 2 + WRITE_SIZE {tj['write_size_kb'] / 1e3:.0f} MB = **{tj['hbm_bytes_per_launch'] / 1e6:.0f} MB = {tj['hbm_bytes_per_launch'] / rf['algorithmic_bytes_per_launch']:.2f} × algorithmic**
@@ -77,16 +82,19 @@ The `r01_*` files are round 1's, kept for the history.
 ## Where the step goes ({pairs} pairs/step)
 
 HIP-event totals per kernel family (`roofline.by_kernel`).  Targets and sources are prepared on two concurrent streams, so the
-durations of the preparation kernels overlap (their sum exceeds the step)"""
-    if ser:
-        out += f"; the third column is the same family with `MI355_BATCH_SIDE_STREAMS=0` (one stream, nothing overlaps: {ser['ms_per_step']:.1f} ms/step)"
-    out += ".\n\n| kernel family | launches/step | ms/step, default (avg per launch) | " + ("ms per launch, one stream | " if ser else "") + "frac of HBM peak (algorithmic bytes) | note |\n"
-    out += "|---|---|---|" + ("---|" if ser else "") + "---|---|\n"
-    for name, v in rf["by_kernel"].items():
-        s1 = ser["roofline"]["by_kernel"].get(name, {}).get("avg_launch_ms") if ser else None
-        frac = v.get("frac_of_hbm_peak")
+durations of the kernels overlap (their sum exceeds the step); the isolated column is the same kernel with nothing beside it.
+
+| kernel family | launches/step | live: ms/step (avg per launch) | isolated: ms per launch | frac of HBM peak, isolated (algorithmic bytes) | note |
+|---|---|---|---|---|---|
+"""
+    order = sorted(rf["by_kernel"].items(), key=lambda kv: -kv[1].get("isolated_avg_launch_ms", kv[1]["avg_launch_ms"]) * kv[1]["launches_per_step"])
+    for name, v in order:
+        frac = v.get("isolated_frac_of_hbm_peak")
+        iso = v.get("isolated_avg_launch_ms")
         out += (f"| `{name}` | {v['launches_per_step']:.0f} | {v['total_ms_per_step']:.2f} ({v['avg_launch_ms']:.3f}) | "
-                + (f"{s1:.3f} | " if ser else "") + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {NOTES.get(name, '')} |\n")
+                + (f"{iso:.3f} | " if iso is not None else "– | ") + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {NOTES.get(name, '')} |\n")
+    if ser:
+        out += f"\nOne batch of 1 024 pairs with the preparation chains serialised (`{R}_bench_serial_streams.json`): {ser['ms_per_step']:.1f} ms/step.\n"
     by_threads = ", ".join(f"{t} threads: {v}" for t, v in cpu["pairs_per_s_by_threads"].items())
     oc = open(os.path.join(P, f"{R}_other_configs.txt")).read()
     ocj = json.loads(oc)
@@ -95,9 +103,10 @@ durations of the preparation kernels overlap (their sum exceeds the step)"""
 
 | what | value |
 |---|---|
-| `python bench.py` ({pairs} pairs/step) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 1: 11 572; boxes of the pool differ by a few per cent) |
+| `python bench.py` ({pairs} pairs per batch, {b['config'].get('batches_in_flight', 1)} in flight) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms per batch (boxes of the pool differ by a few per cent) |
+| `--inflight 1 --pairs 1024` (one batch at a time: round 1's protocol, 11 572 pairs/s then) | {one['value']:.0f} pairs/s, {one['ms_per_step']:.1f} ms/step |
+| `--inflight 3` | {i3['value']:.0f} pairs/s |
 | `--pairs 128` | {p128['value']:.0f} pairs/s |
-| `--inflight 2` | {i2['value']:.0f} pairs/s: the LM iterations of one batch overlap the indexing of the next |
 | `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |
 | CPU oracle on the same host ({cpu['cpu_model']}, {cpu['host_hw_threads']} hardware threads) | {by_threads} pairs/s; `cpu_baseline.value` is the {cpu['cores']}-thread figure, 4 threads is the reference's configuration (`lidar_scan_matcher.param.yaml:10`) |
 | GPU vs CPU pose of the same world-transformed pair | {cpu['gpu_vs_cpu_pose_dt_m'] * 1e3:.4f} mm / {cpu['gpu_vs_cpu_pose_dr_rad']:.1e} rad (bench.py aborts above 1 mm / 1e-4 rad) |

@@ -287,6 +287,10 @@ typedef struct mi355_kernel_time {
   int launches;
   int reserved;
 } mi355_kernel_time;
+/* Where mi355_batch_set_targets* / _sources* run their preparation chains: 1 = on two internal side streams that overlap each other
+ * (joined by mi355_batch_align), 0 = on the batch's own stream, one after the other, -1 = the library default (1).  Results are
+ * identical; 0 is what a profiler wants when it asks how long a kernel takes by itself. */
+int mi355_batch_set_side_streams(mi355_batch* b, int mode);
 int mi355_batch_set_timing(mi355_batch* b, int enable);
 int mi355_batch_kernel_times(mi355_batch* b, mi355_kernel_time* out, int capacity, int* n_out);
 

@@ -131,7 +131,7 @@ EXPORTS = [
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
     "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
-    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times",
+    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams",
 ]
 # include/mi355_scan_matcher.h
 EXPORTS_SCAN_MATCHER = [
@@ -284,6 +284,7 @@ def lib():
         L.mi355_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_batch_set_side_streams.argtypes = [C.c_void_p, C.c_int]
         L.mi355_batch_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
         L.mi355_loop_closure_default_params.argtypes = [C.POINTER(LoopClosureParams)]
         L.mi355_loop_closure_default_params.restype = None

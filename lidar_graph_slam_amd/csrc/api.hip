@@ -11,7 +11,7 @@ using namespace mi355;
 namespace mi355 {
 thread_local KernelTimers* g_timers = nullptr;
 const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
-                                                 "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_linearize",
+                                                 "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
                                                  "k_gicp_error", "k_gicp_solve+k_gicp_decide", "k_fitness"};
 const Tuning& tuning() {
   static const Tuning t = [] {
@@ -156,6 +156,7 @@ struct mi355_batch {
   CloudSet src, tgt;
   GicpBatch gb;
   KernelTimers timers;  // mi355_batch_set_timing / mi355_batch_kernel_times
+  int side_streams = -1;  // mi355_batch_set_side_streams: -1 = the library default (Tuning::side_streams), 0 / 1 = off / on
   DevBuf<float4> host_stage;
   DevBuf<float4> cloud_stage_src, cloud_stage_tgt;  // mi355_batch_set_*_clouds: the slots assembled on the device
   hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
@@ -1104,7 +1105,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
   // fork: everything already enqueued on the context stream (the producer of d_points, the previous align that still reads
   // this cloud set) comes first
-  const bool side_streams = tuning().side_streams != 0;
+  const bool side_streams = (b->side_streams >= 0 ? b->side_streams : tuning().side_streams) != 0;
   TimerScope timing(&b->timers);
   if (side_streams) {
     MI_HIP(hipEventRecord(sd.fork, b->stream()));
@@ -1274,6 +1275,17 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     } else {
       gicp_results(b->stream(), b->gb, b->src, b->tgt, results, fitness);
     }
+  });
+}
+
+extern "C" int mi355_batch_set_side_streams(mi355_batch* b, int mode) {
+  if (!b || mode < -1 || mode > 1) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    MI_HIP(hipSetDevice(b->ctx->device));
+    for (auto& sd : b->side)  // nothing of an earlier call may still be running on a side stream when the mode changes
+      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    batch_join(b);
+    b->side_streams = mode;
   });
 }
 

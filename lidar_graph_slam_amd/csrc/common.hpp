@@ -98,7 +98,7 @@ const Tuning& tuning();
 // HIP events recorded on the LAUNCHING stream around the launches of a family, only while a batch has timing enabled
 // (mi355_batch_set_timing).  The durations are read after the streams have been synchronised (mi355_batch_kernel_times).
 enum KernelFamily : int {
-  KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_LINEARIZE, KF_ERROR, KF_SOLVE_DECIDE,
+  KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_CORRESPOND_TILE, KF_LINEARIZE, KF_ERROR, KF_SOLVE_DECIDE,
   KF_FITNESS, KF_COUNT
 };
 extern const char* const kKernelFamilyName[KF_COUNT];

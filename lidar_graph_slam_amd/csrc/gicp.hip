@@ -1049,15 +1049,17 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
   const int lin_ppt = tuning().lin_ppt;
   auto kl = lin_ppt == 1 ? k_gicp_linearize<1> : (lin_ppt == 2 ? k_gicp_linearize<2> : k_gicp_linearize<4>);
   {
-    TimedLaunch tl(KF_CORRESPOND, s);
     const Tuning& tn = tuning();
     // a handful of pairs cannot fill the chip with tiles: their few hundred waves would each wait out their own gathers, and a
     // lone pair is usually a scan against a dense multi-key-frame sub-map, where the per-lane walk wins anyway
     const bool tiles = tile_search >= 0 ? tile_search != 0 : (iteration < tn.corr_tiles && gb.S >= 8);
-    if (tiles)
+    if (tiles) {
+      TimedLaunch tl(KF_CORRESPOND_TILE, s);
       hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
                          tgt.pts.p, tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p,
                          gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p, (double)tn.margin_step);
+    }
+    TimedLaunch tl(KF_CORRESPOND, s);
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                        tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
                        gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step);

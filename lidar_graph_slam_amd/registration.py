@@ -368,6 +368,11 @@ class BatchRegistration:
         out = [r.to_dict() for r in res]
         return (out, fit) if with_fitness else out
 
+    def set_side_streams(self, on: bool | None):
+        """Prepare targets and sources on two overlapping side streams (True, the default), or one after the other on the batch's
+        own stream (False: what a profiler wants); None = the library default."""
+        self.ctx.check(self.ctx._lib.mi355_batch_set_side_streams(self.handle, -1 if on is None else (1 if on else 0)))
+
     def set_timing(self, enable: bool = True):
         """Record HIP events around the hot kernels of this batch (bench.py's roofline block)."""
         self.ctx.check(self.ctx._lib.mi355_batch_set_timing(self.handle, 1 if enable else 0))
