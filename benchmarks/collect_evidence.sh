@@ -12,10 +12,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_fetch.err"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_write.err"
 timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinputs.json" 2> "$O/bench_hostinputs.err"
-timeout 300 python bench.py --inflight 1 --pairs 1024 --no-cpu-baseline > "$O/bench_single_batch.json" 2> "$O/bench_single_batch.err"
-timeout 300 python bench.py --inflight 3 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"
+timeout 300 python bench.py --inflight 2 --pairs 512 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
+timeout 300 python bench.py --inflight 3 --pairs 512 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"
 timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.json" 2> "$O/bench_128pairs.err"
 timeout 900 python benchmarks/other_configs.py --scans 200 > "$O/other_configs.txt" 2> "$O/other_configs.err"
 timeout 600 python benchmarks/config5.py --candidates 512 --submaps 8 > "$O/config5_1gpu.json" 2> "$O/config5_1gpu.err"
-MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --inflight 1 --pairs 1024 --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"
+MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"
 ls -la "$O"

@@ -32,7 +32,7 @@ def load(name):
 
 
 def main():
-    b, tr, hi, one, i3, p128, tj = (load(n) for n in ("bench_default", "bench_under_trace", "bench_hostinputs", "bench_single_batch", "bench_inflight3", "bench_128pairs", "traffic"))
+    b, tr, hi, i2, i3, p128, tj = (load(n) for n in ("bench_default", "bench_under_trace", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "traffic"))
     ser = json.load(open(SERIAL)) if os.path.exists(SERIAL) else None
     rows = list(csv.DictReader(open(os.path.join(P, f"{R}_kernel_stats_bench_default.csv"))))
     tot_ns = sum(float(x["TotalDurationNs"]) for x in rows)
@@ -43,8 +43,8 @@ def main():
     out = f"""# profiles/ — round 2 (MI355X, gfx950, ROCm 7.2)
 
 Everything here comes from ONE command family on a fresh 1-GPU box — `python bench.py` (defaults: {pairs} pairs per step = per
-batch, {b['config'].get('batches_in_flight', 1)} batches in flight on two HIP streams, 20 timed steps, 5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel
-0.2 m, k = 20, exactly 20 LM iterations) — run by
+batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel 0.2 m, k = 20, exactly
+20 LM iterations) — run by
 `benchmarks/collect_evidence.sh {R}` and distilled by `benchmarks/summarize_evidence.py` / `write_profiles_readme.py`.
 The `r01_*` files are round 1's, kept for the history.
 
@@ -55,9 +55,9 @@ The `r01_*` files are round 1's, kept for the history.
 | `{R}_pmc_fetch_write.csv` | per-kernel HBM traffic from two separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE …` / `--pmc WRITE_SIZE …` of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` |
 | `{R}_traffic.json` | the `{tj['kernel']}` row of the above (FETCH_SIZE × 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), read by `bench.py` into `roofline.traffic` |
 | `{R}_bench_hostinputs.json` | `python bench.py --host-inputs`: HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
-| `{R}_bench_single_batch.json` | `python bench.py --inflight 1 --pairs 1024`: ONE batch object of 1 024 pairs (the same memory), nothing pipelined — round 1's protocol |
-| `{R}_bench_inflight3.json` | `python bench.py --inflight 3`: three batches of {pairs} in flight |
-| `{R}_bench_serial_streams.json` | `--inflight 1 --pairs 1024` with `MI355_BATCH_SIDE_STREAMS=0`: every kernel by itself |
+| `{R}_bench_inflight2.json` | `python bench.py --inflight 2 --pairs 512`: two batch objects on two streams used alternately, the memory of the default |
+| `{R}_bench_inflight3.json` | `python bench.py --inflight 3 --pairs 512` |
+| `{R}_bench_serial_streams.json` | the default with `MI355_BATCH_SIDE_STREAMS=0`: the preparation chains one after the other |
 | `{R}_bench_128pairs.json` | `python bench.py --pairs 128` |
 | `{R}_other_configs.txt` | `python benchmarks/other_configs.py --scans 200`: the BASELINE configs that are not the bench line |
 
@@ -69,7 +69,7 @@ The `r01_*` files are round 1's, kept for the history.
   {pairs} clouds of a launch = **{rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB**;
 * mean launch duration: **{rf['avg_launch_ms']:.2f} ms** from HIP events on the launching stream inside `bench.py` ({rf['launches']} launches);
   **{float(top['AverageNs']) / 1e6:.2f} ms** in the rocprofv3 kernel trace of the same command ({top['Calls']} launches) — they agree.  Both are durations
-  WHILE THE KERNEL SHARES THE GPU (the other preparation stream and the other batch's LM iterations run at the same time); by itself
+  WHILE THE KERNEL SHARES THE GPU (targets and sources are indexed on two streams at the same time: two `{dom}` launches overlap); by itself
   — `roofline.isolated`, two extra steps of one batch after the timed region — a launch takes **{rf['isolated']['avg_launch_ms']:.2f} ms = {100 * rf['isolated']['frac']:.2f} % of HBM peak**;
 * achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound, the
   HBM roofline is simply the wrong ceiling for it, and the bench says so instead of picking a flattering kernel;
@@ -103,9 +103,9 @@ durations of the kernels overlap (their sum exceeds the step); the isolated colu
 
 | what | value |
 |---|---|
-| `python bench.py` ({pairs} pairs per batch, {b['config'].get('batches_in_flight', 1)} in flight) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms per batch (boxes of the pool differ by a few per cent) |
-| `--inflight 1 --pairs 1024` (one batch at a time: round 1's protocol, 11 572 pairs/s then) | {one['value']:.0f} pairs/s, {one['ms_per_step']:.1f} ms/step |
-| `--inflight 3` | {i3['value']:.0f} pairs/s |
+| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 1: 11 572; boxes of the pool differ by a few per cent) |
+| `--inflight 2 --pairs 512` (two batches in flight, the same memory) | {i2['value']:.0f} pairs/s — the LM iterations of one batch overlap the indexing of the next; HIP-event brackets then include waiting for the other stream, so the default stays unpipelined |
+| `--inflight 3 --pairs 512` | {i3['value']:.0f} pairs/s |
 | `--pairs 128` | {p128['value']:.0f} pairs/s |
 | `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |
 | CPU oracle on the same host ({cpu['cpu_model']}, {cpu['host_hw_threads']} hardware threads) | {by_threads} pairs/s; `cpu_baseline.value` is the {cpu['cores']}-thread figure, 4 threads is the reference's configuration (`lidar_scan_matcher.param.yaml:10`) |
