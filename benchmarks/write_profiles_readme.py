@@ -68,7 +68,8 @@ The `r01_*` files are round 1's, kept for the history.
 * algorithmic bytes per launch = 40 B per cloud point (16 B point read + 24 B covariance written, SURVEY §8d) × Σ points of the
   {pairs} clouds of a launch = **{rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB**;
 * mean launch duration: **{rf['avg_launch_ms']:.2f} ms** from HIP events on the launching stream inside `bench.py` ({rf['launches']} launches);
-  **{float(top['AverageNs']) / 1e6:.2f} ms** in the rocprofv3 kernel trace of the same command ({top['Calls']} launches) — they agree.  Both are durations
+  **{float(top['AverageNs']) / 1e6:.2f} ms** in the rocprofv3 kernel trace of the same command ({top['Calls']} launches: the warm-up and timed steps plus the 4 isolated launches
+  after the timed region, which pull the trace's average down) — they agree.  Both are durations
   WHILE THE KERNEL SHARES THE GPU (targets and sources are indexed on two streams at the same time: two `{dom}` launches overlap); by itself
   — `roofline.isolated`, two extra steps of one batch after the timed region — a launch takes **{rf['isolated']['avg_launch_ms']:.2f} ms = {100 * rf['isolated']['frac']:.2f} % of HBM peak**;
 * achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound, the
