@@ -252,6 +252,40 @@ def test_device_inputs_follow_the_callers_stream(R, small_pair):
     ctx.set_stream(None)
 
 
+def test_side_streams_only_reorder_independent_work(R, small_pair):
+    """mi355_batch_set_side_streams: the preparation chains of targets and sources on two overlapping side streams (default) or one
+    after the other on the batch's stream (what bench.py's isolated pass uses) — bit-identical poses, and the timers see every
+    kernel family either way."""
+    s, t, _ = small_pair
+    cap = max(len(s), len(t))
+    n = 9  # >= 8 pairs: the first iterations go through k_gicp_correspond_tile
+    srcs = np.zeros((n, cap, 4), np.float32)
+    tgts = np.zeros((n, cap, 4), np.float32)
+    ns, nt = [], []
+    for i in range(n):
+        si, ti = s[: len(s) - 7 * i], t[: len(t) - 2 * i]
+        srcs[i, : len(si)], tgts[i, : len(ti)] = si, ti
+        ns.append(len(si))
+        nt.append(len(ti))
+    b = R.BatchRegistration(n, n, cap, max_iterations=5, force_iterations=1)
+    b.set_timing(True)
+    out = []
+    for mode in (True, False, None):
+        b.set_side_streams(mode)
+        b.set_targets(tgts, nt)
+        b.set_sources(srcs, ns)
+        b.align()
+        out.append(np.stack([r["T"] for r in b.results()]))
+        kt = b.kernel_times()
+        assert kt["k_gicp_correspond"][1] == 5 and kt["k_gicp_correspond_tile"][1] == 2 and kt["k_knn_cov_tile"][1] == 2
+    np.testing.assert_array_equal(out[0], out[1])
+    np.testing.assert_array_equal(out[0], out[2])
+    ref = O.gicp_align(srcs[3, : ns[3]], tgts[3, : nt[3]], O.gicp_params(max_iterations=5, force_iterations=1))
+    dt, dr = synth.pose_error(out[0][3], ref["T"])
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    b.close()
+
+
 def test_batches_on_their_own_streams(R, small_pair):
     """mi355_batch_set_stream: two batch objects on two HIP streams, used alternately with device-resident inputs and their
     results collected late (the double buffering of bench.py --inflight 2) give bit-identical poses to a batch on the context
