@@ -1180,10 +1180,10 @@ __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict_
 }
 
 // One thread per sorted point; the thread at the head of a voxel's run adds the run in ascending point-index order (the
-// stable sort's order — the same as the oracle's, so the fp32 sums are bit-equal), gathering the points straight from
-// memory, four in flight per step.  No barrier and no LDS staging: the first version staged 1 024-point tiles through LDS
-// behind a block barrier and took 5.7 ms per 1 024-cloud launch for 2.2 GB of traffic; a run is ~4 points on average (up
-// to ~100 in the voxels next to the sensor), and a lane that is not a head simply retires.
+// stable sort's order — the same as the oracle's, so the fp32 sums are bit-equal).  History, per 1 024-cloud launch: 1 024-point
+// tiles staged through LDS behind a block barrier 5.7 ms; head threads walking their runs from memory, four gathers in flight,
+// 2.6 ms (a run is ~4 points on average, up to ~100 next to the sensor; 3 lanes of 4 idle); now one gather per lane and the run
+// handed to its head by lane shuffles.
 __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                          const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
                                                          const int* __restrict__ flags, const int* __restrict__ local,
@@ -1194,32 +1194,53 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
   const GridMeta m = vmeta[c];
   const int i = bx * blockDim.x + threadIdx.x;
   if (i == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
-  if (i >= m.n) return;
+  if (bx * (int)blockDim.x >= m.n) return;  // whole block past the end of the cloud
   const size_t o = (size_t)c * cap;
-  if (!flags[o + i]) return;
+  const bool valid = i < m.n;
+  const bool head = valid && flags[o + i] != 0;
   if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (k_voxel_heads flagged what passes through)
-    out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = in[o + i];
+    if (head) out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = in[o + i];
     return;
   }
-  const uint32_t k = keys[o + i];
-  float4 a = in[o + vals[o + i]];
+  // EVERY lane fetches the point at its sorted position (one gather per lane, all in flight together); a head then adds the
+  // points of the lanes behind it in ascending order, passed along by lane shuffles.  The loop runs as long as any head of the
+  // wave still has run left inside the wave (a run is ~4 points); a run that leaves the wave is finished from memory.
+  const int lane = lane_id();
+  const uint32_t k = valid ? keys[o + i] : 0xFFFFFFFEu;  // (no voxel index is that large: the overflow test bounds it by INT_MAX)
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) a = in[o + vals[o + i]];
+  const float4 mine = a;
   int cnt = 1;
-  for (int j = i + 1; j < m.n; j += 4) {
-    uint32_t kk[4];
-    float4 p[4];
+  bool open = head;  // still collecting
+  for (int d = 1; d < kWave; d++) {
+    const uint32_t kk = __shfl_down(k, d, kWave);
+    const float px = __shfl_down(mine.x, d, kWave), py = __shfl_down(mine.y, d, kWave), pz = __shfl_down(mine.z, d, kWave),
+                pw = __shfl_down(mine.w, d, kWave);
+    const bool in_wave = lane + d < kWave;
+    const bool take = open && in_wave && kk == k;
+    if (take) { a.x += px; a.y += py; a.z += pz; a.w += pw; cnt++; }
+    open = take || (open && !in_wave);  // a run that reaches the end of the wave stays open for the memory walk below
+    if (!__any(open && in_wave)) break;
+  }
+  if (!head) return;
+  if (open) {  // the run continues past this wave's 64 points
+    for (int j = i + (kWave - lane); j < m.n; j += 4) {
+      uint32_t kk[4];
+      float4 p[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int jj = min(j + u, m.n - 1);
-      kk[u] = (j + u < m.n) ? keys[o + jj] : ~k;
-      p[u] = in[o + vals[o + jj]];
-    }
-    bool more = true;
+      for (int u = 0; u < 4; u++) {
+        const int jj = min(j + u, m.n - 1);
+        kk[u] = (j + u < m.n) ? keys[o + jj] : ~k;
+        p[u] = in[o + vals[o + jj]];
+      }
+      bool more = true;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      more = more && (kk[u] == k);
-      if (more) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; cnt++; }
+      for (int u = 0; u < 4; u++) {
+        more = more && (kk[u] == k);
+        if (more) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; cnt++; }
+      }
+      if (!more) break;
     }
-    if (!more) break;
   }
   const float fc = (float)cnt;
   out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc);
