@@ -19,7 +19,7 @@ NOTES = {
     "k_gicp_correspond_tile": "F3 for the first two iterations, when every point moves: 64-point tiles, packed distance/ordinal keys",
     "k_knn_hard": "the 1.0 % of the points the tiles hand over (far field, ties), one wave per query",
     "sort_pairs(k_sort_*)": "in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
-    "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order), head thread walks its run 4 loads deep",
+    "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order): one gather per lane, runs handed to their head lane by shuffles",
     "k_gicp_linearize": "F4, streaming: 80 algorithmic B per source point",
     "k_gicp_error": "F5: all 10 LM trial costs in one pass",
     "hash_build(k_count_cells,k_table_clear,k_gather_insert)": "multi-level voxel hash sized to the occupied cells",
