@@ -228,7 +228,7 @@ __device__ __forceinline__ NnState lane_search(const GridView& g, float qx, floa
   if (seeded && seed_d2 < 0.36f * g.m.cell * g.m.cell) {
     // close seed: scan the ball a little larger than the seed distance (so that an isolated nearest neighbour still
     // earns a non-zero margin) — a handful of base cells
-    const float r = sqrtf(seed_d2) * 1.25f + 0.02f;
+    const float r = sqrtf(seed_d2) * 1.05f + 0.005f;  // (1.25 d + 2 cm: larger margins, but 3 % more correspondence time over 20 iterations)
     nn.limit = r * r;
     grid_ball_search(g, qx, qy, qz, nn, 2.1f);
     st = NnState{nn.d1, nn.j1, nn.d2nd, nn.limit, true};
