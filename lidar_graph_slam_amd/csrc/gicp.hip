@@ -351,6 +351,231 @@ __device__ __forceinline__ NnState coop_search(const GridView& g, float qx, floa
   return st;
 }
 
+// ---- a handful of pairs (the odometry stream: ONE scan against a 3 x 10^5-point sub-map) --------------------------------------
+// 16 k queries are 256 waves: the chip is mostly idle and every wave runs as long as its slowest lane's walk through cells that
+// hold 30+ points each — a chain of dependent loads.  Here a query gets an aligned GROUP of 8 lanes: the cells of the cube around
+// its ball are probed 8 at a time, their points scanned 8 at a time, the eight partial results merged by lane exchanges.  Eight
+// times the waves, walks an eighth as long.  The ball comes from a seed — the previous correspondent, or any point of the finest
+// occupied cell that holds the query — so it contains the nearest neighbour by construction; in margin mode it is the same
+// 1.05 d + 5 mm ball the per-lane search explores around a close seed.  Control flow is wave-uniform (loops run while ANY group
+// has work) so that the lane exchanges always find their partners active.
+constexpr int kGroupW = 8;
+constexpr int kGroupSlots = 8;  // cells per lane: 64 cells of the cube around the ball per query
+
+__device__ __forceinline__ float group_min_f(float v) {
+#pragma unroll
+  for (int off = 1; off < kGroupW; off <<= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+__device__ __forceinline__ int group_min_i(int v) {
+#pragma unroll
+  for (int off = 1; off < kGroupW; off <<= 1) v = min(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+// valid, q, jprev: the same in the lanes of a group.  complete == false: the cube needs more than 64 cells even at the top level
+// (it cannot for a finite reach); the caller searches such a query per lane.
+__device__ __forceinline__ NnState group_search(const GridView& g, bool valid, float qx, float qy, float qz, int jprev, float max_corr_d2,
+                                                bool track_margin) {
+  const GridMeta& m = g.m;
+  const int lane = lane_id(), sub = lane & (kGroupW - 1), gbase = lane & ~(kGroupW - 1);
+  NnState out{INFINITY, -1, INFINITY, 0.f, true};
+  if (m.n <= 0) {
+    out.explored2 = INFINITY;
+    return out;
+  }
+  auto base_cell = [&](float v, float o, int d) { return min(max((int)floorf(cell_coord(v, o, m.inv_cell)), 0), d - 1); };
+  // ---- a seed: the previous correspondent, else a few points of the finest occupied cell around the query
+  float seed_d2 = INFINITY;
+  if (valid && jprev >= 0 && jprev < m.n) {
+    const float4 pp = g.pts[jprev];
+    seed_d2 = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
+  }
+  {
+    bool need = valid && !(seed_d2 < INFINITY);
+    const int bx = base_cell(qx, m.ox, m.dx), by = base_cell(qy, m.oy, m.dy), bz = base_cell(qz, m.oz, m.dz);
+    for (int l = 0; l <= m.top_level; l++) {
+      if (!__any(need)) break;
+      int s0 = 0, e0 = 0;
+      if (need && !cell_range(g, ((uint32_t)l << 27) | morton27((uint32_t)(bx >> l), (uint32_t)(by >> l), (uint32_t)(bz >> l)), s0, e0)) s0 = e0 = 0;
+      e0 = min(e0, s0 + 4 * kGroupW);  // any point will do as a seed
+      float best = INFINITY;
+      for (int j = s0 + sub; __any(j < e0); j += kGroupW)
+        if (j < e0) {
+          const float4 pp = g.pts[j];
+          best = fminf(best, dist2f(qx, qy, qz, pp.x, pp.y, pp.z));
+        }
+      best = group_min_f(best);
+      if (need && best < INFINITY) {
+        seed_d2 = best;
+        need = false;
+      }
+    }
+  }
+  // ---- the ball
+  const float limit2 = track_margin ? search_reach2(g, max_corr_d2, true) : max_corr_d2;
+  float R2 = limit2;
+  if (seed_d2 < limit2) {
+    if (track_margin) {
+      const float r = sqrtf(seed_d2) * 1.05f + 0.005f;  // as lane_search around a close seed: an isolated neighbour still earns a margin
+      R2 = fminf(r * r, limit2);
+    } else {
+      R2 = seed_d2 * (1.f + 4e-6f) + 1e-12f;
+    }
+  }
+  // ---- the cells of the cube around the ball, at the finest level that needs at most 64 of them; lane `sub` owns cells sub, sub + 8, ...
+  const float R = sqrtf(R2) * (1.f + 1e-5f) + 1e-5f;
+  const int x0 = base_cell(qx - R, m.ox, m.dx), x1 = base_cell(qx + R, m.ox, m.dx);
+  const int y0 = base_cell(qy - R, m.oy, m.dy), y1 = base_cell(qy + R, m.oy, m.dy);
+  const int z0 = base_cell(qz - R, m.oz, m.dz), z1 = base_cell(qz + R, m.oz, m.dz);
+  int L = 0;
+  auto count = [&](int l) { return ((x1 >> l) - (x0 >> l) + 1) * ((y1 >> l) - (y0 >> l) + 1) * ((z1 >> l) - (z0 >> l) + 1); };
+  while (L < m.top_level && count(L) > kGroupW * kGroupSlots) L++;
+  const int cx0 = x0 >> L, cy0 = y0 >> L, cz0 = z0 >> L;
+  const int sx = (x1 >> L) - cx0 + 1, sy = (y1 >> L) - cy0 + 1, sz = (z1 >> L) - cz0 + 1;
+  const int nc = sx * sy * sz;
+  const bool fits = isfinite(R2) && nc <= kGroupW * kGroupSlots;
+  const float cell = m.cell * (float)(1 << L);
+  int cs[kGroupSlots], ce[kGroupSlots];
+  {
+    uint32_t key[kGroupSlots];
+    int4 sl[kGroupSlots];
+    bool want[kGroupSlots];
+#pragma unroll
+    for (int t = 0; t < kGroupSlots; t++) {
+      const int ci = t * kGroupW + sub;
+      want[t] = false;
+      key[t] = 0;
+      cs[t] = ce[t] = 0;
+      if (valid && fits && ci < nc) {
+        const int ix = cx0 + ci % sx, iy = cy0 + (ci / sx) % sy, iz = cz0 + ci / (sx * sy);
+        const float lx = m.ox + (float)ix * cell, ly = m.oy + (float)iy * cell, lz = m.oz + (float)iz * cell;
+        const float gx = fmaxf(fmaxf(lx - qx, qx - (lx + cell)), 0.f), gy = fmaxf(fmaxf(ly - qy, qy - (ly + cell)), 0.f),
+                    gz = fmaxf(fmaxf(lz - qz, qz - (lz + cell)), 0.f);
+        const float lb = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz) - 1.0e-3f * cell, 0.f);
+        const bool edge = ix == 0 || iy == 0 || iz == 0 || ix == ((m.dx - 1) >> L) || iy == ((m.dy - 1) >> L) || iz == ((m.dz - 1) >> L);
+        want[t] = edge || lb * lb <= R2;  // (border cells also hold the points the clamping put there)
+        key[t] = ((uint32_t)L << 27) | morton27((uint32_t)ix, (uint32_t)iy, (uint32_t)iz);
+      }
+      if (want[t]) sl[t] = first_slot(g, key[t]);  // the probes of a lane are independent: all in flight together
+    }
+#pragma unroll
+    for (int t = 0; t < kGroupSlots; t++)
+      if (want[t]) {
+        int s0, e0;
+        if (resolve_range(g, key[t], sl[t], s0, e0)) { cs[t] = s0; ce[t] = e0; }
+      }
+  }
+  // ---- scan: every cell by the whole group, 8 points per step, two steps in flight
+  float d1 = INFINITY, d2nd = INFINITY;
+  int j1 = -1;
+#pragma unroll
+  for (int t = 0; t < kGroupSlots; t++) {
+#pragma unroll
+    for (int own = 0; own < kGroupW; own++) {
+      const int s0 = __shfl(cs[t], gbase + own, kWave), e0 = __shfl(ce[t], gbase + own, kWave);
+      if (!__any(e0 > s0)) continue;
+      for (int j = s0 + sub; __any(j < e0); j += 2 * kGroupW) {
+        const bool in0 = j < e0, in1 = j + kGroupW < e0;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        if (in0) p0 = g.pts[j];
+        if (in1) p1 = g.pts[j + kGroupW];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const float4 pp = u ? p1 : p0;
+          const int jj = j + u * kGroupW;
+          const float dd = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
+          if ((u ? in1 : in0) && dd <= R2) {
+            if (j1 < 0 || dd < d1 || (dd == d1 && g.orig[jj] < g.orig[j1])) {
+              if (j1 >= 0) d2nd = fminf(d2nd, d1);
+              d1 = dd;
+              j1 = jj;
+            } else if (dd < d2nd) {
+              d2nd = dd;
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- merge the eight partial results: the nearest (ties: lowest caller index), its runner-up = the best of everything else
+  const float best = group_min_f(d1);
+  out.explored2 = R2;
+  out.complete = fits;
+  if (best < INFINITY) {
+    const int oc = group_min_i((d1 == best && j1 >= 0) ? g.orig[j1] : 0x7fffffff);
+    const bool win = d1 == best && j1 >= 0 && g.orig[j1] == oc;
+    const int wl = __builtin_ctzll((__ballot(win) >> gbase) & ((1ull << kGroupW) - 1ull)) & (kGroupW - 1);
+    out.d1 = best;
+    out.j1 = __shfl(j1, gbase + wl, kWave);
+    out.d2nd = group_min_f(sub == wl ? d2nd : d1);
+  }
+  return out;
+}
+
+template <int kTile>
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond_group(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
+                                                                      const float4* __restrict__ tpts, const int* __restrict__ torig,
+                                                                      const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta,
+                                                                      size_t tcap, size_t tslots, const int* __restrict__ tgt_of_src,
+                                                                      const GicpPairState* __restrict__ state, int* __restrict__ corr,
+                                                                      float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
+                                                                      double margin_step) {
+  __shared__ int queue[kTile];
+  __shared__ int qcount;
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
+  const GicpPairState* st = state + pair;
+  if (!st->active) return;
+  const bool track_margin = st->last_step < margin_step;
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
+  const int n = scount[pair];
+  const Pose x0 = st->x0;
+  float Tf[12];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) Tf[4 * r + c] = (float)x0.R[3 * r + c];
+    Tf[4 * r + 3] = (float)x0.t[r];
+  }
+  const size_t so = (size_t)pair * scap;
+  constexpr int kQueriesPerRound = kGicpBlock / kGroupW;
+  for (int base = bx * kTile; base < n; base += G * kTile) {
+    if (threadIdx.x == 0) qcount = 0;
+    __syncthreads();
+    for (int u = threadIdx.x; u < kTile; u += kGicpBlock) {  // phase 1 of k_gicp_correspond: who needs a search?
+      const int i = base + u;
+      if (i >= n) continue;
+      const float4 p = spts[so + i];
+      const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+      const float4 qs = qsearch[so + i];
+      if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) corr[so + i] = -1;
+      else if (!(sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z)) < qs.w)) queue[atomicAdd(&qcount, 1)] = i;
+    }
+    __syncthreads();
+    const int nq = qcount;
+    for (int t0 = 0; t0 < nq; t0 += kQueriesPerRound) {
+      const int tq = t0 + (int)threadIdx.x / kGroupW;
+      const bool valid = tq < nq;
+      const int i = valid ? queue[tq] : 0;
+      const float4 p = spts[so + i];
+      const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+      NnState stq = group_search(g, valid, qx, qy, qz, valid ? corr[so + i] : -1, max_corr_d2, track_margin);
+      // (a cube that does not fit 64 cells: one lane of the group walks the hash as k_gicp_correspond would)
+      const bool lone = valid && !stq.complete && (threadIdx.x & (kGroupW - 1)) == 0;
+      if (lone) stq = lane_search(g, qx, qy, qz, corr[so + i], max_corr_d2, true);
+      if (valid && (threadIdx.x & (kGroupW - 1)) == 0) {
+        int j;
+        float margin;
+        finish_search(stq, max_corr_d2, track_margin || lone, j, margin);
+        corr[so + i] = j;
+        qsearch[so + i] = make_float4(qx, qy, qz, margin);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // F3 update_correspondences, incremental and exact.  PPT = points per thread and pass (tile = 256 * PPT points).
 template <int kLinPointsPerThread>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_correspond(const float4* __restrict__ spts,
@@ -1042,17 +1267,19 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
   return P;
 }
 
-// tile_search: -1 = by iteration and batch size, 0 / 1 = never / always (gicp_linearize_once)
+// search: -1 = by iteration and batch size; gicp_linearize_once forces 0 = per-lane walks only, 1 = tiles (+ per-lane leftovers),
+// 2 = 8-lane groups
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P, int iteration,
-                             int tile_search = -1) {
+                             int search = -1) {
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
   const int lin_ppt = tuning().lin_ppt;
   auto kl = lin_ppt == 1 ? k_gicp_linearize<1> : (lin_ppt == 2 ? k_gicp_linearize<2> : k_gicp_linearize<4>);
   {
     const Tuning& tn = tuning();
-    // a handful of pairs cannot fill the chip with tiles: their few hundred waves would each wait out their own gathers, and a
-    // lone pair is usually a scan against a dense multi-key-frame sub-map, where the per-lane walk wins anyway
-    const bool tiles = tile_search >= 0 ? tile_search != 0 : (iteration < tn.corr_tiles && gb.S >= 8);
+    // a handful of pairs cannot fill the chip with tiles (their few hundred waves would each wait out their own gathers, and a
+    // lone pair is usually a scan against a dense multi-key-frame sub-map): they get 8 lanes per query instead
+    const bool tiles = search >= 0 ? search == 1 : (iteration < tn.corr_tiles && gb.S >= 8);
+    const bool groups = search >= 0 ? search == 2 : (gb.S < 8 && tn.corr_groups != 0);
     if (tiles) {
       TimedLaunch tl(KF_CORRESPOND_TILE, s);
       hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
@@ -1060,9 +1287,17 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
                          gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p, (double)tn.margin_step);
     }
     TimedLaunch tl(KF_CORRESPOND, s);
-    hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
-                       tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                       gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step);
+    if (groups && isfinite(P.max_corr_d2)) {
+      constexpr int kTile = 64;
+      const int Gg = std::max(1, std::min(1024, div_up((long)gb.cap, kTile)));
+      hipLaunchKernelGGL(k_gicp_correspond_group<kTile>, dim3(xcd_grid(Gg, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p,
+                         tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p,
+                         P.max_corr_d2, Gg, gb.S, (double)tn.margin_step);
+    } else {
+      hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
+                         tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
+                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step);
+    }
   }
   TimedLaunch tl(KF_LINEARIZE, s);
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
@@ -1248,27 +1483,27 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
   GicpDevParams P = dev_params(p);
   P.optimizer = MI355_OPT_LM;
-  // this entry point exists for the parity tests: run BOTH correspondence searches from scratch (the per-lane walk first, then
-  // the tile kernel as iteration 0 of an alignment does) and insist that they agree, so that the caller's comparison with the
-  // oracle pins both
-  std::vector<int> lane_corr;
-  if (tuning().corr_tiles) {
-    launch_linearize(s, gb, src, tgt, P, 0, /*tile_search=*/0);
-    lane_corr.resize(gb.cap);
-    MI_HIP(hipMemcpyAsync(lane_corr.data(), gb.corr.p, gb.cap * sizeof(int), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
+  // this entry point exists for the parity tests: run ALL THREE correspondence searches from scratch — the per-lane walk, the
+  // 8-lane groups (what a lone pair gets in an alignment), the tile kernel (what iteration 0 of a batch gets) — and insist that
+  // they agree, so that the caller's comparison with the oracle pins all of them
+  std::vector<int> first;
+  for (int search = 0; search <= 2; search++) {
+    if ((search == 1 && !tuning().corr_tiles) || (search == 2 && !tuning().corr_groups)) continue;
     MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, gb.cap * sizeof(int), s));
     MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
-  }
-  launch_linearize(s, gb, src, tgt, P, 0, /*tile_search=*/tuning().corr_tiles ? 1 : 0);
-  if (!lane_corr.empty()) {
-    std::vector<int> tile_corr(gb.cap);
+    launch_linearize(s, gb, src, tgt, P, 0, search);
+    std::vector<int> got(gb.cap);
     int ns = 0;
-    MI_HIP(hipMemcpyAsync(tile_corr.data(), gb.corr.p, gb.cap * sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipMemcpyAsync(got.data(), gb.corr.p, gb.cap * sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipMemcpyAsync(&ns, src.count.p, sizeof(int), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
+    if (first.empty()) {
+      first.swap(got);
+      continue;
+    }
     for (int i = 0; i < ns; i++)
-      if (tile_corr[(size_t)i] != lane_corr[(size_t)i]) throw ArgError(MI355_ESTATE, "tile and per-lane correspondence searches disagree");
+      if (got[(size_t)i] != first[(size_t)i])
+        throw ArgError(MI355_ESTATE, search == 1 ? "tile and per-lane correspondence searches disagree" : "group and per-lane correspondence searches disagree");
   }
   hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P);
   MI_LAUNCH_CHECK();
