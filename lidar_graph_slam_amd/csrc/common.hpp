@@ -87,7 +87,7 @@ struct Tuning {
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
   int corr_tiles = 2;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)
-  int corr_groups = 1;        // MI355_CORR_GROUPS       0 = per-lane correspondence search also for batches of < 8 pairs (no 8-lane groups)
+  int corr_groups = 1;        // MI355_CORR_GROUPS       0 = per-lane correspondence search also for batches of < 8 pairs (no lane groups)
   float margin_step = 0.03f;  // MI355_MARGIN_STEP       a pair tracks search margins once its last accepted step moved it by less than this (m at a 50 m lever arm)
   int corr_stats = 0;         // MI355_CORR_STATS        1 = count what the correspondence tiles scan, print after every align
   int knn_stats = 0;          // MI355_KNN_STATS         1 = after every covariance launch, synchronise and print to stderr how many

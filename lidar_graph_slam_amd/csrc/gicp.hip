@@ -353,14 +353,14 @@ __device__ __forceinline__ NnState coop_search(const GridView& g, float qx, floa
 
 // ---- a handful of pairs (the odometry stream: ONE scan against a 3 x 10^5-point sub-map) --------------------------------------
 // 16 k queries are 256 waves: the chip is mostly idle and every wave runs as long as its slowest lane's walk through cells that
-// hold 30+ points each — a chain of dependent loads.  Here a query gets an aligned GROUP of 8 lanes: the cells of the cube around
-// its ball are probed 8 at a time, their points scanned 8 at a time, the eight partial results merged by lane exchanges.  Eight
-// times the waves, walks an eighth as long.  The ball comes from a seed — the previous correspondent, or any point of the finest
+// hold 30+ points each — a chain of dependent loads.  Here a query gets an aligned GROUP of lanes: the cells of the cube around
+// its ball are probed kGroupW at a time, their points scanned kGroupW at a time, the partial results merged by lane exchanges:
+// more waves, shorter walks.  The ball comes from a seed — the previous correspondent, or any point of the finest
 // occupied cell that holds the query — so it contains the nearest neighbour by construction; in margin mode it is the same
 // 1.05 d + 5 mm ball the per-lane search explores around a close seed.  Control flow is wave-uniform (loops run while ANY group
 // has work) so that the lane exchanges always find their partners active.
-constexpr int kGroupW = 8;
-constexpr int kGroupSlots = 8;  // cells per lane: 64 cells of the cube around the ball per query
+constexpr int kGroupW = 32;  // measured on the 60-scan stream: 4 lanes 2.9 ms per scan, 8: 2.45, 16: 2.25, 32: 2.10, 64: 2.17 (per-lane walks: 4.25)
+constexpr int kGroupSlots = 64 / kGroupW;  // cells per lane: 64 cells of the cube around the ball per query
 
 __device__ __forceinline__ float group_min_f(float v) {
 #pragma unroll
@@ -423,7 +423,7 @@ __device__ __forceinline__ NnState group_search(const GridView& g, bool valid, f
       R2 = seed_d2 * (1.f + 4e-6f) + 1e-12f;
     }
   }
-  // ---- the cells of the cube around the ball, at the finest level that needs at most 64 of them; lane `sub` owns cells sub, sub + 8, ...
+  // ---- the cells of the cube around the ball, at the finest level that needs at most 64 of them; lane `sub` owns cells sub, sub + kGroupW, ...
   const float R = sqrtf(R2) * (1.f + 1e-5f) + 1e-5f;
   const int x0 = base_cell(qx - R, m.ox, m.dx), x1 = base_cell(qx + R, m.ox, m.dx);
   const int y0 = base_cell(qy - R, m.oy, m.dy), y1 = base_cell(qy + R, m.oy, m.dy);
@@ -466,7 +466,7 @@ __device__ __forceinline__ NnState group_search(const GridView& g, bool valid, f
         if (resolve_range(g, key[t], sl[t], s0, e0)) { cs[t] = s0; ce[t] = e0; }
       }
   }
-  // ---- scan: every cell by the whole group, 8 points per step, two steps in flight
+  // ---- scan: every cell by the whole group, kGroupW points per step, two steps in flight
   float d1 = INFINITY, d2nd = INFINITY;
   int j1 = -1;
 #pragma unroll
@@ -498,14 +498,15 @@ __device__ __forceinline__ NnState group_search(const GridView& g, bool valid, f
       }
     }
   }
-  // ---- merge the eight partial results: the nearest (ties: lowest caller index), its runner-up = the best of everything else
+  // ---- merge the partial results of the lanes: the nearest (ties: lowest caller index), its runner-up = the best of everything else
   const float best = group_min_f(d1);
   out.explored2 = R2;
   out.complete = fits;
   if (best < INFINITY) {
     const int oc = group_min_i((d1 == best && j1 >= 0) ? g.orig[j1] : 0x7fffffff);
     const bool win = d1 == best && j1 >= 0 && g.orig[j1] == oc;
-    const int wl = __builtin_ctzll((__ballot(win) >> gbase) & ((1ull << kGroupW) - 1ull)) & (kGroupW - 1);
+    constexpr unsigned long long kGroupMask = kGroupW >= 64 ? ~0ull : ((1ull << (kGroupW & 63)) - 1ull);
+    const int wl = __builtin_ctzll((__ballot(win) >> gbase) & kGroupMask) & (kGroupW - 1);
     out.d1 = best;
     out.j1 = __shfl(j1, gbase + wl, kWave);
     out.d2nd = group_min_f(sub == wl ? d2nd : d1);
@@ -1268,7 +1269,7 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
 }
 
 // search: -1 = by iteration and batch size; gicp_linearize_once forces 0 = per-lane walks only, 1 = tiles (+ per-lane leftovers),
-// 2 = 8-lane groups
+// 2 = lane groups
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P, int iteration,
                              int search = -1) {
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
@@ -1277,7 +1278,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
   {
     const Tuning& tn = tuning();
     // a handful of pairs cannot fill the chip with tiles (their few hundred waves would each wait out their own gathers, and a
-    // lone pair is usually a scan against a dense multi-key-frame sub-map): they get 8 lanes per query instead
+    // lone pair is usually a scan against a dense multi-key-frame sub-map): they get a group of lanes per query instead
     const bool tiles = search >= 0 ? search == 1 : (iteration < tn.corr_tiles && gb.S >= 8);
     const bool groups = search >= 0 ? search == 2 : (gb.S < 8 && tn.corr_groups != 0);
     if (tiles) {
@@ -1484,7 +1485,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   GicpDevParams P = dev_params(p);
   P.optimizer = MI355_OPT_LM;
   // this entry point exists for the parity tests: run ALL THREE correspondence searches from scratch — the per-lane walk, the
-  // 8-lane groups (what a lone pair gets in an alignment), the tile kernel (what iteration 0 of a batch gets) — and insist that
+  // lane groups (what a lone pair gets in an alignment), the tile kernel (what iteration 0 of a batch gets) — and insist that
   // they agree, so that the caller's comparison with the oracle pins all of them
   std::vector<int> first;
   for (int search = 0; search <= 2; search++) {
