@@ -110,7 +110,7 @@ durations of the kernels overlap (their sum exceeds the step); the isolated colu
 | `--pairs 128` | {p128['value']:.0f} pairs/s |
 | `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |
 | CPU oracle on the same host ({cpu['cpu_model']}, {cpu['host_hw_threads']} hardware threads) | {by_threads} pairs/s; `cpu_baseline.value` is the {cpu['cores']}-thread figure, 4 threads is the reference's configuration (`lidar_scan_matcher.param.yaml:10`) |
-| GPU vs CPU pose of the same world-transformed pair | {cpu['gpu_vs_cpu_pose_dt_m'] * 1e3:.4f} mm / {cpu['gpu_vs_cpu_pose_dr_rad']:.1e} rad (bench.py aborts above 1 mm / 1e-4 rad) |
+| GPU vs CPU pose of the same world-transformed pair | {cpu['gpu_vs_cpu_pose_dt_m'] * 1e9:.0f} nm / {cpu['gpu_vs_cpu_pose_dr_rad']:.1e} rad (bench.py aborts above 1 mm / 1e-4 rad) |
 | config 2, one 64 k pair (18 k / 20 k points after the voxel grid) | {ocj['config2_single_pair']['ms_median']:.2f} ms per align |
 | config 3, NDT: 65 k-point scan vs 1.05 M-point sub-map, 1.0 m cells | target build {ocj['config3_ndt_1M_submap']['set_target_ms']:.1f} ms, align {ocj['config3_ndt_1M_submap']['align_ms_median']:.2f} ms ({ocj['config3_ndt_1M_submap']['iterations']} iterations) |
 | config 4, 200-scan stream, window 20, FAST_GICP, key-frame covariances carried (C' = R C Rᵀ) | {ocj['config4_stream_FAST_GICP']['ms_per_scan']:.2f} ms/scan, end pose {ocj['config4_stream_FAST_GICP']['end_pose_err_vs_truth'][0]:.2f} m off after 160 m |
