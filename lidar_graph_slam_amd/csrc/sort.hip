@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
 void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes) {
   TimedLaunch tl(KF_SORT, s);
   const int max_tiles = div_up((long)cap, kTsTile);
-  if (max_tiles <= 4) {
+  if (max_tiles <= 64) {  // up to 1.5 M elements per segment: log2(tiles) merge rounds still move less than 4 global passes
     // tile sort a -> b, then ceil(log2(max_tiles)) merge rounds ping-ponging; an odd number of hops ends in b: swap the handles
     int hops = 1;
     for (int run = 1; run < max_tiles; run *= 2) hops++;
