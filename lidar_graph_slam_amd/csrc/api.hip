@@ -107,6 +107,8 @@ struct mi355_reg {
   IcpScratch icp;
   mi355_gicp_bfgs_params bp;  // MI355_METHOD_GICP
   BfgsScratch bfgs;
+  // NDT (and, for the source, ICP) register without the voxel hash of the cloud; only getFitnessScore needs it: built on demand
+  bool src_grid_stale = false, tgt_grid_stale = false;
   Workspace ws;
   Uploader up;
   DevBuf<float4> stage_src, stage_tgt;
@@ -619,9 +621,8 @@ extern "C" int mi355_reg_set_target(mi355_reg* reg, const mi355_cloud_view* clou
       build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
     } else {
       ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
-      // getFitnessScore needs the NN structure of the target as well
       reg->tgt.alloc(1, reg->n_tgt);
-      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+      reg->tgt_grid_stale = true;  // getFitnessScore needs the NN structure of the target as well: mi355_reg_fitness builds it
     }
     reg->has_tgt = true;
   });
@@ -637,7 +638,8 @@ extern "C" int mi355_reg_set_source(mi355_reg* reg, const mi355_cloud_view* clou
     reg->aligned = false;
     if (reg->n_src == 0) throw ArgError(MI355_EINVAL, "empty source cloud");
     reg->src.alloc(1, reg->n_src);
-    build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
+    reg->src_grid_stale = !needs_covariances(reg->method);
+    if (!reg->src_grid_stale) build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
     if (needs_covariances(reg->method)) {
       if ((size_t)reg->gp.k_correspondences > reg->n_src) throw ArgError(MI355_EINVAL, "source has fewer points than k_correspondences");
       compute_covariances(ctx->stream, reg->src, reg->gp.k_correspondences, reg->gp.regularization_method);
@@ -699,6 +701,14 @@ extern "C" int mi355_reg_fitness(mi355_reg* reg, double max_range, double* score
   mi355_ctx* ctx = reg->ctx;
   return guarded(ctx, [&] {
     reg_require(reg);
+    if (reg->src_grid_stale) {
+      build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
+      reg->src_grid_stale = false;
+    }
+    if (reg->tgt_grid_stale) {
+      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+      reg->tgt_grid_stale = false;
+    }
     const int zero = 0;
     MI_HIP(hipMemcpyAsync(reg->gb.tgt_of_src.p, &zero, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
@@ -993,7 +1003,8 @@ extern "C" int mi355_reg_set_source_cloud(mi355_reg* reg, mi355_cloud* cloud) {
     reg->aligned = false;
     if (reg->n_src == 0) throw ArgError(MI355_EINVAL, "empty source cloud");
     reg->src.alloc(1, reg->n_src);
-    build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
+    reg->src_grid_stale = !needs_covariances(reg->method);
+    if (!reg->src_grid_stale) build_grid(ctx->stream, reg->ws, reg->stage_src.p, reg->cnt_src.p, reg->src, ctx->grid_cell);
     if (needs_covariances(reg->method)) {
       if ((size_t)reg->gp.k_correspondences > reg->n_src) throw ArgError(MI355_EINVAL, "source has fewer points than k_correspondences");
       const bool cached = cloud->has_cov && cloud->cov_k == reg->gp.k_correspondences && cloud->cov_method == reg->gp.regularization_method;
@@ -1035,7 +1046,7 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
     } else {
       ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
       reg->tgt.alloc(1, reg->n_tgt);
-      build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
+      reg->tgt_grid_stale = true;
     }
     reg->has_tgt = true;
   });
