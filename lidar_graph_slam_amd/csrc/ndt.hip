@@ -51,6 +51,7 @@ struct NdtTarget {
   DevBuf<float4> trans;
   DevBuf<double> partials;
   DevBuf<double> sums;
+  DevBuf<int> done;  // blocks of the current request that have finished (ndt_last_block_reduce re-arms it)
   PinnedBuf<double> h_sums;
   int blocks = 0;
 };
@@ -312,6 +313,26 @@ __device__ __forceinline__ int ndt_neighbors7(const HashSlot* table, const NdtGr
 }
 
 // computeDerivatives with ndt_omp's fp32 per-point maths (N3).
+// One pair: the block that finishes LAST adds the block partials, in block order (the order the batch path's
+// k_ndt_batch_advance uses), and re-arms the counter — one launch and one 224-byte read-back per request instead of two launches.
+__device__ __forceinline__ void ndt_last_block_reduce(const double* partials, int* done, double* __restrict__ sums) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __threadfence();  // this block's partials are visible before the count says so
+    is_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  const volatile double* p = partials;
+  if (threadIdx.x < kNdtAcc) {
+    double sacc = 0;
+    for (int gidx = 0; gidx < (int)gridDim.x; gidx++) sacc += p[(size_t)gidx * 32 + threadIdx.x];
+    sums[threadIdx.x] = sacc;
+  }
+  if (threadIdx.x == 0) *done = 0;
+}
+
 // Block `block` of `nblocks` strides over the n source points; its 28 sums go to partials_row[0..27].  The single-pair
 // kernel and the batch kernel (pair state in HBM) share this body, so a pair gets the same sums either way.
 __device__ __forceinline__ void ndt_derivatives_body(const float4* __restrict__ src, int n, const NdtLeafF* __restrict__ leaves,
@@ -392,10 +413,12 @@ __device__ __forceinline__ void ndt_derivatives_body(const float4* __restrict__ 
 
 __global__ __launch_bounds__(kNdtBlock) void k_ndt_derivatives(const float4* __restrict__ src, int n, const NdtLeafF* __restrict__ leaves,
                                                                const HashSlot* __restrict__ table, const NdtGridMeta* __restrict__ meta,
-                                                               NdtAngles A, NdtPassParams P, double* __restrict__ partials) {
+                                                               NdtAngles A, NdtPassParams P, double* __restrict__ partials,
+                                                               int* __restrict__ done, double* __restrict__ sums) {
   __shared__ double smem[4 * kNdtAcc];
   const NdtGridMeta m = *meta;
   ndt_derivatives_body(src, n, leaves, table, m, A, P, blockIdx.x, gridDim.x, partials + (size_t)blockIdx.x * 32, smem);
+  ndt_last_block_reduce(partials, done, sums);
 }
 
 // computeHessian / updateHessian: fp64 per-point maths.
@@ -469,19 +492,14 @@ __device__ __forceinline__ void ndt_hessian64_body(const float4* __restrict__ sr
 
 __global__ __launch_bounds__(kNdtBlock) void k_ndt_hessian64(const float4* __restrict__ src, int n, const NdtLeafD* __restrict__ leaves,
                                                              const HashSlot* __restrict__ table, const NdtGridMeta* __restrict__ meta, NdtAngles A,
-                                                             NdtPassParams P, double* __restrict__ partials) {
+                                                             NdtPassParams P, double* __restrict__ partials, int* __restrict__ done,
+                                                             double* __restrict__ sums) {
   __shared__ double smem[4 * kNdtAcc];
   const NdtGridMeta m = *meta;
   ndt_hessian64_body(src, n, leaves, table, m, A, P, blockIdx.x, gridDim.x, partials + (size_t)blockIdx.x * 32, smem);
+  ndt_last_block_reduce(partials, done, sums);
 }
 
-__global__ __launch_bounds__(64) void k_ndt_reduce(const double* __restrict__ partials, int G, double* __restrict__ sums) {
-  const int l = threadIdx.x;
-  if (l >= kNdtAcc) return;
-  double s = 0;
-  for (int g = 0; g < G; g++) s += partials[(size_t)g * 32 + l];
-  sums[l] = s;
-}
 
 
 // ---- executors of the ndt_mt.hpp state machine (N2, N4) ---------------------------------------------------------------------
@@ -511,14 +529,19 @@ struct NdtRun {
     t.partials.ensure((size_t)t.blocks * 32);
     t.sums.ensure(32);
     t.h_sums.ensure(32);
+    if (!t.done.p) {
+      t.done.ensure(1);
+      MI_HIP(hipMemsetAsync(t.done.p, 0, sizeof(int), s));
+    }
   }
   const double* answer(int request, const float* T, const NdtAngles& ang) {
     const NdtPassParams P = pass_params(T, c, request == NDT_REQ_DERIV_HESS);
     if (request == NDT_REQ_HESS64)
-      hipLaunchKernelGGL(k_ndt_hessian64, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_d.p, t.table.p, t.meta.p, ang, P, t.partials.p);
+      hipLaunchKernelGGL(k_ndt_hessian64, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_d.p, t.table.p, t.meta.p, ang, P, t.partials.p,
+                         t.done.p, t.sums.p);
     else
-      hipLaunchKernelGGL(k_ndt_derivatives, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_f.p, t.table.p, t.meta.p, ang, P, t.partials.p);
-    hipLaunchKernelGGL(k_ndt_reduce, dim3(1), dim3(64), 0, s, t.partials.p, t.blocks, t.sums.p);
+      hipLaunchKernelGGL(k_ndt_derivatives, dim3(t.blocks), dim3(kNdtBlock), 0, s, src, n, t.leaf_f.p, t.table.p, t.meta.p, ang, P, t.partials.p,
+                         t.done.p, t.sums.p);
     MI_LAUNCH_CHECK();
     MI_HIP(hipMemcpyAsync(t.h_sums.p, t.sums.p, kNdtAcc * sizeof(double), hipMemcpyDeviceToHost, s));
     MI_HIP(hipStreamSynchronize(s));
@@ -672,7 +695,7 @@ __global__ __launch_bounds__(kNdtBlock) void k_ndt_batch_hessian64(const float4*
   ndt_hessian64_body(src + (size_t)pair * src_cap, n, tr.leaf_d, tr.table, m, st.ang, Pp, bx, nb, partials + ((size_t)pair * G + bx) * 32, smem);
 }
 
-// One wave per pair: lanes 0..27 add the pair's block partials in block order (k_ndt_reduce's order), lane 0 advances the
+// One wave per pair: lanes 0..27 add the pair's block partials in block order (the single path's order), lane 0 advances the
 // pair's state machine to its next request.  n_active (optional) counts the pairs still asking.
 __global__ __launch_bounds__(64) void k_ndt_batch_advance(NdtPairState* __restrict__ states, const double* __restrict__ partials, NdtConsts c, int P,
                                                           int G, int* __restrict__ n_active) {
