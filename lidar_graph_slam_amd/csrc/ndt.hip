@@ -106,19 +106,45 @@ __global__ __launch_bounds__(128) void k_ndt_leaves(const float4* __restrict__ p
                                                     int n, int min_points, double eig_mult) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) meta->n_leaves = totals[0];
-  if (i >= n || !flags[i]) return;
-  const int li = local[i] + blockoff[i / kScanTile];
-  const uint32_t key = keys[i];
+  // Every lane fetches the point at its sorted position (one gather per lane, all in flight together); the lane at the head of a
+  // voxel's run then adds the points of the lanes behind it IN ORDER, handed over by lane shuffles, and finishes from memory
+  // whatever of its run lies beyond the wave (a head walking its whole run from memory — 30+ dependent gathers per voxel at
+  // 2 m cells — took 0.57 ms per 3 x 10^5-point target).
+  const int lane = lane_id();
+  const bool valid = i < n;
+  const bool head = valid && flags[i] != 0;
+  const uint32_t key = valid ? keys[i] : 0xFFFFFFFEu;
+  float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) mine = pts[vals[i]];
   double sx = 0, sy = 0, sz = 0;
   Sym3<double> sq = {0, 0, 0, 0, 0, 0};
-  int j = i;
-  for (; j < n && keys[j] == key; j++) {
-    const float4 p = pts[vals[j]];
-    const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  auto add = [&](float fx, float fy, float fz) {
+    const double x = (double)fx, y = (double)fy, z = (double)fz;
     sx += x; sy += y; sz += z;
     sq.xx += x * x; sq.xy += x * y; sq.xz += x * z; sq.yy += y * y; sq.yz += y * z; sq.zz += z * z;
+  };
+  if (head) add(mine.x, mine.y, mine.z);
+  int cnt = head ? 1 : 0;
+  bool open = head;
+  for (int d = 1; d < kWave; d++) {
+    const uint32_t kk = __shfl_down(key, d, kWave);
+    const float px = __shfl_down(mine.x, d, kWave), py = __shfl_down(mine.y, d, kWave), pz = __shfl_down(mine.z, d, kWave);
+    const bool in_wave = lane + d < kWave;
+    const bool take = open && in_wave && kk == key;
+    if (take) { add(px, py, pz); cnt++; }
+    open = take || (open && !in_wave);
+    if (!__any(open && in_wave)) break;
   }
-  const int cnt = j - i;
+  if (!head) return;
+  if (open) {  // the run continues past this wave
+    int j = i + (kWave - lane);
+    for (; j < n && keys[j] == key; j++) {
+      const float4 p = pts[vals[j]];
+      add(p.x, p.y, p.z);
+    }
+    cnt = j - i;
+  }
+  const int li = local[i] + blockoff[i / kScanTile];
   const double nn = (double)cnt;
   NdtLeafD L;
   L.n = cnt;
