@@ -362,7 +362,7 @@ constexpr int kOrdBits = 10;
 constexpr int kTileMaxCand = 768;            // candidates per tile segment (list positions; at most 2^kOrdBits)
 constexpr uint32_t kOrdMask = (1u << kOrdBits) - 1u;
 constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
-constexpr int kSubQ = 16;                    // lanes (queries) per sub-tile (8: 10.9 + 1.8 ms per launch, 16: 10.7 + 1.7 ms, 4: 12.3 + 2.5 ms)
+constexpr int kSubQ = 16;                    // lanes (queries) per sub-tile (8: 10.9 + 1.8 ms per launch, 16: 10.7 + 1.7 ms, 32: 11.2 + 1.7 ms, 4: 12.3 + 2.5 ms)
 constexpr int kNSub = kWave / kSubQ;
 // candidates per sub-tile list.  12 KB tile list + 7.5 KB of sub-lists per wave = 8 waves per CU, the same footprint as
 // the first split (1 024 + 8 x 220): measured at 1 024 clouds, lists that overflow are what sends most points to k_knn_hard —
@@ -565,10 +565,10 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               const unsigned long long mask = __ballot(in[u]);
-              const uint32_t hits = (uint32_t)(mask >> (mysub * kSubQ)) & ((1u << kSubQ) - 1u);
-              const int at = slen + __popc(hits & ((1u << sublane) - 1u));
+              const unsigned long long hits = (mask >> (mysub * kSubQ)) & ((1ull << kSubQ) - 1ull);
+              const int at = slen + __popcll(hits & ((1ull << sublane) - 1ull));
               if (in[u] && at < kSubCap) sub[mysub][at] = (uint16_t)((base + u * kSubQ + sublane) << 4);  // byte offset of the candidate in cand[]
-              slen += __popc(hits);  // may run past kSubCap
+              slen += __popcll(hits);  // may run past kSubCap
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
