@@ -162,11 +162,14 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   uint32_t il[kTsE];  // local index (high half) | rank inside the wave for the current pass (low half)
   // element p of the tile lives in wave p / 1536, round (p % 1536) / 64, lane p % 64; padding sorts to the end (all-ones key,
   // last in the stable order)
+  // (positions as p0 + a constant, bounds as a constant against lim: one register each instead of 24 live positions)
+  const int p0 = w * kTsSpan + l;
+  const int lim = len - p0;  // element r of this lane exists iff r * kWave < lim
+  const uint32_t* kin = keys_in + o + p0;
 #pragma unroll
   for (int r = 0; r < kTsE; r++) {
-    const int p = w * kTsSpan + r * kWave + l;
-    key[r] = (p < len) ? keys_in[o + p] : 0xFFFFFFFFu;
-    il[r] = (uint32_t)p << 16;
+    key[r] = (r * kWave < lim) ? kin[r * kWave] : 0xFFFFFFFFu;
+    il[r] = (uint32_t)(p0 + r * kWave) << 16;
   }
   const unsigned long long lt_mask = (1ull << l) - 1ull;
   // (fully unrolled: carried through a rolled loop the two register arrays become 32-wide vector values that the compiler
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
       if (rank == 0) cnt[w][d] = (uint16_t)(before + __popcll(peers));
       __builtin_amdgcn_wave_barrier();
       il[r] = (il[r] & 0xFFFF0000u) | (uint32_t)(before + rank);
+      asm volatile("" : "+v"(il[r]));  // materialise the rank HERE: deferred, the 64-bit peer masks of all 24 elements stay live (and spill)
     }
     __syncthreads();
     // ---- exclusive scan of the 256 x 16 counters, digit-major: thread t owns digit t / 4, waves 4 (t % 4) .. + 3
@@ -219,6 +223,10 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
     }
     __syncthreads();
     // ---- permute through LDS
+    // (the keys pass through an empty asm: the compiler then recomputes the two-instruction counter address of every element here
+    // instead of keeping the 24 addresses of the rank loop alive across the scan — those were spilled to scratch)
+#pragma unroll
+    for (int r = 0; r < kTsE; r++) asm volatile("" : "+v"(key[r]));
 #pragma unroll
     for (int r = 0; r < kTsE; r++) {
       const int dest = (int)cnt[w][(key[r] >> shift) & 255u] + (int)(il[r] & 0xFFFFu);
@@ -229,19 +237,19 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kTsE; r++) {
-      const int p = w * kTsSpan + r * kWave + l;
-      key[r] = keyL[p];
-      il[r] = (uint32_t)idxL[p] << 16;
+      key[r] = keyL[p0 + r * kWave];
+      il[r] = (uint32_t)idxL[p0 + r * kWave] << 16;
       if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
+  uint32_t* kout = keys_out + o + p0;
+  int* vout = vals_out + o + p0;
 #pragma unroll
   for (int r = 0; r < kTsE; r++) {
-    const int p = w * kTsSpan + r * kWave + l;
-    if (p < len) {
-      keys_out[o + p] = key[r];
-      vals_out[o + p] = base + (int)(il[r] >> 16);
+    if (r * kWave < lim) {
+      kout[r * kWave] = key[r];
+      vout[r * kWave] = base + (int)(il[r] >> 16);
     }
   }
 }
