@@ -369,6 +369,11 @@ constexpr int kNSub = kWave / kSubQ;
 // 220 entries: 2.65 % handed over, tile kernel 11.3 ms + hard 3.9 ms per launch; 476 entries with a 768-entry tile list:
 // 1.08 %, 10.9 ms + 1.8 ms (604 / 640: 1.27 %, 11.1 + 2.0; 348 / 1 024: 1.24 %, 12.4 + 2.0).  (Those with 8-lane sub-tiles; the
 // 16-lane sub-tiles in the tree have 4 lists of 764: 1.01 %.)
+// Occupancy is LDS-bound at 2 waves per SIMD (18 KB per wave).  Measured alternatives that reach 3 waves: a 512-entry tile list
+// with 508-entry sub-lists (12 KB): tile kernel 9.9 ms but 1.68 % handed over, k_knn_hard 2.6 ms — the same sum; sub-lists as
+// per-sub-tile BITMASKS over the 768-entry tile list (12.7 KB, 168 VGPRs): same hand-over, 11.0 ms (11.3 ms with two candidate
+// loads in flight) — walking set bits costs ~10 more VALU instructions per candidate than reading a 16-bit list entry, and the
+// rank loop is VALU-bound, so the extra wave does not pay for it.
 constexpr int kSubCap = 764;
 constexpr int kSubRow = kSubCap + 4;         // row pitch: the 4-way unrolled rank loop may read (and ignore) up to 3 entries past the end
 
