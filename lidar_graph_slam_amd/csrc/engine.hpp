@@ -50,6 +50,7 @@ struct Workspace {
   DevBuf<float> fscratch;
   DevBuf<double> dscratch;
   DevBuf<GridMeta> vmeta;  // voxel-grid meta
+  DevBuf<int> sort_passes;  // [B] radix passes the keys of a segment need (set by k_voxel_meta / k_grid_meta)
 };
 
 struct CloudSet {
@@ -72,7 +73,9 @@ struct CloudSet {
 // ---- sort.hip ------------------------------------------------------------------------------------------------
 // Stable LSD radix sort of (key32, val32) pairs per cloud segment, `passes` x 8 bits from bit 0.
 // Result ends up in (keys_a, vals_a) of the workspace.
-void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes);
+// d_passes (optional, [B] on the device): 8-bit passes segment c really needs (its keys are below 2^(8 d_passes[c]) - 1, or below
+// 2^(8 d_passes[c]) when every segment element carries a real key); honoured by the in-LDS tile path, ignored by the global passes.
+void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes = nullptr);
 // Exclusive scan of ws.flags per cloud: position(i) = ws.scan_local[i] + ws.scan_block[c*nblk + i/1024]; totals[c].
 void scan_flags(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts);
 constexpr int kScanTile = 1024;

@@ -143,7 +143,8 @@ __device__ __forceinline__ void tile_geometry(int n, int& nt, int& tl) {
 // kernels skip it: a voxelised scan costs one launch's worth of traffic, not three.
 __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
                                                           uint32_t* __restrict__ keys_final, int* __restrict__ vals_final,
-                                                          const int* __restrict__ counts, size_t cap, int passes) {
+                                                          const int* __restrict__ counts, size_t cap, int passes_max,
+                                                          const int* __restrict__ seg_passes) {
   __shared__ uint32_t keyL[kTsTile];
   __shared__ uint16_t idxL[kTsTile];
   __shared__ uint16_t cnt[kTsWaves][256];
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   tile_geometry(n, nt, tl);
   if ((int)blockIdx.x >= nt) return;
   if (nt == 1) { keys_out = keys_final; vals_out = vals_final; }
+  const int passes = seg_passes ? min(passes_max, max(1, seg_passes[c])) : passes_max;
   const int base = blockIdx.x * tl;
   const int len = max(0, min(tl, n - base));
   const int w = wave_id(), l = lane_id();
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
 
 // Sorts B segments of (key, index-in-segment) pairs by the low 8 * passes key bits, stably; the result ends up in
 // (keys_a, vals_a) of the workspace.  vals_a on input must be the identity (vals[i] = i) — every caller's is.
-void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes) {
+void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes) {
   TimedLaunch tl(KF_SORT, s);
   const int max_tiles = div_up((long)cap, kTsTile);
   if (max_tiles <= 64) {  // up to 1.5 M elements per segment: log2(tiles) merge rounds still move less than 4 global passes
@@ -336,7 +338,7 @@ void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_co
     for (int run = 1; run < max_tiles; run *= 2) hops++;
     // after `hops` hops (a -> b -> a ...) the result sits in b when hops is odd
     hipLaunchKernelGGL(k_sort_tile, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
-                       (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes);
+                       (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes, d_passes);
     hops = 1;
     uint32_t* ki = ws.keys_b.p; uint32_t* ko = ws.keys_a.p;
     int* vi = ws.vals_b.p; int* vo = ws.vals_a.p;
