@@ -23,6 +23,7 @@ const Tuning& tuning() {
     geti("MI355_CORR_TILES", v.corr_tiles);
     geti("MI355_CORR_STATS", v.corr_stats);
     geti("MI355_CORR_GROUPS", v.corr_groups);
+    geti("MI355_ERR_FIRST", v.err_first);
     getf("MI355_CORR_R1", v.corr_r1);
     getf("MI355_MARGIN_STEP", v.margin_step);
     geti("MI355_BLOCKS_LIN", v.blocks_lin);

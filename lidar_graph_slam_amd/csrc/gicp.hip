@@ -1143,21 +1143,27 @@ __device__ __forceinline__ double point_error(const Pose& x, const float4& p, co
 // so the register budget is the points plus NT accumulators (the first version kept all NT poses in VGPRs: 256 VGPRs +
 // AGPRs, one wave per SIMD, and spent its time waiting on the point loads with nothing to overlap them).
 constexpr int kErrPoints = 2;
+// The kernel is VALU-bound, not memory-bound: the residual and the quadratic form are fp64 without contraction (the oracle's
+// arithmetic) — 94 v_add_f64 / v_mul_f64 + 24 conversions per trial and pair of points, 10 trials: 85 % of its 0.38 ms per
+// 1 024-pair launch is issue time.  LM accepts its FIRST trial far more often than not, so a batch evaluates trial 0 alone
+// (`want` = 1, NT = 1: a streaming pass), k_gicp_decide(phase 0) takes it or marks the pair (need_error = 2), and only the marked
+// pairs pay for trials 1 .. in a second launch (`want` = 2).  Trials [t0, min(t0 + NT, n_trials)) of every pair whose
+// need_error == want.
 template <int NT>
 __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
                                                            const GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
                                                            const int* __restrict__ corr, const Cov6* __restrict__ mahal,
-                                                           double* __restrict__ partials, int n_trials) {
+                                                           double* __restrict__ partials, int t0, int n_trials, int want) {
   __shared__ double smem[4 * NT];
   const int pair = blockIdx.y;
   const GicpPairState* st = state + pair;
-  if (!st->active || !st->need_error) return;
+  if (!st->active || st->need_error != want) return;
   const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
-  const LmTrial* tr = trials + (size_t)pair * kMaxTrials;
+  const LmTrial* tr = trials + (size_t)pair * kMaxTrials + t0;
   const int n = scount[pair];
   const size_t so = (size_t)pair * scap;
-  const int nt = min(n_trials, NT);
+  const int nt = min(n_trials - t0, NT);
   double acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) acc[t] = 0.0;
@@ -1186,21 +1192,26 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
       for (int k = 0; k < NT; k++) acc[k] += (k == t) ? e : 0.0;
     }
   }
-  // trials past n_trials repeat the last one (the decision never reads them)
+  // slots past the last trial hold zeros (the decision never reads them)
   block_sum<NT, 4>(acc, smem);
   if (threadIdx.x == 0) {
-    double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + kTrialSlot;
+    double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + kTrialSlot + t0;
 #pragma unroll
-    for (int t = 0; t < NT; t++) out[t] = acc[t];
+    for (int t = 0; t < NT; t++)
+      if (t0 + t < kMaxTrials) out[t] = acc[t];
   }
 }
 
 // step_lm's accept / reject walk over the pre-evaluated trials + iteration bookkeeping.
+// phase 0: only trial 0 has been evaluated (pairs with need_error == 1) — take it if step_lm would, else mark the pair
+// (need_error = 2) for the remaining trials and leave its state alone; phase 1: the full walk for the marked pairs;
+// phase 2: the full walk for pairs with need_error == 1 (all trials evaluated in one launch: batches of a few pairs).
 __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
-                                                    const double* __restrict__ partials, int G, GicpDevParams P) {
+                                                    const double* __restrict__ partials, int G, GicpDevParams P, int phase) {
   __shared__ double yi[kMaxTrials];
   const int pair = blockIdx.x;
-  if (!state[pair].active || !state[pair].need_error) return;
+  if (!state[pair].active || state[pair].need_error != (phase == 1 ? 2 : 1)) return;
+  const int walk = (phase == 0) ? 1 : P.lm_max_iterations;
   const int l = threadIdx.x;
   if (l < P.lm_max_iterations) {
     double s = 0;
@@ -1212,7 +1223,7 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
   GicpPairState& s = state[pair];  // in place: only the fields of the taken branch move (the state is 1 KB)
   bool finished = false;
   double lam_next = s.lambda, nu = 2.0;
-  for (int t = 0; t < P.lm_max_iterations && !finished; t++) {
+  for (int t = 0; t < walk && !finished; t++) {
     const LmTrial& tr = trials[(size_t)pair * kMaxTrials + t];
     double denom = 0;
     for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - s.b[i]);
@@ -1240,6 +1251,10 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
       finish_step(s, P, true);
       finished = true;
     }
+  }
+  if (!finished && phase == 0 && P.lm_max_iterations > 1) {  // trial 0 rejected: the other trials are evaluated next
+    s.need_error = 2;
+    return;
   }
   if (!finished) {  // every trial rejected: "lm not converged!!"
     s.lambda = lam_next;
@@ -1340,13 +1355,24 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     }
     if (p.optimizer == MI355_OPT_LM) {
       auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
-      {
+      auto error = [&](auto kernel, int t0, int want) {
         TimedLaunch tl(KF_ERROR, s);
-        hipLaunchKernelGGL(ke, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, P.lm_max_iterations);
+        hipLaunchKernelGGL(kernel, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
+                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, t0, P.lm_max_iterations, want);
+      };
+      auto decide = [&](int phase) {
+        TimedLaunch tl(KF_SOLVE_DECIDE, s);
+        hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P, phase);
+      };
+      if (S >= 8 && P.lm_max_iterations > 1 && tuning().err_first) {  // first trial alone, the rest only where it was rejected
+        error(k_gicp_error<1>, 0, 1);
+        decide(0);
+        error(ke, 1, 2);
+        decide(1);
+      } else {  // a few pairs: launch-bound, everything in one pass
+        error(ke, 0, 1);
+        decide(2);
       }
-      TimedLaunch tl(KF_SOLVE_DECIDE, s);
-      hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P);
     }
     if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
       // early stop: every few iterations ask the device whether any pair is still optimising
