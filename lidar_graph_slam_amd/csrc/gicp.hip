@@ -55,10 +55,13 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.ppt = tn.corr_ppt == 1 ? 1 : 4;
   gb.S = S;
   gb.cap = cap;
-  // One pair is worked on by (up to) 64 blocks of 256 threads that all land on one XCD (primitives.hpp): enough waves to
-  // fill that XCD's 32 CUs while only ~2 pairs' working sets compete for its 4 MB L2.
+  // One pair is worked on by 16 - 64 blocks of 256 threads that all land on one XCD (primitives.hpp): about 16 k blocks over the
+  // batch.  In steady state a block's life is a chain of dependent loads (pair state, points, stored queries) around very little
+  // work, so a big batch wants fewer blocks that each walk several tiles — measured at 1 024 pairs: 64 blocks per pair 74.5 ms per
+  // step (k_gicp_correspond 12.9, the tile kernel 8.2), 16: 72.1 ms (12.2 / 7.4), 8: 72.4, 4: 73.5; at 128 pairs 64 is best
+  // (12.7 ms per step against 13.2 at 16).
   (void)compute_units;
-  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : 64;
+  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(16, std::min(64, 16384 / std::max(S, 1)));
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
@@ -1144,8 +1147,8 @@ __device__ __forceinline__ double point_error(const Pose& x, const float4& p, co
 // AGPRs, one wave per SIMD, and spent its time waiting on the point loads with nothing to overlap them).
 constexpr int kErrPoints = 2;
 // The kernel is VALU-bound, not memory-bound: the residual and the quadratic form are fp64 without contraction (the oracle's
-// arithmetic) — 94 v_add_f64 / v_mul_f64 + 24 conversions per trial and pair of points, 10 trials: 85 % of its 0.38 ms per
-// 1 024-pair launch is issue time.  LM accepts its FIRST trial far more often than not, so a batch evaluates trial 0 alone
+// arithmetic) — 83 v_add_f64 / v_mul_f64 per trial and pair of points, 10 trials: most of its 0.30 ms per 1 024-pair launch is
+// issue time (0.38 ms before the conversions were hoisted out of the trial loop and the sums moved to LDS).  LM accepts its FIRST trial far more often than not, so a batch evaluates trial 0 alone
 // (`want` = 1, NT = 1: a streaming pass), k_gicp_decide(phase 0) takes it or marks the pair (need_error = 2), and only the marked
 // pairs pay for trials 1 .. in a second launch (`want` = 2).  Trials [t0, min(t0 + NT, n_trials)) of every pair whose
 // need_error == want.
@@ -1156,9 +1159,14 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
                                                            const int* __restrict__ corr, const Cov6* __restrict__ mahal,
                                                            double* __restrict__ partials, int t0, int n_trials, int want) {
   __shared__ double smem[4 * NT];
+  __shared__ double accL[NT > 1 ? NT : 1][NT > 1 ? kGicpBlock : 1];  // per-thread sums of the trials (NT > 1)
   const int pair = blockIdx.y;
   const GicpPairState* st = state + pair;
   if (!st->active || st->need_error != want) return;
+  if constexpr (NT > 1) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) accL[t][threadIdx.x] = 0.0;
+  }
   const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
   const LmTrial* tr = trials + (size_t)pair * kMaxTrials + t0;
   const int n = scount[pair];
@@ -1182,15 +1190,46 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
       q[u] = tp[max(j, 0)];
       m[u] = mahal[ii];
     }
+    if constexpr (NT == 1) {
+      const Pose xi = tr[0].xi;  // wave-uniform: scalar loads
+#pragma unroll
+      for (int u = 0; u < kErrPoints; u++) acc[0] += ok[u] ? point_error(xi, p[u], q[u], m[u]) : 0.0;
+    } else {
+      // the fp32 -> fp64 conversions of the points and matrices once per tile, not once per trial (the compiler keeps them in the
+      // trial loop: 24 of its ~140 instructions), and the per-trial sums in LDS: a register accumulator chosen by the loop
+      // counter costs NT selects + adds per trial (30 more)
+      double pd[kErrPoints][3], qd[kErrPoints][3], md[kErrPoints][6];
+#pragma unroll
+      for (int u = 0; u < kErrPoints; u++) {
+        pd[u][0] = (double)p[u].x; pd[u][1] = (double)p[u].y; pd[u][2] = (double)p[u].z;
+        qd[u][0] = (double)q[u].x; qd[u][1] = (double)q[u].y; qd[u][2] = (double)q[u].z;
+#pragma unroll
+        for (int k = 0; k < 6; k++) md[u][k] = (double)m[u].v[k];
+      }
 #pragma unroll 1
-    for (int t = 0; t < nt; t++) {
-      const Pose xi = tr[t].xi;  // wave-uniform: scalar loads
-      double e = 0.0;
+      for (int t = 0; t < nt; t++) {
+        const Pose x = tr[t].xi;  // wave-uniform: scalar loads
+        double e = 0.0;
 #pragma unroll
-      for (int u = 0; u < kErrPoints; u++) e += ok[u] ? point_error(xi, p[u], q[u], m[u]) : 0.0;
-#pragma unroll
-      for (int k = 0; k < NT; k++) acc[k] += (k == t) ? e : 0.0;
+        for (int u = 0; u < kErrPoints; u++) {
+          // residual() and cost64() on the converted operands: the same operations in the same order
+          const double dax = x.R[0] * pd[u][0] + x.R[1] * pd[u][1] + x.R[2] * pd[u][2] + x.t[0];
+          const double day = x.R[3] * pd[u][0] + x.R[4] * pd[u][1] + x.R[5] * pd[u][2] + x.t[1];
+          const double daz = x.R[6] * pd[u][0] + x.R[7] * pd[u][1] + x.R[8] * pd[u][2] + x.t[2];
+          const double ex = qd[u][0] - dax, ey = qd[u][1] - day, ez = qd[u][2] - daz;
+          const double a = md[u][0] * ex + md[u][1] * ey + md[u][2] * ez;
+          const double b = md[u][1] * ex + md[u][3] * ey + md[u][4] * ez;
+          const double c = md[u][2] * ex + md[u][4] * ey + md[u][5] * ez;
+          e += ok[u] ? (ex * a + ey * b + ez * c) : 0.0;
+        }
+        accL[t][threadIdx.x] += e;
+      }
     }
+  }
+  if constexpr (NT > 1) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = accL[t][threadIdx.x];
+    __syncthreads();
   }
   // slots past the last trial hold zeros (the decision never reads them)
   block_sum<NT, 4>(acc, smem);
@@ -1364,7 +1403,10 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
         TimedLaunch tl(KF_SOLVE_DECIDE, s);
         hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P, phase);
       };
-      if (S >= 8 && P.lm_max_iterations > 1 && tuning().err_first) {  // first trial alone, the rest only where it was rejected
+      // first trial alone, the rest only where it was rejected — unless the iterations are forced: pairs then keep stepping at
+      // their optimum, where half of the first trials are rejected and the second pass costs more than it saves (measured at 1 024
+      // pairs x 20 forced iterations: 7.5 ms per step in two phases, 7.1 ms in one)
+      if (S >= 8 && P.lm_max_iterations > 1 && !P.force_iterations && tuning().err_first) {
         error(k_gicp_error<1>, 0, 1);
         decide(0);
         error(ke, 1, 2);
