@@ -709,7 +709,10 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
 // The covariance is fused: the k neighbours sit in k lanes, mean and covariance are wave reductions in fp64, and the raw
 // matrices of up to 64 queries are parked in LDS so that the regularisation (the expensive part) runs lane-parallel.
 template <int K>
-__global__ __launch_bounds__(64) void k_knn_hard(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
+// Occupancy: a query is a chain of dependent phases (cell lookups, two candidate walks, the LDS merge), so resident waves are what
+// hides it: 4 per SIMD (128 VGPRs, 288 B of scratch) 1.36 ms per 1 024-cloud launch, the compiler's own 161 VGPRs (3 waves) 1.68 ms,
+// 5 waves (460 B of scratch) 2.2 ms, 6: 1.67 ms.
+__global__ __launch_bounds__(64, (K <= 32 ? 4 : 1)) void k_knn_hard(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
                                                  const GridMeta* __restrict__ meta, Cov6* __restrict__ cov, const int* __restrict__ queue,
                                                  const float* __restrict__ queue_hint, const int* __restrict__ queue_n, size_t cap, size_t slots_cap,
                                                  int k, int method, int G, int B) {
