@@ -22,6 +22,14 @@ void CloudSet::alloc(int B_, size_t cap_) {
   has_cov = false;
 }
 
+// Threads per block of the one-thread-per-point kernels without block-level cooperation (keys, heads, centroids, cell counts,
+// gather + insert).  ONE WAVE per block: a 256-thread block waits for four free wave slots on one CU and gives them back together
+// when its slowest wave is done, and these waves live ~2 us — measured on k_voxel_centroids at 1 024 clouds (PMC: 5.4 resident
+// waves per CU of 32 at 256 threads): 3.5 ms per launch beside the other chain with 256- and 512-thread blocks, 3.9 ms with
+// 1 024, 1.74 ms with 64 (alone: 1.77 / 1.69 ms at 256 / 64).
+constexpr int kPointBlock = 64;
+constexpr int kHashBlock = 64;  // (the hash build alone: 1.46 ms per launch at 256 threads, 1.59 at 64; beside the other chain 2.69 / 2.35 ms)
+
 void ws_reserve(Workspace& ws, int B, size_t cap) {
   const size_t n = (size_t)B * cap;
   ws.keys_a.ensure(n); ws.keys_b.ensure(n);
@@ -237,15 +245,15 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   compute_bounds(s, ws, in, cnt_in, B, cap);
   hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, out.meta.p, B, cell, ws.sort_passes.p);
   hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
-  const dim3 grid(div_up((long)cap, 256), B);
-  hipLaunchKernelGGL(k_cell_keys, grid, dim3(256), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
+  const dim3 grid(div_up((long)cap, kHashBlock), B);
+  hipLaunchKernelGGL(k_cell_keys, grid, dim3(kHashBlock), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
   TimedLaunch tl(KF_HASH_BUILD, s);
-  hipLaunchKernelGGL(k_count_cells, grid, dim3(256), 0, s, ws.keys_a.p, out.meta.p, cap);
+  hipLaunchKernelGGL(k_count_cells, grid, dim3(kHashBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
   hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap);
-  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = div_up((long)cap, 256);
+  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = div_up((long)cap, kHashBlock);
   hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
-  hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
+  hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(kHashBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
                      out.table.p, cap, out.slots_cap, Gi, B);
   MI_LAUNCH_CHECK();
   out.built = true;
@@ -1213,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict_
 // tiles staged through LDS behind a block barrier 5.7 ms; head threads walking their runs from memory, four gathers in flight,
 // 2.6 ms (a run is ~4 points on average, up to ~100 next to the sensor; 3 lanes of 4 idle); now one gather per lane and the run
 // handed to its head by lane shuffles.
-__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
+__global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                          const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
                                                          const int* __restrict__ flags, const int* __restrict__ local,
                                                          const int* __restrict__ blockoff, const int* __restrict__ totals,
@@ -1280,14 +1288,14 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   ws_reserve(ws, B, cap);
   compute_bounds(s, ws, in, cnt_in, B, cap, min_distance);
   hipLaunchKernelGGL(k_voxel_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, ws.vmeta.p, B, leaf, ws.sort_passes.p);
-  const dim3 grid(div_up((long)cap, 256), B);
-  hipLaunchKernelGGL(k_voxel_keys, grid, dim3(256), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap, min_distance);
+  const dim3 grid(div_up((long)cap, kPointBlock), B);
+  hipLaunchKernelGGL(k_voxel_keys, grid, dim3(kPointBlock), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap, min_distance);
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
-  hipLaunchKernelGGL(k_voxel_heads, grid, dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap, in, min_distance);
+  hipLaunchKernelGGL(k_voxel_heads, grid, dim3(kPointBlock), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap, in, min_distance);
   scan_flags(s, ws, B, cap, cnt_in);
-  const int Gv = div_up((long)cap, 256);
+  const int Gv = div_up((long)cap, kPointBlock);
   TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
-  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(256), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
+  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kPointBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
                      ws.scan_block.p, ws.totals.p, out, cnt_out, cap, div_up((long)cap, kScanTile), Gv, B);
   MI_LAUNCH_CHECK();
 }
