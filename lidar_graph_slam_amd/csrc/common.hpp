@@ -89,7 +89,7 @@ struct Tuning {
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)
   int corr_groups = 1;        // MI355_CORR_GROUPS       0 = per-lane correspondence search also for batches of < 8 pairs (no lane groups)
   float margin_step = 0.03f;  // MI355_MARGIN_STEP       a pair tracks search margins once its last accepted step moved it by less than this (m at a 50 m lever arm)
-  int err_first = 1;          // MI355_ERR_FIRST         0 = batches evaluate all LM trials in one k_gicp_error pass (no first-trial-alone pass)
+  int err_first = -1;         // MI355_ERR_FIRST         LM trials a batch evaluates before the rest (1..4); 0 = all in one pass; -1 = 1, or 0 with forced iterations
   int corr_stats = 0;         // MI355_CORR_STATS        1 = count what the correspondence tiles scan, print after every align
   int knn_stats = 0;          // MI355_KNN_STATS         1 = after every covariance launch, synchronise and print to stderr how many
                               //                         points the tile kernel handed over to k_knn_hard (tuning aid, host side only)

@@ -1242,15 +1242,15 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
 }
 
 // step_lm's accept / reject walk over the pre-evaluated trials + iteration bookkeeping.
-// phase 0: only trial 0 has been evaluated (pairs with need_error == 1) — take it if step_lm would, else mark the pair
-// (need_error = 2) for the remaining trials and leave its state alone; phase 1: the full walk for the marked pairs;
+// phase 0: only the first `first` trials have been evaluated (pairs with need_error == 1) — take one if step_lm would, else mark
+// the pair (need_error = 2) for the remaining trials and leave its state alone; phase 1: the full walk for the marked pairs;
 // phase 2: the full walk for pairs with need_error == 1 (all trials evaluated in one launch: batches of a few pairs).
 __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
-                                                    const double* __restrict__ partials, int G, GicpDevParams P, int phase) {
+                                                    const double* __restrict__ partials, int G, GicpDevParams P, int phase, int first) {
   __shared__ double yi[kMaxTrials];
   const int pair = blockIdx.x;
   if (!state[pair].active || state[pair].need_error != (phase == 1 ? 2 : 1)) return;
-  const int walk = (phase == 0) ? 1 : P.lm_max_iterations;
+  const int walk = (phase == 0) ? min(first, P.lm_max_iterations) : P.lm_max_iterations;
   const int l = threadIdx.x;
   if (l < P.lm_max_iterations) {
     double s = 0;
@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
       finished = true;
     }
   }
-  if (!finished && phase == 0 && P.lm_max_iterations > 1) {  // trial 0 rejected: the other trials are evaluated next
+  if (!finished && phase == 0 && P.lm_max_iterations > walk) {  // the first trials rejected: the other trials are evaluated next
     s.need_error = 2;
     return;
   }
@@ -1394,26 +1394,31 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     }
     if (p.optimizer == MI355_OPT_LM) {
       auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
-      auto error = [&](auto kernel, int t0, int want) {
+      auto error = [&](auto kernel, int t0, int t1, int want) {
         TimedLaunch tl(KF_ERROR, s);
         hipLaunchKernelGGL(kernel, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, t0, P.lm_max_iterations, want);
+                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, t0, t1, want);
       };
-      auto decide = [&](int phase) {
+      auto decide = [&](int phase, int first) {
         TimedLaunch tl(KF_SOLVE_DECIDE, s);
-        hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P, phase);
+        hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P, phase, first);
       };
-      // first trial alone, the rest only where it was rejected — unless the iterations are forced: pairs then keep stepping at
-      // their optimum, where half of the first trials are rejected and the second pass costs more than it saves (measured at 1 024
-      // pairs x 20 forced iterations: 7.5 ms per step in two phases, 7.1 ms in one)
-      if (S >= 8 && P.lm_max_iterations > 1 && !P.force_iterations && tuning().err_first) {
-        error(k_gicp_error<1>, 0, 1);
-        decide(0);
-        error(ke, 1, 2);
-        decide(1);
+      // The first trial alone, the rest only where it was rejected: a converging pair accepts its first trial almost always.  With
+      // forced iterations pairs keep stepping at their optimum, where no trial lowers the cost and all of them have to be evaluated
+      // anyway — measured at 1 024 pairs x 20 forced iterations, k_gicp_error + decide per step: one pass 7.2 ms, 1 / 2 / 3 / 4 first
+      // trials 7.7 / 7.4 / 7.2 / 7.1 ms — so forced iterations keep the one-pass form.
+      const int n_lm = P.lm_max_iterations;
+      int first = tuning().err_first < 0 ? (P.force_iterations ? 0 : 1) : tuning().err_first;
+      first = std::min(first, 4);
+      if (S >= 8 && first >= 1 && first < n_lm) {
+        if (first == 1) error(k_gicp_error<1>, 0, 1, 1);
+        else error(k_gicp_error<4>, 0, first, 1);
+        decide(0, first);
+        error(ke, first, n_lm, 2);
+        decide(1, first);
       } else {  // a few pairs: launch-bound, everything in one pass
-        error(ke, 0, 1);
-        decide(2);
+        error(ke, 0, n_lm, 1);
+        decide(2, first);
       }
     }
     if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
