@@ -80,6 +80,42 @@ def test_voxel_grid_known_answer_and_edges(F):
     np.testing.assert_array_equal(vg.filter(), one)
 
 
+@pytest.mark.parametrize("extent", [(3, 3, 3), (6, 6, 6), (39, 39, 40), (40, 40, 40), (255, 255, 254), (255, 255, 255), (300, 280, 260)])
+def test_voxel_grid_radix_pass_boundaries(F, extent):
+    """The tile sort runs only the radix passes the voxel count needs (1 .. 4): clouds whose voxel counts sit on both sides of 2^8,
+    2^16 and 2^24, with points the grid drops (NaN) in between, must still come out exactly as the oracle's."""
+    rng = np.random.default_rng(sum(extent))
+    n = 20000
+    pts = np.zeros((n, 4), np.float32)
+    pts[:, :3] = rng.uniform(0.0, 1.0, (n, 3)) * np.array(extent, np.float32)
+    pts[0, :3] = 0.0
+    pts[1, :3] = np.array(extent, np.float32)  # both corners: the grid spans exactly extent + 1 voxels per axis at leaf 1
+    pts[:, 3] = rng.uniform(0, 100, n)
+    pts[rng.choice(np.arange(2, n), 500, replace=False), 0] = np.nan
+    vg = F.VoxelGrid()
+    vg.setLeafSize(1.0, 1.0, 1.0)
+    vg.setInputCloud(pts)
+    out = vg.filter()
+    ref, ovf = O.voxel_grid(pts, 1.0)
+    assert not ovf and not vg.overflow
+    np.testing.assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("extent", [1.0, 8.0, 100.0, 200.0])
+def test_knn_hash_sort_pass_counts(F, extent):
+    """cell coordinates of 2, 5, 8 and 9 bits per axis: 1, 2, 3 and 4 radix passes in the hash build"""
+    rng = np.random.default_rng(int(extent))
+    t = np.zeros((6000, 4), np.float32)
+    t[:, :3] = rng.uniform(0.0, extent, (6000, 3))
+    t[:, 2] *= 0.1
+    q = t[rng.choice(6000, 500, replace=False)].copy()
+    q[:, :3] += rng.normal(0, 0.01 * extent, (500, 3)).astype(np.float32)
+    idx, d2 = F.knn(t, q, 8)
+    ri, rd = O.knn(t, q, 8)
+    np.testing.assert_array_equal(d2, rd)
+    np.testing.assert_array_equal(idx, ri)
+
+
 def test_voxel_grid_full_size_properties(F):
     src, _, _ = synth.make_pair()
     vg = F.VoxelGrid()
