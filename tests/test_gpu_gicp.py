@@ -185,6 +185,39 @@ def test_batch_matches_single(R, small_pair):
     assert b.kernel_times() == {}  # counters reset by the read
 
 
+def test_batch_of_many_converging_pairs(R, small_pair):
+    """>= 8 pairs without forced iterations: correspondence tiles in the first iterations and the LM trials in two phases (the first
+    trial alone, the rest only for the pairs that rejected it) — pair by pair the same pose and iteration count as the oracle.  One
+    pair starts at its optimum, where first trials do get rejected."""
+    s, t, T = small_pair
+    cap = max(len(s), len(t)) + 3
+    nS = 10
+    srcs = np.zeros((nS, cap, 4), np.float32)
+    tgts = np.zeros((1, cap, 4), np.float32)
+    tgts[0, : len(t)] = t
+    ns = []
+    for i in range(nS):
+        si = O.transform(s[: len(s) - 7 * i], synth.se3(0.03 * i, -0.02 * i, 0.01 * i, 0, 0, 0.002 * i).astype(np.float32))
+        srcs[i, : len(si)] = si
+        ns.append(len(si))
+    p = O.gicp_params(max_iterations=30)
+    first = O.gicp_align(srcs[0, : ns[0]], t, p)
+    opt = O.transform(srcs[0, : ns[0]], first["T"].astype(np.float32))  # pair 9: already aligned
+    srcs[9, : len(opt)] = opt
+    srcs[9, len(opt):] = 0
+    ns[9] = len(opt)
+    b = R.BatchRegistration(nS, 1, cap, max_iterations=30)
+    b.set_targets(tgts, [len(t)])
+    b.set_sources(srcs, ns)
+    b.align([0] * nS)
+    res = b.results()
+    for i in range(nS):
+        ref = O.gicp_align(srcs[i, : ns[i]], t, p)
+        dt, dr = synth.pose_error(res[i]["T"], ref["T"])
+        assert dt <= TOL_T and dr <= TOL_R, (i, dt, dr)
+        assert res[i]["converged"] == ref["converged"] and abs(res[i]["iterations"] - ref["iterations"]) <= 1, (i, res[i], ref)
+
+
 def test_batch_flags_pairs_with_too_few_points(R, small_pair):
     """a cloud that holds fewer than k_correspondences points (here: handed over that way; in production a voxel
     filter can shrink a sparse key-frame sub-map that far) must not be registered with made-up neighbours: the pair reports
