@@ -24,10 +24,12 @@ typedef struct mi355_scan_matcher_params {
   double ndt_resolution;              /* yaml:15 -> 2.0 */
   double max_correspondence_distance; /* yaml:18 -> 2.0 */
   int correspondence_randomness;      /* yaml:19 -> 20 */
-  int reuse_key_frame_covariances;    /* 1: a key frame's GICP covariances are computed once and rotated into every sub-map
-                                         (C' = R C R^T); 0: recomputed over the merged sub-map at every key frame,
-                                         as fast_gicp does (lidar_scan_matcher.cpp:212 -> setInputTarget).  The sub-map itself is
-                                         assembled on the device either way. */
+  int reuse_key_frame_covariances;    /* 0 (the default of every wrapper, and what a drop-in must pass): target covariances are
+                                         recomputed over the merged sub-map at every key frame, as fast_gicp does
+                                         (lidar_scan_matcher.cpp:212 -> setInputTarget) = the reference's arithmetic.
+                                         1: opt-in optimisation, NOT the reference's arithmetic: a key frame's GICP covariances
+                                         are computed once and rotated into every sub-map (C' = R C R^T).  The
+                                         sub-map itself is assembled on the device either way. */
   double correspondence_distance;     /* yaml:22 -> 5.0 ("GICP": setMaxCorrespondenceDistance, cpp:88) */
   int max_optimizer_iteration;        /* yaml:25 -> 20  ("GICP": setMaximumOptimizerIterations, cpp:91) */
 } mi355_scan_matcher_params;

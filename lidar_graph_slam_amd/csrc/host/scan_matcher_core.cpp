@@ -115,6 +115,14 @@ ScanOutput ScanMatcherCore::callback_cloud(const PointCloud& input_cloud, const 
     }
     target_cloud_ = DeviceCloud::concat(ctx_, parts, poses, carry);
     registration_->setInputTarget(target_cloud_);  // :212
+    // only the last max_scan_accumulate_num key frames are ever read again: the one that has just left the window moves to
+    // the host (where the reference keeps every key_frame.cloud, :196) and gives its HBM back - points and covariances
+    const int leaving = sub_map_size - 1 - params_.max_scan_accumulate_num;
+    if (leaving >= 0 && key_frame_array_[(size_t)leaving].device) {
+      KeyFrame& old = key_frame_array_[(size_t)leaving];
+      old.device->download(old.cloud);
+      old.device.reset();
+    }
     out.new_key_frame = true;
     out.key_frame_id = key_frame_array_.back().id;
   }

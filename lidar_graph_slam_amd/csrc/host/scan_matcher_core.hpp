@@ -73,7 +73,8 @@ inline Matrix4f matmul(const Matrix4f& a, const Matrix4f& b) {  // Eigen Matrix4
 
 struct KeyFrame {  // lidar_graph_slam_msgs/msg/KeyFrame.msg:1-5 (header dropped)
   PointCloud cloud;           // host copy: filled by callers that hand key frames over on the host (LoopClosureCore::add_key_frame)
-  DeviceCloud::Ptr device;    // the cloud in HBM (with its GICP covariances once it has been a registration source)
+                              // and by ScanMatcherCore when a key frame leaves the sliding window (its `device` is then released)
+  DeviceCloud::Ptr device;    // the cloud in HBM (with its GICP covariances once it has been a registration source); null once evicted
   Pose pose;
   double accum_distance = 0.0;
   long id = 0;
@@ -95,11 +96,13 @@ struct ScanMatcherParams {  // lidar_scan_matcher.param.yaml:3-19
   double euclidean_fitness_epsilon = 1e-8;
   int max_optimizer_iteration = 20;
   bool use_reciprocal_correspondences = false;
-  // a key frame's k-NN covariances are computed once (when the scan is registered) and ROTATED into every
-  // sub-map it is part of (C' = R C R^T) instead of being recomputed over the ~3 x 10^5-point union at every key frame.
-  // false = the reference's arithmetic: fast_gicp recomputes them over the merged sub-map (its neighbourhoods then also
-  // hold points of the other key frames); the sub-map is still assembled on the device.
-  bool reuse_key_frame_covariances = true;
+  // false (default) = the reference's arithmetic: fast_gicp's setInputTarget (lidar_scan_matcher.cpp:212) recomputes the
+  // k-NN covariances over the merged sub-map, whose neighbourhoods also hold points of the other key frames; the sub-map
+  // is still assembled on the device.
+  // true = opt-in optimisation, NOT the reference's arithmetic: a key frame's covariances are computed once
+  // (when the scan is registered) and ROTATED into every sub-map it is part of (C' = R C R^T) instead of being recomputed
+  // over the ~3 x 10^5-point union at every key frame.  Measured deviation: DESIGN.md section 3.
+  bool reuse_key_frame_covariances = false;
 };
 
 struct ScanOutput {
@@ -118,6 +121,14 @@ class ScanMatcherCore {
   // `msg` cloud in the sensor frame; base_to_sensor = the TF the node looks up (identity when the lookup fails, cpp:259-271)
   ScanOutput callback_cloud(const PointCloud& input_cloud, const Matrix4f& base_to_sensor);
   const std::vector<KeyFrame>& key_frames() const { return key_frame_array_; }
+  // key_frame.cloud as the reference holds it (:145,196): from the host copy, or downloaded while the frame is still in the window
+  PointCloud key_frame_cloud(size_t i) const {
+    const KeyFrame& kf = key_frame_array_.at(i);
+    if (!kf.device) return kf.cloud;
+    PointCloud c;
+    kf.device->download(c);
+    return c;
+  }
   // the sliding sub-map (target_cloud_), downloaded on demand
   PointCloudPtr target_cloud() const;
   size_t target_points() const { return target_cloud_ ? target_cloud_->size() : 0; }

@@ -14,7 +14,7 @@ class LidarScanMatcher:
 
     def __init__(self, registration_method="NDT_OMP", displacement=1.0, max_scan_accumulate_num=20, max_iteration=64, omp_num_thread=4,
                  transformation_epsilon=0.01, step_size=0.1, ndt_resolution=2.0, max_correspondence_distance=2.0, correspondence_randomness=20,
-                 reuse_key_frame_covariances=True, correspondence_distance=5.0, max_optimizer_iteration=20, device_id=0):
+                 reuse_key_frame_covariances=False, correspondence_distance=5.0, max_optimizer_iteration=20, device_id=0):
         method = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP, "GICP": L.METHOD_GICP}.get(registration_method, -1)
         self.params = L.ScanMatcherParams(method, displacement, max_scan_accumulate_num, max_iteration, omp_num_thread, transformation_epsilon,
                                           step_size, ndt_resolution, max_correspondence_distance, correspondence_randomness,

@@ -49,6 +49,17 @@ def pose_error(T_est: np.ndarray, T_ref: np.ndarray):
     return dt, float(np.arctan2(sn, cs))
 
 
+def band_error(T_a: np.ndarray, T_b: np.ndarray):
+    """The difference of two poses measured the way fast_gicp's is_converged measures a step: with
+    delta = T_a * T_b^-1, (max |delta.t_i|, max |(delta.R - I)_ij|).  Two correct runs that stop one LM iteration apart
+    differ by one step that passed `max|t_i| < transformation_epsilon (0.01 m) and max|R - I| < rotation_epsilon (2e-3)`:
+    THIS is the "convergence band" of BASELINE.md section 4, component-wise, not a Euclidean norm / rotation angle."""
+    T_a = np.asarray(T_a, dtype=np.float64).reshape(4, 4)
+    T_b = np.asarray(T_b, dtype=np.float64).reshape(4, 4)
+    d = T_a @ np.linalg.inv(T_b)
+    return float(np.abs(d[:3, 3]).max()), float(np.abs(d[:3, :3] - np.eye(3)).max())
+
+
 class Scene:
     """Axis-aligned boxes + ground plane."""
 

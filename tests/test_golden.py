@@ -90,6 +90,7 @@ def test_hip_path_reproduces_golden(golden):
     bf.setInputTarget(G["tgt_voxel"])
     bf.setInputSource(G["voxel"])
     bf.align()
-    dt, dr = synth.pose_error(bf.getFinalTransformation(), G["bfgs_T_1"])
-    assert dt <= 5e-3 and dr <= 5e-4, (dt, dr)
+    import parity
+
+    parity.assert_fixed(bf.getFinalTransformation(), G["bfgs_T_1"], "golden/bfgs_outer1", t=2e-3, r=2e-4)  # one outer iteration
     assert abs(bf._result["error"] - float(G["bfgs_cost_1"])) <= 2e-3 * float(G["bfgs_cost_1"])

@@ -3,15 +3,17 @@ full-size inputs and checks it against the oracle on the same inputs and/or agai
 
   config 2  noise-free 64 k-point pair: <= 5 mm / 5e-4 rad vs truth, <= 1 mm / 1e-4 rad vs the oracle
   config 3  64 k-point scan vs a ~1 M-point target, 1.0 m NDT cells, vs O.ndt_align
-  config 4  KITTI-shaped stream through ScanMatcherCore: 100 scans x 64 k rays, window 20 — FAST_GICP scan by scan against
-            the reference-policy restatement registering with the oracle (first 24 scans, covariances recomputed as fast_gicp
-            does), then both engines against the ground truth over the whole stream
+  config 4  KITTI-shaped stream through ScanMatcherCore, window 20: 1 000 scans x 64 k rays (the stated size) with FAST_GICP in
+            the default mode - first 24 scans against the reference-policy restatement registering with the oracle, all of them
+            against the ground truth (ATE, key frames), with ground returns cut at 20 m and out to 80 m; and a 100-scan stream
+            for both engines and the opt-in carried-covariance mode
   config 5  the per-GPU share of the loop-closure batch (512 candidates, 8 sub-maps, 0.5 m voxel) vs truth, a sample vs the
             oracle (pose and fitness)
 """
 import numpy as np
 import pytest
 
+import parity
 from lidar_graph_slam_amd import synth
 from oracle import oracle_py as O
 
@@ -72,8 +74,7 @@ def test_config3_ndt_scan_vs_1m_point_submap():
     assert abs(len(cells["idx"]) - len(ref_cells["idx"])) <= 2  # leaves (a voxel on the eigenvalue-sign edge may differ)
     assert ndt.hasConverged() and ref["converged"]
     assert abs(ndt.result["iterations"] - ref["iterations"]) <= 1
-    dt, dr = synth.pose_error(ndt.getFinalTransformation(), ref["T"])
-    assert dt <= 0.01 and dr <= 2e-3, (dt, dr)  # inside the convergence band of the last step
+    parity.assert_in_band(ndt.getFinalTransformation(), ref["T"], "config3/ndt_1M")  # inside the convergence band of the last step
     dt, dr = synth.pose_error(ndt.getFinalTransformation(), T_true)
     assert dt <= 0.05 and dr <= 2e-3, (dt, dr)
 
@@ -91,13 +92,13 @@ def street_stream():
 
 
 def test_config4_gicp_stream_matches_the_reference_policy(street_stream):
-    """Scan by scan against the restatement of callback_cloud registering with the ORACLE; reuse_key_frame_covariances = 0:
-    the target covariances are recomputed over the merged sub-map exactly as fast_gicp does."""
+    """Scan by scan against the restatement of callback_cloud registering with the ORACLE, in the DEFAULT mode
+    (reuse_key_frame_covariances = 0): the target covariances are recomputed over the merged sub-map exactly as fast_gicp does."""
     from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
     from ref_scan_matcher import RefScanMatcher
 
     poses, scans = street_stream
-    sm = LidarScanMatcher(registration_method="FAST_GICP", reuse_key_frame_covariances=False)
+    sm = LidarScanMatcher(registration_method="FAST_GICP")
     ref = RefScanMatcher(method="FAST_GICP")
     for i in range(24):
         a, b = sm.callback_cloud(scans[i]), ref.callback_cloud(scans[i])
@@ -105,8 +106,7 @@ def test_config4_gicp_stream_matches_the_reference_policy(street_stream):
         if a["first_scan"]:
             continue
         assert a["converged"] and b["converged"], i
-        dt, dr = synth.pose_error(a["pose"], b["pose"])
-        assert dt <= 0.012 and dr <= 2.5e-3, (i, dt, dr)
+        parity.assert_in_band(a["pose"], b["pose"], f"config4_100/FAST_GICP/scan{i}")
         assert a["new_key_frame"] == b["new_key_frame"], i
         assert a["target_points"] == len(ref.target), i
     tgt = sm.target_cloud()
@@ -116,7 +116,7 @@ def test_config4_gicp_stream_matches_the_reference_policy(street_stream):
     np.testing.assert_array_equal(tgt[:, 3], ref.target[:, 3])
 
 
-@pytest.mark.parametrize("method,reuse", [("FAST_GICP", True), ("NDT_OMP", True)])
+@pytest.mark.parametrize("method,reuse", [("FAST_GICP", False), ("FAST_GICP", True), ("NDT_OMP", False)])
 def test_config4_stream_tracks_the_ground_truth(street_stream, method, reuse):
     """100 scans x 64 k rays, window 20 (80 m of path): odometry error against the ground truth at every scan.  NDT_OMP at 2 m
     cells — the reference's default — tracks on this scene (the corridor scene of round 1 it could not track on is analysed in
@@ -142,6 +142,67 @@ def test_config4_stream_tracks_the_ground_truth(street_stream, method, reuse):
     # key frames every ~1.0 m of 0.8 m steps: every second scan, +-
     assert 40 <= n_kf <= 60, n_kf
     assert o["target_points"] > 150_000  # 20 key frames in the window
+
+
+def _cast_for_stream(args):
+    """Worker of the 1 000-scan stream (spawned processes: NumPy only, never the GPU)."""
+    length, i, pose, gmr = args
+    from lidar_graph_slam_amd import synth as S
+
+    return S.cast_scan(S.street(length), pose, seed=300 + i, ground_max_range=gmr)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("ground_max_range", [20.0, None])
+def test_config4_at_its_stated_size_1000_scans(ground_max_range):
+    """BASELINE configs[3] at its stated length: 1 000 scans x 64 k rays (800 m of path at 0.8 m/scan), key frame 1.0 m,
+    window 20, FAST_GICP in the default (reference-arithmetic) mode, through ScanMatcherCore:
+      * scans 0..23 scan by scan against RefScanMatcher registering with the oracle (inside the convergence band),
+      * all 1 000 scans against the ground truth: per-scan error bound, ATE (RMSE of the translation error), key-frame count.
+    ground_max_range = 20 m is the street scene of the 100-scan tests; None keeps the ground returns out to 80 m as SURVEY 8(d)
+    specifies the scene (the rings that trap NDT, tests/test_oracle_ndt.py; GICP tracks through them).  The scans are ray-cast
+    by a pool of spawned CPU workers while the GPU registers."""
+    import multiprocessing as mp
+    import os
+
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+    from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
+    from ref_scan_matcher import RefScanMatcher
+
+    n = 1000
+    length = n * 0.8 + 10.0
+    poses = synth.trajectory(n, seed=3)
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+    sm = LidarScanMatcher(registration_method="FAST_GICP")
+    ref = RefScanMatcher(method="FAST_GICP")
+    err = np.zeros(n)
+    n_kf = 0
+    workers = max(2, min(48, (os.cpu_count() or 8) - 2))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        raws = pool.imap(_cast_for_stream, [(length, i, poses[i], ground_max_range) for i in range(n)], chunksize=2)
+        for i, raw in enumerate(raws):
+            scan = pre.callback_sensor_points(raw)
+            o = sm.callback_cloud(scan)
+            if i < 24:
+                b = ref.callback_cloud(scan)
+                assert o["first_scan"] == b["first_scan"]
+                if not o["first_scan"]:
+                    assert o["converged"] and b["converged"], i
+                    parity.assert_in_band(o["pose"], b["pose"], f"config4_1000/gmr{ground_max_range}/scan{i}")
+                    assert o["new_key_frame"] == b["new_key_frame"], i
+                    assert o["target_points"] == len(ref.target), i
+            if o["first_scan"]:
+                continue
+            assert o["converged"], i
+            n_kf += o["new_key_frame"]
+            dt, dr = synth.pose_error(o["pose"], np.linalg.inv(poses[0]) @ poses[i])
+            err[i] = dt
+            assert dt < 0.05 + 0.003 * (0.8 * i) and dr < 0.02, (i, dt, dr)  # drift bound: 5 cm + 0.3 % of the path
+    ate = float(np.sqrt(np.mean(err**2)))
+    parity._log(f"config4_1000/gmr{ground_max_range}/summary", ate_m=ate, end_err_m=float(err[-1]), key_frames=n_kf, path_m=0.8 * (n - 1))
+    assert ate < 1.0, ate
+    assert 420 <= n_kf <= 580, n_kf  # a key frame every 1.0 m of 0.8 m steps: every second scan, +-
+    assert o["n_key_frames"] == n_kf + 1 and o["target_points"] > 150_000
 
 
 @pytest.mark.parametrize("method,n", [("FAST_GICP", 512), ("NDT_OMP", 128)])
@@ -205,6 +266,5 @@ def test_config5_per_gpu_share_of_the_loop_closure_batch(method, n):
         else:
             ref = O.ndt_align(load_source(p), t, O.ndt_params(**kw))
             assert abs(int(out["iterations"][p]) - ref["iterations"]) <= 2, (p, out["iterations"][p], ref["iterations"])
-        dt, dr = synth.pose_error(out["T"][p], ref["T"])
-        assert dt <= 0.012 and dr <= 2.5e-3, (method, p, dt, dr)  # both stop inside the convergence band
+        parity.assert_in_band(out["T"][p], ref["T"], f"config5/{method}/pair{p}")  # both stop inside the convergence band
         np.testing.assert_allclose(out["fitness"][p], O.fitness(load_source(p), t, out["T"][p]), rtol=1e-6)

@@ -6,6 +6,7 @@ import pytest
 from lidar_graph_slam_amd import synth
 from oracle import oracle_py as O
 from ref_scan_matcher import RefScanMatcher
+import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -20,10 +21,11 @@ def _stream(n_scans, n_azimuth=128):
     return poses, scans
 
 
-@pytest.mark.parametrize("method,reuse", [("FAST_GICP", False), ("FAST_GICP", True), ("NDT_OMP", True)])
+@pytest.mark.parametrize("method,reuse", [("FAST_GICP", False), ("FAST_GICP", True), ("NDT_OMP", False)])
 def test_stream_matches_reference_policy(method, reuse):
-    """reuse = False: target covariances recomputed over the merged sub-map as fast_gicp does; True: each key frame's
-    covariances rotated into the sub-map — both inside the convergence band of the oracle's pose."""
+    """reuse = False (the default): target covariances recomputed over the merged sub-map as fast_gicp does — held to the
+    oracle's pose scan by scan; True (opt-in, not the reference's arithmetic): each key frame's covariances rotated into the
+    sub-map — held to the policy decisions and the ground truth only."""
     from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
 
     poses, scans = _stream(10)
@@ -37,13 +39,12 @@ def test_stream_matches_reference_policy(method, reuse):
         if a["first_scan"]:
             continue
         assert a["converged"] and b["converged"], (i, a["converged"], b["converged"])
-        dt, dr = synth.pose_error(a["pose"], b["pose"])
-        # both stop inside the convergence band of each scan.  With rotated per-key-frame covariances (reuse) a target point's
-        # neighbourhood holds its own scan's points only; on these sparse 8 k-ray scans that moves the optimum by centimetres and
-        # the two streams then see different key frames - that mode is held to the ground truth below instead (and, at full
-        # size, in test_gpu_fullsize.py)
+        # both stop inside the convergence band of each scan (measured as is_converged measures it).
+        # With rotated per-key-frame covariances (reuse) a target point's neighbourhood holds its own scan's points only; on
+        # these sparse 8 k-ray scans that moves the optimum by centimetres and the two streams then see different key frames -
+        # that opt-in mode is held to the ground truth below instead (and, at full size, in test_gpu_fullsize.py)
         if not (method == "FAST_GICP" and reuse):
-            assert dt <= 0.012 and dr <= 2.5e-3, (method, i, dt, dr)
+            parity.assert_in_band(a["pose"], b["pose"], f"scan_matcher_small/{method}/scan{i}")
         # the poses drive the key-frame gate; a scan sitting on the 1.0 m threshold could flip it, the stream avoids that
         assert a["new_key_frame"] == b["new_key_frame"], i
         n_kf += a["new_key_frame"]
