@@ -233,7 +233,9 @@ int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud);
  * points_prefiltering.cpp:70; pcl::toROSMsg at lidar_scan_matcher.cpp:145,196 and graph_based_slam.cpp:462): the raw message
  * bytes cross PCIe once and are unpacked / packed by a kernel.  Field offsets and datatypes are the message's `fields`
  * entries for x, y, z, intensity (sensor_msgs/PointField: INT8=1 UINT8=2 INT16=3 UINT16=4 INT32=5 UINT32=6 FLOAT32=7 FLOAT64=8);
- * x, y, z must be FLOAT32; an absent intensity field is off_intensity = -1 (intensity 0, as fromROSMsg leaves it). */
+ * x, y, z must be FLOAT32; an absent intensity field is off_intensity = -1 (intensity 0, as fromROSMsg leaves it), and so is an
+ * intensity field whose datatype is not FLOAT32: pcl::fromROSMsg maps a field only when name, datatype and count match the
+ * point type's (pcl::PointXYZI::intensity is a float) and otherwise warns and leaves the default 0 - nothing is converted. */
 typedef struct mi355_pointcloud2 {
   const void* data;      /* msg.data */
   uint32_t width, height;
@@ -241,6 +243,8 @@ typedef struct mi355_pointcloud2 {
   int32_t off_x, off_y, off_z, off_intensity;
   uint8_t intensity_datatype;
   uint8_t is_bigendian;  /* must be 0 (every ROS 2 platform is little-endian) */
+  size_t data_size;      /* msg.data.size(): must cover row_step * height bytes (MI355_EINVAL otherwise - an inconsistent message
+                            is refused, not read past its end) */
 } mi355_pointcloud2;
 mi355_cloud* mi355_cloud_from_pointcloud2(mi355_ctx* ctx, const mi355_pointcloud2* msg);
 /* pcl::toROSMsg(pcl::PointCloud<pcl::PointXYZI>): point_step 32, x@0 y@4 z@8 (data[3] = 1.0f @12) intensity@16, padding 0;
@@ -276,11 +280,16 @@ int mi355_batch_set_sources_clouds(mi355_batch* b, mi355_cloud* const* clouds, c
 int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesses16, int with_fitness);
 /* Synchronises and copies results (n_sources entries) and optional fitness scores. */
 int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
+/* Use only the first n_sources / n_targets slots of the batch (1 <= live <= what mi355_batch_create was given) until the next call:
+ * a caller that keeps ONE batch object for requests of varying size (LoopClosureCore, the lanes of mi355_multi) pays nothing for
+ * the slots a request does not fill.  Invalidates the sources, targets and results that were set before. */
+int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets);
 /* Per-kernel-family timing for the benchmark's roofline block.  With timing enabled the library records HIP events on the
  * launching stream around every launch of the hot kernels (k_knn_cov_tile, k_gicp_correspond, k_gicp_linearize, ...; short
  * kernels that always run back to back, e.g. the 12 launches of one radix sort, share one bracket).
  * mi355_batch_kernel_times synchronises the batch, returns one entry per family (total milliseconds and number of brackets
- * since the last call) and resets the counters; *n_out is the number of families that ran (may exceed capacity). */
+ * since the last call); *n_out is the number of families that ran.  The counters are reset only when every family fitted into
+ * `capacity` - a caller whose array was too small calls again with *n_out entries and loses nothing. */
 typedef struct mi355_kernel_time {
   char name[64];
   double total_ms;
@@ -299,6 +308,34 @@ int mi355_batch_kernel_times(mi355_batch* b, mi355_kernel_time* out, int capacit
  * prefiltered and indexed - the double buffering a streaming caller (one batch of loop-closure candidates / scan pairs
  * after the other) wants.  Device pointers handed to mi355_batch_set_*_dev must be valid in THAT stream's order. */
 int mi355_batch_set_stream(mi355_batch* batch, void* hip_stream, int use_context_stream);
+
+/* ---- multi-device: one host process, one context + stream per device (SURVEY 8b "ctx_or_multi", 8e) ---------- */
+/* The loop-closure back end is a C++ node (graph_based_slam.cpp:238-352) and registers one candidate per tick (:311-322);
+ * BASELINE configs[4] registers thousands of independent candidates at once, sharded over the GPUs of one node.  A mi355_multi
+ * owns one mi355_ctx (its stream, its buffers) per entry of device_ids — the same ordinal may appear twice: two independent
+ * lanes on one device.  Pairs are dealt to lanes by target (sub-map) so that every sub-map is uploaded, filtered and indexed
+ * once: targets by descending pair count (ties: lower target id), each to the least-loaded lane (ties: lower lane) — the rule
+ * of lidar_graph_slam_amd/sharding.py, whose torchrun form (one process per GPU, results all-gathered over RCCL) produces the
+ * same partition.  Here the process is one, so the only exchange step — the 80-byte results — is a D2H copy per lane; every
+ * lane is driven by its own host thread.  No pair crosses lanes: results are those of a single batch, pair for pair. */
+typedef struct mi355_multi mi355_multi;
+mi355_multi* mi355_multi_create(const int* device_ids, int n_devices);
+void mi355_multi_destroy(mi355_multi* m);
+const char* mi355_multi_last_error(const mi355_multi* m);
+int mi355_multi_device_count(const mi355_multi* m);
+/* lane i's context (for device clouds / filters on that device); owned by the multi object */
+mi355_ctx* mi355_multi_context(mi355_multi* m, int lane);
+/* the partition alone (host only): lane_of_pair[p] for n_pairs pairs over n_lanes lanes */
+int mi355_multi_shard_by_target(const int* tgt_of_src, int n_pairs, int n_lanes, int* lane_of_pair);
+/* mi355_batch_* over all lanes in one call: pair p aligns sources[p] to targets[tgt_of_src[p]] (host views, any stride) from
+ * guesses16 + 16 p (NULL = identity, graph_based_slam.cpp:318).  method / params as mi355_batch_create; the prefilters
+ * (optional) run on the device (graph_based_slam.cpp:311-313: VoxelGrid 0.5 m on the sub-map).  results: n_sources entries;
+ * fitness (optional, with_fitness != 0): getFitnessScore per pair (:321); lane_of_pair (optional): where each pair ran.
+ * Every lane keeps its batch object between calls (grow-only). */
+int mi355_multi_batch_register(mi355_multi* m, int method, const void* params, const mi355_cloud_view* sources, int n_sources,
+                               const mi355_cloud_view* targets, int n_targets, const int* tgt_of_src, const float* guesses16,
+                               const mi355_prefilter_params* source_prefilter, const mi355_prefilter_params* target_prefilter, int with_fitness,
+                               mi355_result* results, double* fitness, int* lane_of_pair);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,8 @@ typedef struct mi355_loop_closure_params {
   double ndt_resolution;                  /* yaml:18 -> 1.0 (NDT_OMP) */
   double correspondence_distance;         /* yaml:26 -> 2.0 (GICP) */
   int max_optimizer_iteration;            /* yaml:23 -> 20 (GICP) */
+  int ransac_iteration;                   /* yaml:29 -> 0 (GICP: setRANSACIterations, graph_based_slam.cpp:131,139; ICP hard-codes 0 at
+                                             :149).  Only 0 - no RANSAC correspondence rejector - is built: create fails otherwise */
 } mi355_loop_closure_params;
 
 typedef struct mi355_loop_result {
@@ -49,6 +51,11 @@ typedef struct mi355_loop_result {
 void mi355_loop_closure_default_params(mi355_loop_closure_params* p);
 /* No GPU is touched before the first mi355_loop_closure_close call. */
 mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi355_loop_closure_params* params);
+/* The same over several devices from one process (one context + stream per device): the candidates of one
+ * mi355_loop_closure_close call are dealt to the devices by sub-map (the rule of mi355_multi_shard_by_target), every device
+ * registers its share with one batch launch sequence under its own host thread, results come back in query order.  An ordinal
+ * may appear twice (two lanes on one device).  Results are those of the single-device object, query for query. */
+mi355_loop_closure* mi355_loop_closure_create_multi(const int* device_ids, int n_devices, const mi355_loop_closure_params* params);
 void mi355_loop_closure_destroy(mi355_loop_closure* h);
 const char* mi355_loop_closure_last_error(const mi355_loop_closure* h);
 /* key_frame_callback's bookkeeping (:354-380 without the graph factors): cloud in the key frame's own frame (KeyFrame.msg),

@@ -82,7 +82,7 @@ PAIR_OK, PAIR_TOO_FEW_POINTS = 0, 1
 class PointCloud2(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("point_step", C.c_uint32), ("row_step", C.c_uint32),
                 ("off_x", C.c_int32), ("off_y", C.c_int32), ("off_z", C.c_int32), ("off_intensity", C.c_int32), ("intensity_datatype", C.c_uint8),
-                ("is_bigendian", C.c_uint8)]
+                ("is_bigendian", C.c_uint8), ("data_size", C.c_size_t)]
 
 
 class KernelTime(C.Structure):
@@ -131,7 +131,9 @@ EXPORTS = [
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
     "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
-    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams",
+    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams", "mi355_batch_set_live",
+    "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_last_error", "mi355_multi_device_count", "mi355_multi_context",
+    "mi355_multi_shard_by_target", "mi355_multi_batch_register",
 ]
 # include/mi355_scan_matcher.h
 EXPORTS_SCAN_MATCHER = [
@@ -140,7 +142,7 @@ EXPORTS_SCAN_MATCHER = [
 ]
 # include/mi355_loop_closure.h
 EXPORTS_LOOP_CLOSURE = [
-    "mi355_loop_closure_default_params", "mi355_loop_closure_create", "mi355_loop_closure_destroy", "mi355_loop_closure_last_error",
+    "mi355_loop_closure_default_params", "mi355_loop_closure_create", "mi355_loop_closure_create_multi", "mi355_loop_closure_destroy", "mi355_loop_closure_last_error",
     "mi355_loop_closure_add_key_frame", "mi355_loop_closure_set_pose", "mi355_loop_closure_candidate", "mi355_loop_closure_close",
 ]
 
@@ -161,6 +163,7 @@ class LoopClosureParams(C.Structure):
         ("ndt_resolution", C.c_double),
         ("correspondence_distance", C.c_double),
         ("max_optimizer_iteration", C.c_int),
+        ("ransac_iteration", C.c_int),
     ]
 
 
@@ -290,6 +293,21 @@ def lib():
         L.mi355_loop_closure_default_params.restype = None
         L.mi355_loop_closure_create.restype = C.c_void_p
         L.mi355_loop_closure_create.argtypes = [C.c_int, C.POINTER(LoopClosureParams)]
+        L.mi355_loop_closure_create_multi.restype = C.c_void_p
+        L.mi355_loop_closure_create_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(LoopClosureParams)]
+        L.mi355_batch_set_live.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.mi355_multi_create.restype = C.c_void_p
+        L.mi355_multi_create.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_multi_destroy.argtypes = [C.c_void_p]
+        L.mi355_multi_destroy.restype = None
+        L.mi355_multi_last_error.restype = C.c_char_p
+        L.mi355_multi_last_error.argtypes = [C.c_void_p]
+        L.mi355_multi_device_count.argtypes = [C.c_void_p]
+        L.mi355_multi_context.restype = C.c_void_p
+        L.mi355_multi_context.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_multi_shard_by_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.mi355_multi_batch_register.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(PrefilterParams), C.POINTER(PrefilterParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_loop_closure_destroy.argtypes = [C.c_void_p]
         L.mi355_loop_closure_destroy.restype = None
         L.mi355_loop_closure_last_error.restype = C.c_char_p

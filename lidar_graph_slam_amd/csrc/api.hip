@@ -142,7 +142,8 @@ struct mi355_batch {
   mi355_ndt_params np;       // method == MI355_METHOD_NDT_OMP
   NdtBatch* ndt = nullptr;
   std::vector<int> ndt_src_counts, ndt_tgt_counts;  // points per cloud after the prefilter (host copies)
-  int n_sources = 0, n_targets = 0;
+  int n_sources = 0, n_targets = 0;          // live slots (mi355_batch_set_live; = the allocation after mi355_batch_create)
+  int alloc_sources = 0, alloc_targets = 0;  // slots the buffers were sized for
   size_t cap = 0;
   // Targets and sources are prepared (prefilter, sort, voxel hash, k-NN covariances) on two side streams forked from the
   // context stream at call time and joined by mi355_batch_align: the two chains are independent, and most of their kernels
@@ -184,6 +185,7 @@ static CtxExtras* extras(mi355_ctx* ctx);
 
 // ---- defaults ------------------------------------------------------------------------------------------------------
 extern "C" void mi355_gicp_default_params(mi355_gicp_params* p) {
+  if (!p) return;
   p->k_correspondences = 20;
   p->max_iterations = 64;
   p->transformation_epsilon = 0.01;
@@ -197,6 +199,7 @@ extern "C" void mi355_gicp_default_params(mi355_gicp_params* p) {
   p->num_threads = 0;
 }
 extern "C" void mi355_ndt_default_params(mi355_ndt_params* p) {
+  if (!p) return;
   p->transformation_epsilon = 0.01;
   p->step_size = 0.1;
   p->resolution = 2.0;
@@ -224,6 +227,7 @@ extern "C" void mi355_gicp_bfgs_default_params(mi355_gicp_bfgs_params* p) {  // 
 }
 
 extern "C" void mi355_icp_default_params(mi355_icp_params* p) {  // graph_based_slam.cpp:146-150
+  if (!p) return;
   p->max_correspondence_distance = 30.0;
   p->max_iterations = 100;
   p->transformation_epsilon = 1e-8;
@@ -232,6 +236,7 @@ extern "C" void mi355_icp_default_params(mi355_icp_params* p) {  // graph_based_
   p->ransac_iterations = 0;
 }
 extern "C" void mi355_prefilter_default_params(mi355_prefilter_params* p) {
+  if (!p) return;
   p->min_distance = 1.0;
   p->leaf_size = 0.1;
   p->mean_k = 30;
@@ -912,15 +917,18 @@ extern "C" mi355_cloud* mi355_cloud_from_pointcloud2(mi355_ctx* ctx, const mi355
     if (m->off_x < 0 || m->off_y < 0 || m->off_z < 0 || (uint32_t)std::max(m->off_x, std::max(m->off_y, m->off_z)) + 4 > m->point_step ||
         (m->off_intensity >= 0 && (uint32_t)(m->off_intensity + isz) > m->point_step) || (size_t)m->width * m->point_step > m->row_step)
       throw ArgError(MI355_EINVAL, "PointCloud2 field offsets / steps are inconsistent");
+    const size_t bytes = (size_t)m->row_step * m->height;
+    if (m->data_size < bytes) throw ArgError(MI355_EINVAL, "PointCloud2 data is shorter than row_step * height");
+    // pcl::fromROSMsg maps `intensity` only when the field is a FLOAT32 (datatype 7) like pcl::PointXYZI's; else it stays 0
+    const int off_intensity = (m->off_intensity >= 0 && m->intensity_datatype == 7) ? m->off_intensity : -1;
     MI_HIP(hipSetDevice(ctx->device));
     c = new_cloud(ctx, n);
     if (n == 0) return;
-    const size_t bytes = (size_t)m->row_step * m->height;
     FilterScratch& fs = extras(ctx)->fs;
     fs.mask.ensure(bytes);
     MI_HIP(hipMemcpyAsync(fs.mask.p, m->data, bytes, hipMemcpyHostToDevice, ctx->stream));
     pointcloud2_unpack(ctx->stream, fs.mask.p, c->pts.p, m->width, m->height, m->point_step, m->row_step, m->off_x, m->off_y, m->off_z,
-                       m->off_intensity, m->intensity_datatype);
+                       off_intensity, 7);
     MI_HIP(hipStreamSynchronize(ctx->stream));  // the caller's message buffer and the raw staging are free again
   });
   if (rc != MI355_OK) {
@@ -1066,8 +1074,8 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
   mi355_ndt_default_params(&b->np);
   if (params && method == MI355_METHOD_FAST_GICP) b->gp = *(const mi355_gicp_params*)params;
   if (params && method == MI355_METHOD_NDT_OMP) b->np = *(const mi355_ndt_params*)params;
-  b->n_sources = n_sources;
-  b->n_targets = n_targets;
+  b->n_sources = b->alloc_sources = n_sources;
+  b->n_targets = b->alloc_targets = n_targets;
   b->cap = capacity;
   const int rc = guarded(ctx, [&] {
     MI_HIP(hipSetDevice(ctx->device));
@@ -1302,6 +1310,24 @@ extern "C" int mi355_batch_set_side_streams(mi355_batch* b, int mode) {
   });
 }
 
+extern "C" int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    if (n_sources <= 0 || n_sources > b->alloc_sources || n_targets <= 0 || n_targets > b->alloc_targets)
+      throw ArgError(MI355_EINVAL, "mi355_batch_set_live: 1 <= live slots <= the slots given to mi355_batch_create");
+    MI_HIP(hipSetDevice(b->ctx->device));
+    for (auto& sd : b->side)  // nothing of an earlier call may still be running when the slot counts change
+      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    batch_join(b);
+    MI_HIP(hipStreamSynchronize(b->stream()));
+    // every per-cloud / per-pair array is cloud-major, so a smaller batch is a prefix of the allocation
+    b->n_sources = b->src.B = b->gb.S = n_sources;
+    b->n_targets = b->tgt.B = n_targets;
+    if (b->ndt) ndt_batch_set_live(*b->ndt, n_sources, n_targets);
+    b->has_src = b->has_tgt = b->aligned = false;
+  });
+}
+
 extern "C" int mi355_batch_set_timing(mi355_batch* b, int enable) {
   if (!b) return MI355_EINVAL;
   b->timers.enabled = enable != 0;
@@ -1328,6 +1354,6 @@ extern "C" int mi355_batch_kernel_times(mi355_batch* b, mi355_kernel_time* out, 
       n++;
     }
     *n_out = n;
-    b->timers.reset();
+    if (n <= capacity) b->timers.reset();  // a caller whose array was too small asks again with n entries and loses nothing
   });
 }

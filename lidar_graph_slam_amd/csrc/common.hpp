@@ -114,17 +114,23 @@ struct KernelTimers {
   ~KernelTimers() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   }
-  Rec* open(int fam, hipStream_t s) {
+  // returns the record's INDEX (a bracket opened inside another one may grow `recs`), -1 when no event could be created
+  long open(int fam, hipStream_t s) {
     if (used == recs.size()) {
       Rec r{fam, nullptr, nullptr};
-      if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return nullptr;
+      if (hipEventCreate(&r.e0) != hipSuccess) return -1;
+      if (hipEventCreate(&r.e1) != hipSuccess) {
+        (void)hipEventDestroy(r.e0);
+        return -1;
+      }
       recs.push_back(r);
     }
-    Rec* r = &recs[used++];
-    r->fam = fam;
-    (void)hipEventRecord(r->e0, s);
-    return r;
+    const long i = (long)used++;
+    recs[(size_t)i].fam = fam;
+    (void)hipEventRecord(recs[(size_t)i].e0, s);
+    return i;
   }
+  void close(long i, hipStream_t s) { (void)hipEventRecord(recs[(size_t)i].e1, s); }
   // every recorded event must have completed (callers synchronise the streams first)
   void collect() {
     for (size_t i = 0; i < used; i++) {
@@ -139,13 +145,17 @@ struct KernelTimers {
 };
 extern thread_local KernelTimers* g_timers;  // set by the batch entry points while they enqueue work (api.hip)
 struct TimedLaunch {  // RAII bracket around the launches of one family on stream s
-  KernelTimers::Rec* r = nullptr;
+  KernelTimers* t = nullptr;
+  long r = -1;
   hipStream_t s;
   TimedLaunch(int fam, hipStream_t s_) : s(s_) {
-    if (g_timers && g_timers->enabled) r = g_timers->open(fam, s);
+    if (g_timers && g_timers->enabled) {
+      t = g_timers;
+      r = t->open(fam, s);
+    }
   }
   ~TimedLaunch() {
-    if (r) (void)hipEventRecord(r->e1, s);
+    if (r >= 0) t->close(r, s);
   }
 };
 struct TimerScope {

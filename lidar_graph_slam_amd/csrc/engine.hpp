@@ -187,6 +187,7 @@ void ndt_cells(hipStream_t s, NdtTarget& t, int64_t* leaf_idx, int* leaf_n, doub
 struct NdtBatch;
 NdtBatch* ndt_batch_create(int P, int U);
 void ndt_batch_destroy(NdtBatch*);
+void ndt_batch_set_live(NdtBatch& b, int P_live, int U_live);  // register the first P_live pairs against the first U_live targets only
 void ndt_batch_set_target(hipStream_t s, Workspace& ws, NdtBatch& b, int u, const float4* d_pts, size_t n, const mi355_ndt_params& p);
 void ndt_batch_align(hipStream_t s, NdtBatch& b, const float4* d_src, size_t src_cap, const int* h_counts, const int* tgt_of_src_host,
                      const float* guesses_host, const mi355_ndt_params& p);

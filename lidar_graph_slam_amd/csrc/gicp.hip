@@ -140,7 +140,12 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
 
 // e^T M e with the residual in fp64 and the stored fp32 Mahalanobis matrix: y0 (linearize) and yi (compute_error) must
 // resolve cost decreases far below fp32 resolution or the LM rho test degenerates into a coin flip near convergence.
+// fp64 multiply-adds are allowed to fuse here and in residual() (the library is otherwise built with -ffp-contract=off for the
+// fp32 steps whose rounding the parity contract specifies): upstream is Eigen under -O3 -march=native, which fuses as it likes,
+// so there is no contraction pattern to be faithful to, parity of the cost is a tolerance, and the all-trials cost pass is
+// fp64-issue-bound: 83 -> 47 fp64 instructions per trial and pair of points.
 __device__ __forceinline__ double cost64(double ex, double ey, double ez, float mxx, float mxy, float mxz, float myy, float myz, float mzz) {
+#pragma clang fp contract(fast)
   const double a = (double)mxx * ex + (double)mxy * ey + (double)mxz * ez;
   const double b = (double)mxy * ex + (double)myy * ey + (double)myz * ez;
   const double c = (double)mxz * ex + (double)myz * ey + (double)mzz * ez;
@@ -149,6 +154,7 @@ __device__ __forceinline__ double cost64(double ex, double ey, double ez, float 
 
 __device__ __forceinline__ void residual(const Pose& x, const float4& p, const float4& q, float& ax, float& ay, float& az, float& ex, float& ey,
                                          float& ez, double& dex, double& dey, double& dez) {
+#pragma clang fp contract(fast)
   // transed_mean_A = trans * mean_A in fp64 (as upstream); the small residual is then handed to fp32
   const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
   const double dax = x.R[0] * px + x.R[1] * py + x.R[2] * pz + x.t[0];
@@ -1208,6 +1214,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
       }
 #pragma unroll 1
       for (int t = 0; t < nt; t++) {
+#pragma clang fp contract(fast)
         const Pose x = tr[t].xi;  // wave-uniform: scalar loads
         double e = 0.0;
 #pragma unroll

@@ -37,11 +37,13 @@ int LoopClosureCore::candidate(int query) const {
   return min_id;
 }
 
-LoopClosureCore::~LoopClosureCore() {
-  pairwise_.reset();
-  if (batch_) mi355_batch_destroy(batch_);
-  key_frames_.clear();  // device clouds go before the context
+LoopClosureCore::LoopClosureCore(const std::vector<int>& device_ids, const LoopClosureParams& p) : params_(p) {
+  if (device_ids.empty()) throw Error(MI355_EINVAL, "LoopClosureCore needs at least one device");
+  if (p.ransac_iteration != 0) throw Error(MI355_EINVAL, "ransac_iteration: only 0 (no RANSAC rejector, the yaml's value) is built");
+  for (int d : device_ids) lanes_.emplace_back(new LaneState(d));
 }
+
+LoopClosureCore::~LoopClosureCore() = default;  // LaneState: clouds and registration objects go before their lane's context
 
 // double-precision rigid transform from a geometry Pose (what gtsam::Pose3(Rot3::Quaternion, Point3) holds)
 static void pose_to_matrix_d(const Pose& p, double M[16]) {
@@ -58,28 +60,21 @@ static void pose_to_matrix_d(const Pose& p, double M[16]) {
   M[15] = 1.0;
 }
 
-std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) {
-  std::vector<LoopResult> out(queries.size());
-  std::vector<int> cand(queries.size()), uniq;  // uniq: candidate ids that need a sub-map
-  for (size_t i = 0; i < queries.size(); i++) {
-    out[i].query_id = queries[i];
-    cand[i] = candidate(queries[i]);
-    out[i].candidate_id = cand[i];
-    if (cand[i] >= 0 && std::find(uniq.begin(), uniq.end(), cand[i]) == uniq.end()) uniq.push_back(cand[i]);
-  }
-  if (uniq.empty()) return out;
-
-  if (!ctx_) ctx_.reset(new Context(device_id_));
-  auto on_device = [&](int k) -> const DeviceCloud::Ptr& {  // one upload per key frame, ever
-    KeyFrame& kf = key_frames_[(size_t)k];
-    if (!kf.device) kf.device = DeviceCloud::upload(*ctx_, kf.cloud);
-    return kf.device;
+void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows, const std::vector<LoopResult>& out, std::vector<mi355_result>& res,
+                                    std::vector<double>& fit) {
+  Context& ctx = ls.lane.ctx();
+  ls.key_frame.resize(key_frames_.size());
+  auto on_device = [&](int k) -> const DeviceCloud::Ptr& {  // one upload per key frame and lane, ever
+    if (!ls.key_frame[(size_t)k]) ls.key_frame[(size_t)k] = DeviceCloud::upload(ctx, key_frames_[(size_t)k].cloud);
+    return ls.key_frame[(size_t)k];
   };
   // sub-maps (:297-309): key frames min_id - N .. min_id + N, each moved by its own pose, concatenated in index order —
   // transform kernels writing one device cloud per sub-map
   const int n_kf = (int)key_frames_.size();
+  std::vector<int> uniq;  // candidate ids of this lane, in order of first use
+  for (int i : rows)
+    if (std::find(uniq.begin(), uniq.end(), out[(size_t)i].candidate_id) == uniq.end()) uniq.push_back(out[(size_t)i].candidate_id);
   std::vector<DeviceCloud::Ptr> submap(uniq.size());
-  size_t cap = 1;
   for (size_t u = 0; u < uniq.size(); u++) {
     std::vector<DeviceCloud::Ptr> parts;
     std::vector<Matrix4f> poses;
@@ -89,53 +84,50 @@ std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) 
       parts.push_back(on_device(k));
       poses.push_back(geometry_pose_to_matrix(key_frames_[(size_t)k].pose));
     }
-    submap[u] = DeviceCloud::concat(*ctx_, parts, poses, /*carry_covariances=*/false);  // voxel-filtered next: new points
-    cap = std::max(cap, submap[u]->size());
+    submap[u] = DeviceCloud::concat(ctx, parts, poses, /*carry_covariances=*/false);  // voxel-filtered next: new points
   }
   // sources (:248-252): the query key frame moved by its pose
-  std::vector<size_t> src_of;  // rows of `out` that are registered
   std::vector<DeviceCloud::Ptr> source;
-  for (size_t i = 0; i < queries.size(); i++) {
-    if (cand[i] < 0) continue;
-    src_of.push_back(i);
-    source.push_back(on_device(queries[i])->transformed(geometry_pose_to_matrix(key_frames_[(size_t)queries[i]].pose)));
-    cap = std::max(cap, source.back()->size());
+  std::vector<int> tgt_of_src;
+  for (int i : rows) {
+    const int q = out[(size_t)i].query_id;
+    source.push_back(on_device(q)->transformed(geometry_pose_to_matrix(key_frames_[(size_t)q].pose)));
+    tgt_of_src.push_back((int)(std::find(uniq.begin(), uniq.end(), out[(size_t)i].candidate_id) - uniq.begin()));
   }
   const int S = (int)source.size(), U = (int)uniq.size();
-
-  std::vector<mi355_result> res((size_t)std::max(S, batch_S_));
-  std::vector<double> fit((size_t)std::max(S, batch_S_));
+  std::vector<mi355_result> r((size_t)S);
+  std::vector<double> f((size_t)S);
   const mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
   if (params_.registration_method == MI355_METHOD_ICP || params_.registration_method == MI355_METHOD_GICP) {
     // one candidate at a time as the reference does (:315-321), everything device-resident
-    if (!pairwise_ && params_.registration_method == MI355_METHOD_ICP) {
-      auto icp = std::make_shared<IterativeClosestPoint>(*ctx_);
+    if (!ls.pairwise && params_.registration_method == MI355_METHOD_ICP) {
+      auto icp = std::make_shared<IterativeClosestPoint>(ctx);
       icp->setMaxCorrespondenceDistance(30);  // :145-149
       icp->setMaximumIterations(100);
       icp->setTransformationEpsilon(1e-8);
       icp->setEuclideanFitnessEpsilon(1e-6);
-      icp->setRANSACIterations(0);
-      pairwise_ = icp;
-    } else if (!pairwise_) {
-      auto gicp = std::make_shared<GeneralizedIterativeClosestPoint>(*ctx_);
-      gicp->setMaxCorrespondenceDistance(params_.correspondence_distance);  // :133-138
+      icp->setRANSACIterations(0);  // :149 (hard-coded there; the yaml's ransac_iteration is read for "GICP" only)
+      ls.pairwise = icp;
+    } else if (!ls.pairwise) {
+      auto gicp = std::make_shared<GeneralizedIterativeClosestPoint>(ctx);
+      gicp->setMaxCorrespondenceDistance(params_.correspondence_distance);  // :133-139
       gicp->setMaximumIterations(params_.max_iteration);
       gicp->setMaximumOptimizerIterations(params_.max_optimizer_iteration);
       gicp->setTransformationEpsilon(params_.transformation_epsilon);
       gicp->setEuclideanFitnessEpsilon(params_.euclidean_fitness_epsilon);
-      gicp->setRANSACIterations(0);
-      pairwise_ = gicp;
+      gicp->setRANSACIterations(params_.ransac_iteration);  // :131,:139
+      ls.pairwise = gicp;
     }
     std::vector<DeviceCloud::Ptr> filtered((size_t)U);
     for (int u = 0; u < U; u++) filtered[(size_t)u] = submap[(size_t)u]->prefiltered(pf);
     for (int s = 0; s < S; s++) {
-      const size_t u = (size_t)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
-      pairwise_->setInputTarget(filtered[u]);
-      pairwise_->setInputSource(source[(size_t)s]);
-      pairwise_->align(identity4());
-      res[(size_t)s] = pairwise_->result();
-      res[(size_t)s].n_target = (int)filtered[u]->size();
-      fit[(size_t)s] = pairwise_->getFitnessScore();
+      const size_t u = (size_t)tgt_of_src[(size_t)s];
+      ls.pairwise->setInputTarget(filtered[u]);
+      ls.pairwise->setInputSource(source[(size_t)s]);
+      ls.pairwise->align(identity4());
+      r[(size_t)s] = ls.pairwise->result();
+      r[(size_t)s].n_target = (int)filtered[u]->size();
+      f[(size_t)s] = ls.pairwise->getFitnessScore();
     }
   } else {
     mi355_gicp_params gp;
@@ -151,41 +143,54 @@ std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) 
     np.resolution = params_.ndt_resolution;
     np.max_iterations = params_.max_iteration;
     const bool ndt = params_.registration_method == MI355_METHOD_NDT_OMP;
-    if (!batch_ || S > batch_S_ || U > batch_U_ || cap > batch_cap_) {  // grow-only
-      if (batch_) mi355_batch_destroy(batch_);
-      batch_S_ = std::max(S, batch_S_); batch_U_ = std::max(U, batch_U_); batch_cap_ = std::max(cap, batch_cap_);
-      batch_ = mi355_batch_create(ctx_->get(), params_.registration_method, ndt ? (const void*)&np : (const void*)&gp, batch_S_, batch_U_, batch_cap_);
-      if (!batch_) {
-        batch_S_ = batch_U_ = 0;
-        batch_cap_ = 0;
-        throw Error(MI355_EHIP, mi355_last_error(ctx_->get()));
-      }
-      res.resize((size_t)batch_S_);
-      fit.resize((size_t)batch_S_);
-    }
-    mi355_batch* b = batch_;
-    // unused slots of the persistent batch get an empty cloud
-    PointCloud none;
-    DeviceCloud::Ptr empty = DeviceCloud::upload(*ctx_, none);
-    std::vector<mi355_cloud*> th((size_t)batch_U_, empty->get()), sh((size_t)batch_S_, empty->get());
-    for (int u = 0; u < U; u++) th[(size_t)u] = submap[(size_t)u]->get();
-    for (int s2 = 0; s2 < S; s2++) sh[(size_t)s2] = source[(size_t)s2]->get();
-    ctx_->check(mi355_batch_set_targets_clouds(b, th.data(), &pf));
-    ctx_->check(mi355_batch_set_sources_clouds(b, sh.data(), nullptr));
-    std::vector<int> tgt_of_src((size_t)batch_S_, 0);
-    for (int s = 0; s < S; s++)
-      tgt_of_src[(size_t)s] = (int)(std::find(uniq.begin(), uniq.end(), cand[src_of[(size_t)s]]) - uniq.begin());
-    ctx_->check(mi355_batch_align(b, tgt_of_src.data(), nullptr /* align(*output): identity guess, :318 */, /*with_fitness=*/1));
-    ctx_->check(mi355_batch_results(b, res.data(), fit.data()));
+    std::vector<mi355_cloud*> th, sh;
+    for (auto& c : submap) th.push_back(c->get());
+    for (auto& c : source) sh.push_back(c->get());
+    // the lane's batch object outlives close() (grow-only) and runs its live slots only
+    ls.lane.register_batch(params_.registration_method, ndt ? (const void*)&np : (const void*)&gp, ndt ? sizeof(np) : sizeof(gp), sh, th, tgt_of_src,
+                           nullptr /* align(*output): identity guess, :318 */, nullptr, &pf, /*with_fitness=*/true, r.data(), f.data());
   }
-
   for (int s = 0; s < S; s++) {
-    LoopResult& r = out[src_of[(size_t)s]];
-    const mi355_result& m = res[(size_t)s];
+    res[(size_t)rows[(size_t)s]] = r[(size_t)s];
+    fit[(size_t)rows[(size_t)s]] = f[(size_t)s];
+  }
+}
+
+std::vector<LoopResult> LoopClosureCore::close(const std::vector<int>& queries) {
+  std::vector<LoopResult> out(queries.size());
+  std::vector<int> rows, cand_of_row;  // rows of `out` that are registered, and their candidates
+  for (size_t i = 0; i < queries.size(); i++) {
+    out[i].query_id = queries[i];
+    out[i].candidate_id = candidate(queries[i]);
+    if (out[i].candidate_id >= 0) {
+      rows.push_back((int)i);
+      cand_of_row.push_back(out[i].candidate_id);
+    }
+  }
+  if (rows.empty()) return out;
+
+  // deal the registered rows to the lanes by candidate (= sub-map): a sub-map is assembled, filtered and indexed on one lane only
+  std::vector<mi355_result> res(queries.size());
+  std::vector<double> fit(queries.size(), 0.0);
+  const auto shards = shard_by_target(cand_of_row.data(), (int)rows.size(), (int)lanes_.size());
+  std::vector<int> busy;
+  for (int l = 0; l < (int)lanes_.size(); l++)
+    if (!shards[(size_t)l].empty()) busy.push_back(l);
+  for_each_lane(busy, [&](int l) {
+    std::vector<int> mine;
+    for (int k : shards[(size_t)l]) mine.push_back(rows[(size_t)k]);
+    register_rows(*lanes_[(size_t)l], mine, out, res, fit);
+  });
+
+  const int S = (int)rows.size();
+  const std::vector<int>& src_of = rows;
+  for (int s = 0; s < S; s++) {
+    LoopResult& r = out[(size_t)src_of[(size_t)s]];
+    const mi355_result& m = res[(size_t)src_of[(size_t)s]];
     std::copy(m.T, m.T + 16, r.transform.begin());
     r.converged = m.converged != 0;
     r.iterations = m.iterations;
-    r.fitness = fit[(size_t)s];
+    r.fitness = fit[(size_t)src_of[(size_t)s]];
     r.target_points = m.n_target;
     r.accepted = r.converged && !(params_.score_threshold < r.fitness);  // :328
     // :331-340  pose_from = transform * pose(query) through geometry_msgs::Pose, pose_to = pose(candidate)
@@ -256,10 +261,16 @@ extern "C" void mi355_loop_closure_default_params(mi355_loop_closure_params* p) 
   p->ndt_resolution = d.ndt_resolution;
   p->correspondence_distance = d.correspondence_distance;
   p->max_optimizer_iteration = d.max_optimizer_iteration;
+  p->ransac_iteration = d.ransac_iteration;
 }
 
 extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi355_loop_closure_params* p) {
-  if (!p || p->search_key_frame_num < 0 || !(p->submap_leaf >= 0.f)) return nullptr;
+  return mi355_loop_closure_create_multi(&device_id, 1, p);
+}
+
+extern "C" mi355_loop_closure* mi355_loop_closure_create_multi(const int* device_ids, int n_devices, const mi355_loop_closure_params* p) {
+  if (!p || !device_ids || n_devices <= 0 || p->search_key_frame_num < 0 || !(p->submap_leaf >= 0.f)) return nullptr;
+  if (p->ransac_iteration != 0) return nullptr;  // only "no RANSAC rejector" (the yaml's value, graph_based_slam.param.yaml:29) is built
   if (p->registration_method != MI355_METHOD_FAST_GICP && p->registration_method != MI355_METHOD_NDT_OMP && p->registration_method != MI355_METHOD_ICP &&
       p->registration_method != MI355_METHOD_GICP)
     return nullptr;  // unknown strings leave the reference with a null registration too (:153)
@@ -278,8 +289,14 @@ extern "C" mi355_loop_closure* mi355_loop_closure_create(int device_id, const mi
   lp.ndt_resolution = p->ndt_resolution;
   lp.correspondence_distance = p->correspondence_distance;
   lp.max_optimizer_iteration = p->max_optimizer_iteration;
+  lp.ransac_iteration = p->ransac_iteration;
   auto* h = new mi355_loop_closure();
-  h->core.reset(new mi355::LoopClosureCore(device_id, lp));
+  try {
+    h->core.reset(new mi355::LoopClosureCore(std::vector<int>(device_ids, device_ids + n_devices), lp));
+  } catch (const std::exception&) {
+    delete h;
+    return nullptr;
+  }
   return h;
 }
 

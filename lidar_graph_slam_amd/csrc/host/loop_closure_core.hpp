@@ -7,6 +7,7 @@
 #include <memory>
 #include <vector>
 
+#include "lanes.hpp"
 #include "scan_matcher_core.hpp"
 
 namespace mi355 {
@@ -31,6 +32,7 @@ struct LoopClosureParams {  // graph_based_slam.param.yaml:3-23; sub-map leaf ha
   double correspondence_distance = 2.0;    // yaml:26 (GICP)
   int max_optimizer_iteration = 20;        // yaml:23
   double euclidean_fitness_epsilon = 1e-8; // yaml:27
+  int ransac_iteration = 0;                // yaml "ransac_iteration" (setRANSACIterations, :139,:150): only 0 — no rejector — is built
 };
 
 struct LoopResult {
@@ -45,7 +47,10 @@ struct LoopResult {
 
 class LoopClosureCore {
  public:
-  LoopClosureCore(int device_id, const LoopClosureParams& p) : device_id_(device_id), params_(p) {}
+  // device_ids: one lane (context + stream + batch object) per entry; the candidates of one close() are dealt to the lanes by
+  // sub-map (lanes.hpp) and every lane registers its share under its own host thread.  The same ordinal may appear twice.
+  LoopClosureCore(const std::vector<int>& device_ids, const LoopClosureParams& p);
+  LoopClosureCore(int device_id, const LoopClosureParams& p) : LoopClosureCore(std::vector<int>{device_id}, p) {}
   ~LoopClosureCore();
   // key_frame_callback's bookkeeping (:354-380): the cloud is in the key frame's own frame
   int add_key_frame(PointCloud cloud, const Pose& pose, double accum_distance);
@@ -55,18 +60,20 @@ class LoopClosureCore {
   // :282-341 for every query, one batch
   std::vector<LoopResult> close(const std::vector<int>& queries);
   size_t size() const { return key_frames_.size(); }
+  int lanes() const { return (int)lanes_.size(); }
 
  private:
-  int device_id_;
+  struct LaneState {
+    explicit LaneState(int device) : lane(device) {}
+    Lane lane;                                // first member: destroyed last (its context outlives everything below)
+    std::vector<DeviceCloud::Ptr> key_frame;  // this lane's copies: one upload per key frame and lane, by the first close() that needs it
+    std::shared_ptr<Registration> pairwise;   // registration_method == ICP or GICP: one candidate at a time
+  };
+  // one lane's share of a close(): rows of `out` (all with a candidate) -> res / fit at the same positions
+  void register_rows(LaneState& ls, const std::vector<int>& rows, const std::vector<LoopResult>& out, std::vector<mi355_result>& res, std::vector<double>& fit);
   LoopClosureParams params_;
-  std::vector<KeyFrame> key_frames_;   // KeyFrame::device is filled (one upload per key frame) by the first close() that needs it
-  std::unique_ptr<Context> ctx_;       // created by the first close(): the bookkeeping above needs no GPU
-  // the batch object outlives close(): its buffers (tens of GB at 512 candidates) are allocated once and grown only when a
-  // call needs more sources, sub-maps or capacity
-  mi355_batch* batch_ = nullptr;
-  std::shared_ptr<Registration> pairwise_;  // registration_method == ICP or GICP: one candidate at a time
-  int batch_S_ = 0, batch_U_ = 0;
-  size_t batch_cap_ = 0;
+  std::vector<KeyFrame> key_frames_;   // host copies (KeyFrame::cloud); no GPU is touched before the first close()
+  std::vector<std::unique_ptr<LaneState>> lanes_;
 };
 
 }  // namespace mi355

@@ -81,6 +81,7 @@ class DeviceCloud {
     const mi355_cloud_view v = view_of(cloud);
     return wrap(ctx, mi355_cloud_upload(ctx.get(), &v));
   }
+  static Ptr upload_view(Context& ctx, const mi355_cloud_view& v) { return wrap(ctx, mi355_cloud_upload(ctx.get(), &v)); }
   // pcl::transformPointCloud (lidar_scan_matcher.cpp:275-294)
   Ptr transformed(const Matrix4f& T) const { return wrap(ctx_, mi355_cloud_transform(h_, T.data())); }
   // T_0 c_0 ++ T_1 c_1 ++ ... (lidar_scan_matcher.cpp:199-210; graph_based_slam.cpp:297-309)

@@ -657,6 +657,10 @@ NdtBatch* ndt_batch_create(int P, int U) {
   return b;
 }
 void ndt_batch_destroy(NdtBatch* b) { delete b; }
+void ndt_batch_set_live(NdtBatch& b, int P_live, int U_live) {  // arrays are pair-major / target-major: a prefix of the allocation
+  b.P = P_live;
+  b.U = U_live;
+}
 size_t ndt_batch_num_cells(NdtBatch& b, int u) { return ndt_num_cells(*b.targets[(size_t)u]); }
 int ndt_batch_rounds(const NdtBatch& b) { return b.rounds; }
 

@@ -17,7 +17,7 @@ class LoopClosure:
     def __init__(self, search_key_frame_num=20, score_threshold=0.3, search_for_candidate_threshold=15.0, accumulate_distance_threshold=100.0,
                  submap_leaf=0.5, max_iteration=100, transformation_epsilon=0.01, max_correspondence_distance=2.0, correspondence_randomness=20,
                  registration_method="ICP", step_size=0.1, ndt_resolution=1.0, correspondence_distance=2.0, max_optimizer_iteration=20,
-                 device_id=0):
+                 ransac_iteration=0, device_id=0, device_ids=None):
         self._lib = L.lib()
         # graph_based_slam.param.yaml:9 defaults to "ICP" (run pair by pair); "FAST_GICP" / "NDT_OMP" go through one batch.
         # "GICP" (pclomp's BFGS GICP) runs pair by pair like ICP.
@@ -26,10 +26,13 @@ class LoopClosure:
             raise L.Mi355Error(L.EINVAL, f"registration_method {registration_method!r}: FAST_GICP, NDT_OMP, ICP or GICP")
         self.params = L.LoopClosureParams(search_key_frame_num, score_threshold, search_for_candidate_threshold, accumulate_distance_threshold,
                                           submap_leaf, max_iteration, transformation_epsilon, max_correspondence_distance, correspondence_randomness,
-                                          methods[registration_method], step_size, ndt_resolution, correspondence_distance, max_optimizer_iteration)
-        self.handle = self._lib.mi355_loop_closure_create(device_id, C.byref(self.params))
+                                          methods[registration_method], step_size, ndt_resolution, correspondence_distance, max_optimizer_iteration,
+                                          ransac_iteration)
+        # device_ids: one lane per entry (mi355_loop_closure_create_multi); a close() deals its candidates to the lanes by sub-map
+        ids = np.ascontiguousarray([device_id] if device_ids is None else list(device_ids), dtype=np.int32)
+        self.handle = self._lib.mi355_loop_closure_create_multi(ids.ctypes.data, len(ids), C.byref(self.params))
         if not self.handle:
-            raise L.Mi355Error(L.EINVAL, "mi355_loop_closure_create: bad parameters")
+            raise L.Mi355Error(L.EINVAL, "mi355_loop_closure_create: bad parameters (only ransac_iteration = 0 is built)")
 
     def _check(self, rc):
         if rc != L.OK:

@@ -1,0 +1,69 @@
+"""Python handle on mi355_multi_* (include/mi355_lidar.h, csrc/host/multi.cpp): sharded batch registration over several
+devices from ONE process — one context + stream + host thread per device, pairs dealt to devices by sub-map, results gathered
+by D2H.  The logic is C++ below the C-ABI (the loop-closure caller is a C++ node); this file only marshals.  The
+one-process-per-GPU form of the same partition, with the results all-gathered over RCCL, is sharding.py / loop_batch.py."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def shard_by_target(tgt_of_src, n_lanes: int) -> np.ndarray:
+    """lane_of_pair for every pair (the C++ rule; equals sharding.shard_by_target)."""
+    t = np.ascontiguousarray(tgt_of_src, dtype=np.int32)
+    out = np.empty(len(t), dtype=np.int32)
+    rc = L.lib().mi355_multi_shard_by_target(t.ctypes.data, len(t), int(n_lanes), out.ctypes.data)
+    if rc != L.OK:
+        raise L.Mi355Error(rc, "mi355_multi_shard_by_target")
+    return out
+
+
+class MultiDevice:
+    def __init__(self, device_ids=(0,)):
+        self._lib = L.lib()
+        ids = np.ascontiguousarray(list(device_ids), dtype=np.int32)
+        self.handle = self._lib.mi355_multi_create(ids.ctypes.data, len(ids))
+        if not self.handle:
+            raise L.Mi355Error(L.EHIP, f"mi355_multi_create({list(device_ids)}) failed: no such HIP device (there is no CPU fallback)")
+        self.n_devices = self._lib.mi355_multi_device_count(self.handle)
+
+    def batch_register(self, sources, targets, tgt_of_src=None, guesses=None, *, method="FAST_GICP", source_prefilter=None,
+                       target_prefilter=None, with_fitness=True, **params):
+        """sources / targets: lists of float32 [n,4] (or [n,8] PointXYZI-shaped) clouds.  Returns (list of result dicts,
+        fitness array or None, lane_of_pair)."""
+        m = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP}[method]
+        p = L.gicp_params(**params) if m == L.METHOD_FAST_GICP else L.ndt_params(**params)
+        sv = (L.CloudView * len(sources))()
+        tv = (L.CloudView * len(targets))()
+        keep = []
+        for arr, views in ((sources, sv), (targets, tv)):
+            for i, c in enumerate(arr):
+                v, k = L.view(c)
+                views[i] = v
+                keep.append(k)
+        t = None if tgt_of_src is None else np.ascontiguousarray(tgt_of_src, dtype=np.int32)
+        g = None if guesses is None else np.ascontiguousarray(guesses, dtype=np.float32).reshape(len(sources), 16)
+        res = (L.Result * len(sources))()
+        fit = np.zeros(len(sources), dtype=np.float64)
+        lane = np.full(len(sources), -1, dtype=np.int32)
+        rc = self._lib.mi355_multi_batch_register(
+            self.handle, m, C.byref(p), sv, len(sources), tv, len(targets), None if t is None else t.ctypes.data, None if g is None else g.ctypes.data,
+            None if source_prefilter is None else C.byref(source_prefilter), None if target_prefilter is None else C.byref(target_prefilter),
+            1 if with_fitness else 0, res, fit.ctypes.data if with_fitness else None, lane.ctypes.data)
+        if rc != L.OK:
+            raise L.Mi355Error(rc, self._lib.mi355_multi_last_error(self.handle).decode())
+        return [r.to_dict() for r in res], (fit if with_fitness else None), lane
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.mi355_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

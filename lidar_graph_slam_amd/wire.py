@@ -24,9 +24,14 @@ def cloud_from_pointcloud2(msg: dict, ctx: Context | None = None) -> DeviceCloud
             raise ValueError("x, y, z must be FLOAT32 (what every LiDAR driver publishes and pcl::fromROSMsg maps without conversion)")
     raw = np.frombuffer(msg["data"], dtype=np.uint8)
     oi, it = f.get("intensity", (-1, FLOAT32))
+    if raw.size < msg["row_step"] * msg["height"]:
+        raise ValueError(f"PointCloud2 data holds {raw.size} bytes, row_step * height = {msg['row_step'] * msg['height']}")
     m = L.PointCloud2(raw.ctypes.data if raw.size else None, msg["width"], msg["height"], msg["point_step"], msg["row_step"], f["x"][0], f["y"][0],
-                      f["z"][0], oi, it, 1 if msg.get("is_bigendian") else 0)
-    return DeviceCloud(ctx._lib.mi355_cloud_from_pointcloud2(ctx.handle, C.byref(m)), ctx)
+                      f["z"][0], oi, it, 1 if msg.get("is_bigendian") else 0, raw.size)
+    h = ctx._lib.mi355_cloud_from_pointcloud2(ctx.handle, C.byref(m))
+    if not h:
+        raise L.Mi355Error(L.EINVAL, ctx._lib.mi355_last_error(ctx.handle).decode())
+    return DeviceCloud(h, ctx)
 
 
 def cloud_to_pointcloud2(cloud: DeviceCloud) -> dict:

@@ -372,6 +372,8 @@ def pointcloud2_unpack(msg: dict) -> np.ndarray:
         if name not in msg["fields"]:
             continue
         off, dt = msg["fields"][name]
+        if name == "intensity" and dt != 7:
+            continue  # pcl::fromROSMsg maps a field only when its datatype is the point type's (FLOAT32): warns, leaves 0
         size = np.dtype(_PF_DTYPE[dt]).itemsize
         out[:, k] = np.ascontiguousarray(rows[:, off : off + size]).view(_PF_DTYPE[dt])[:, 0].astype(np.float32)
     return out

@@ -10,6 +10,8 @@ full-size inputs and checks it against the oracle on the same inputs and/or agai
   config 5  the per-GPU share of the loop-closure batch (512 candidates, 8 sub-maps, 0.5 m voxel) vs truth, a sample vs the
             oracle (pose and fitness)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -157,13 +159,16 @@ def _cast_for_stream(args):
 def test_config4_at_its_stated_size_1000_scans(ground_max_range):
     """BASELINE configs[3] at its stated length: 1 000 scans x 64 k rays (800 m of path at 0.8 m/scan), key frame 1.0 m,
     window 20, FAST_GICP in the default (reference-arithmetic) mode, through ScanMatcherCore:
-      * scans 0..23 scan by scan against RefScanMatcher registering with the oracle (inside the convergence band),
-      * all 1 000 scans against the ground truth: per-scan error bound, ATE (RMSE of the translation error), key-frame count.
+      * scans 0..23 scan by scan against RefScanMatcher registering with the oracle, live (inside the convergence band),
+      * all 1 000 scans against the ORACLE's trajectory of the same stream (tests/golden/stream1000_gmr*.npz, made by
+        tests/golden/make_stream_golden.py from RefScanMatcher + oracle alone): same converged / key-frame decisions scan for
+        scan, pose inside the band while the two sub-map histories are the same, and the same drift,
+      * all 1 000 scans against the ground truth: drift bound, ATE (RMSE of the translation error), key-frame count.
     ground_max_range = 20 m is the street scene of the 100-scan tests; None keeps the ground returns out to 80 m as SURVEY 8(d)
-    specifies the scene (the rings that trap NDT, tests/test_oracle_ndt.py; GICP tracks through them).  The scans are ray-cast
-    by a pool of spawned CPU workers while the GPU registers."""
+    specifies the scene (the rings that trap NDT, tests/test_oracle_ndt.py; GICP tracks through them - and drifts far less:
+    the ground rings constrain yaw / pitch, 0.08 m after 800 m against 0.6 % of the path without them, oracle and GPU alike).
+    The scans are ray-cast by a pool of spawned CPU workers while the GPU registers."""
     import multiprocessing as mp
-    import os
 
     from lidar_graph_slam_amd.filters import PointsPreFiltering
     from lidar_graph_slam_amd.scan_matcher import LidarScanMatcher
@@ -172,6 +177,9 @@ def test_config4_at_its_stated_size_1000_scans(ground_max_range):
     n = 1000
     length = n * 0.8 + 10.0
     poses = synth.trajectory(n, seed=3)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"stream1000_gmr{'80' if ground_max_range is None else int(ground_max_range)}.npz"))
+    assert int(gold["scans"]) == n
+    same_history = True  # until a converged / key-frame decision differs, GPU and oracle register against the same sub-maps
     pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
     sm = LidarScanMatcher(registration_method="FAST_GICP")
     ref = RefScanMatcher(method="FAST_GICP")
@@ -191,16 +199,37 @@ def test_config4_at_its_stated_size_1000_scans(ground_max_range):
                     parity.assert_in_band(o["pose"], b["pose"], f"config4_1000/gmr{ground_max_range}/scan{i}")
                     assert o["new_key_frame"] == b["new_key_frame"], i
                     assert o["target_points"] == len(ref.target), i
+            assert len(scan) == int(gold["n_points"][i]), i  # the HIP prefilter feeds the stream the oracle's scans
             if o["first_scan"]:
                 continue
             assert o["converged"], i
             n_kf += o["new_key_frame"]
+            # against the oracle's trajectory: identical decisions and in-band poses as long as the histories agree; a single
+            # flipped key-frame decision (a scan sitting on the 1.0 m gate) gives the two streams different sub-maps from then
+            # on, after which they are two valid odometry runs and only their drift is comparable
+            if same_history:
+                bt, br, dt_o, dr_o = parity.deltas(o["pose"], gold["pose"][i])
+                parity._log(f"config4_1000/gmr{ground_max_range}/vs_golden/scan{i}", band_t=bt, band_r=br, dt=dt_o, dr=dr_o, scale=1.0)
+                if bool(gold["new_key_frame"][i]) != o["new_key_frame"] or not gold["converged"][i]:
+                    same_history = False
+                    first_split = i
+                elif not os.environ.get("PARITY_LOG_ONLY"):
+                    assert bt <= parity.BAND_T and br <= parity.BAND_R, (i, bt, br)
             dt, dr = synth.pose_error(o["pose"], np.linalg.inv(poses[0]) @ poses[i])
             err[i] = dt
-            assert dt < 0.05 + 0.003 * (0.8 * i) and dr < 0.02, (i, dt, dr)  # drift bound: 5 cm + 0.3 % of the path
+            dt_gold = synth.pose_error(gold["pose"][i], gold["truth"][i])[0]
+            # drift: at most 1 % of the path (LiDAR odometry without loop closure), and not worse than the oracle's own by more
+            # than a quarter of a percent of the path
+            assert dt < 0.10 + 0.01 * (0.8 * i) and dr < 0.03, (i, dt, dr)
+            assert dt < dt_gold + 0.10 + 0.0025 * (0.8 * i), (i, dt, dt_gold)
     ate = float(np.sqrt(np.mean(err**2)))
-    parity._log(f"config4_1000/gmr{ground_max_range}/summary", ate_m=ate, end_err_m=float(err[-1]), key_frames=n_kf, path_m=0.8 * (n - 1))
-    assert ate < 1.0, ate
+    err_gold = np.array([synth.pose_error(gold["pose"][i], gold["truth"][i])[0] for i in range(n)])
+    ate_gold = float(np.sqrt(np.mean(err_gold**2)))
+    parity._log(f"config4_1000/gmr{ground_max_range}/summary", ate_m=ate, end_err_m=float(err[-1]), key_frames=n_kf, path_m=0.8 * (n - 1),
+                oracle_ate_m=ate_gold, oracle_end_err_m=float(err_gold[-1]), oracle_key_frames=int(gold["new_key_frame"].sum()) - 1,
+                same_history_until_scan=(n if same_history else first_split))
+    assert ate < max(1.25 * ate_gold, ate_gold + 0.05), (ate, ate_gold)
+    assert abs(n_kf - (int(gold["new_key_frame"].sum()) - 1)) <= 5
     assert 420 <= n_kf <= 580, n_kf  # a key frame every 1.0 m of 0.8 m steps: every second scan, +-
     assert o["n_key_frames"] == n_kf + 1 and o["target_points"] > 150_000
 

@@ -53,7 +53,12 @@ def test_batched_loop_closure_matches_restatement(method):
         n_registered += 1
         assert g["target_points"] == w["target_points"]  # same sub-map after the 0.5 m VoxelGrid
         assert g["converged"] == w["converged"] and g["accepted"] == w["accepted"]
-        parity.assert_in_band(g["T"], w["T"], f"loop_closure/{method}/query{g['query_id']}")  # both stop inside the convergence band
+        # both stop inside the convergence band.  pclomp's BFGS GICP ("GICP") evaluates its cost on fp32-transformed points, so f
+        # carries 1e-7 relative noise and PCL's line search ("no progress" exits) ends two correct executions up to two
+        # outer iterations apart: 2 x band for that engine only (measured worst case 14.6 mm, profiles/r03_parity_deltas.txt); its
+        # real gate is the per-outer-iteration parity of test_gpu_gicp_bfgs.py / test_golden.py (2 mm / 2e-4 rad)
+        scale = 2.0 if method == "GICP" else 1.0
+        parity.assert_in_band(g["T"], w["T"], f"loop_closure/{method}/query{g['query_id']}", scale=scale)
         # the fitness the GPU reports is the reference's getFitnessScore at the GPU's own pose
         np.testing.assert_allclose(g["fitness"], O.fitness(w["source"], w["target"], g["T"]), rtol=1e-6)
         # the correction undoes the drift: the corrected pose is the true one
@@ -63,5 +68,5 @@ def test_batched_loop_closure_matches_restatement(method):
         tol_t, tol_r = (0.05, 5e-3) if method in ("FAST_GICP", "GICP") else (0.12, 1.5e-2)
         assert dt < tol_t and dr < tol_r, (method, dt, dr)
         # `between` = key-frame pose^-1 * corrected pose (graph_based_slam.cpp:331-335): the same band seen from the candidate's frame
-        parity.assert_in_band(g["between"], w["between"], f"loop_closure/{method}/between{g['query_id']}")
+        parity.assert_in_band(g["between"], w["between"], f"loop_closure/{method}/between{g['query_id']}", scale=scale)
     assert n_registered >= 4

@@ -32,6 +32,35 @@ def test_shard_by_target_keeps_submaps_together():
         assert max(sizes) - min(sizes) <= 0.15 * 4096 / world + 64
 
 
+def test_the_c_abi_partition_is_the_python_partition():
+    """mi355_multi_shard_by_target (one process, one lane per device: csrc/host/lanes.hpp) and sharding.shard_by_target (one
+    process per GPU) deal the same pairs to the same lane / rank - ties, empty lanes and skewed sub-maps included."""
+    from lidar_graph_slam_amd import multi
+
+    rng = np.random.default_rng(7)
+    cases = [rng.integers(0, 64, 4096), rng.integers(0, 3, 50), np.zeros(9, np.int64), np.arange(17) % 5, np.repeat([4, 1, 9], [7, 7, 7]),
+             (rng.zipf(1.5, 600) % 40)]
+    for tgt in cases:
+        for world in (1, 2, 3, 8):
+            lane = multi.shard_by_target(tgt, world)
+            ref = np.full(len(tgt), -1)
+            for r, idx in enumerate(sharding.shard_by_target(tgt, world)):
+                ref[idx] = r
+            np.testing.assert_array_equal(lane, ref)
+
+
+def test_multi_create_fails_without_a_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lidar_graph_slam_amd import _lib as L
+    from lidar_graph_slam_amd import multi
+
+    with pytest.raises(L.Mi355Error):
+        multi.MultiDevice([0])
+
+
 def _worker(rank, world, port, n_pairs, q):
     import torch.distributed as dist
 

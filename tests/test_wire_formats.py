@@ -42,6 +42,7 @@ def test_pointcloud2_round_trip(layout):
 
     p = _cloud(300)
     n = len(p)
+    expect_intensity_dropped = False
     if layout == "velodyne_xyzir":  # x y z intensity(f32) ring(u16) time(f32): point_step 22, unaligned fields
         ps, fields = 22, {"x": (0, 7), "y": (4, 7), "z": (8, 7), "intensity": (12, 7)}
         w, h, rs = n, 1, 22 * n + 10
@@ -52,6 +53,7 @@ def test_pointcloud2_round_trip(layout):
         ps, fields = 16, {"x": (4, 7), "y": (8, 7), "z": (0, 7), "intensity": (13, 2)}
         w, h, rs = 30, 10, 16 * 30 + 7
         p[:, 3] = np.floor(p[:, 3])
+        expect_intensity_dropped = True  # pcl::fromROSMsg does not convert a UINT8 field into PointXYZI's float: intensity stays 0
     else:
         ps, fields = 12, {"x": (0, 7), "y": (4, 7), "z": (8, 7)}
         w, h, rs = n, 1, 12 * n
@@ -66,7 +68,11 @@ def test_pointcloud2_round_trip(layout):
                 rec[off : off + (4 if dt == 7 else 1)] = np.frombuffer(np.float32(p[i, k]).tobytes() if dt == 7 else np.uint8(p[i, k]).tobytes(), np.uint8)
     msg = {"data": raw.tobytes(), "width": w, "height": h, "point_step": ps, "row_step": rs, "fields": fields, "is_bigendian": False}
     ref = N.pointcloud2_unpack(msg)
+    if expect_intensity_dropped:
+        p[:, 3] = 0
     np.testing.assert_array_equal(ref[~np.isnan(ref)], p[~np.isnan(p)])
+    with pytest.raises(ValueError):  # a message whose data is shorter than row_step * height is refused, not read past its end
+        wire.cloud_from_pointcloud2({**msg, "data": msg["data"][:-1]})
     cloud = wire.cloud_from_pointcloud2(msg)
     got = cloud.download()
     np.testing.assert_array_equal(got, ref)
