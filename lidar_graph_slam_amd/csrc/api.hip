@@ -35,6 +35,8 @@ const Tuning& tuning() {
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
     getf("MI355_GRID_CELL", v.grid_cell);
     geti("MI355_KNN_STATS", v.knn_stats);
+    getf("MI355_BRICK_H", v.brick_h);
+    getf("MI355_BRICK_GATHER", v.brick_gather);
     return v;
   }();
   return t;

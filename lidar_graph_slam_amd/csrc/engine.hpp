@@ -64,6 +64,7 @@ struct CloudSet {
   DevBuf<int> nbr;  // [B*cap*k] k-NN lists (sorted indices) between the search and the covariance kernels
   DevBuf<int> fbq, fbn;  // [B*cap] / [2B] points the tile k-NN hands over to k_knn_hard, their number per cloud (+ the tile counters)
   DevBuf<float> fbhint;  // [B*cap] radius known to hold the k nearest neighbours of a handed-over point (0: unknown)
+  DevBuf<unsigned long long> knn_stats;  // Tuning::knn_stats only: counters of k_knn_cov_brick
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false;

@@ -217,11 +217,12 @@ def test_config4_at_its_stated_size_1000_scans(ground_max_range):
                     assert bt <= parity.BAND_T and br <= parity.BAND_R, (i, bt, br)
             dt, dr = synth.pose_error(o["pose"], np.linalg.inv(poses[0]) @ poses[i])
             err[i] = dt
-            dt_gold = synth.pose_error(gold["pose"][i], gold["truth"][i])[0]
-            # drift: at most 1 % of the path (LiDAR odometry without loop closure), and not worse than the oracle's own by more
-            # than a quarter of a percent of the path
-            assert dt < 0.10 + 0.01 * (0.8 * i) and dr < 0.03, (i, dt, dr)
-            assert dt < dt_gold + 0.10 + 0.0025 * (0.8 * i), (i, dt, dt_gold)
+            dt_gold, dr_gold = synth.pose_error(gold["pose"][i], gold["truth"][i])
+            # drift: at most 1 % of the path and 0.06 rad (LiDAR odometry without loop closure; with the ground cut at 20 m yaw is
+            # weakly observable and the ORACLE ends 5.4 m / 0.036 rad off after 800 m), and not worse than the oracle's own by
+            # more than a quarter of a percent of the path / 5 mrad
+            assert dt < 0.10 + 0.01 * (0.8 * i) and dr < 0.06, (i, dt, dr)
+            assert dt < dt_gold + 0.10 + 0.0025 * (0.8 * i) and dr < dr_gold + 5e-3, (i, dt, dt_gold, dr, dr_gold)
     ate = float(np.sqrt(np.mean(err**2)))
     err_gold = np.array([synth.pose_error(gold["pose"][i], gold["truth"][i])[0] for i in range(n)])
     ate_gold = float(np.sqrt(np.mean(err_gold**2)))
