@@ -50,6 +50,9 @@ ALG_BYTES = {
     "k_voxel_centroids": ("raw point", 32),      # read 16 + write <= 16
     "sort_pairs(k_sort_*)": ("sorted element", 64),  # 4 passes x (8 B read + 8 B written) of (key, index) pairs
     "hash_build(k_count_cells,k_table_clear,k_gather_insert)": ("cloud point", 36),  # read pt 16 + write sorted pt 16 + index 4
+    # --sor only: StatisticalOutlierRemoval, SURVEY 8d: read 16 + mask 1 + compacted 16 per point (priced on the points that SURVIVE
+    # it — the count the batch reports — so a lower bound of the bytes)
+    "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)": ("surviving point", 33),
 }
 TOL_TRUTH_T, TOL_TRUTH_R = 0.015, 1.0e-3   # vs ground truth on the 2 cm-noise scene
 TOL_ORACLE_T, TOL_ORACLE_R = 1.0e-3, 1.0e-4  # vs the oracle on the SAME input, same iteration count
@@ -83,6 +86,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="A/B aid: no HIP events around the kernels (the JSON line then has no roofline block)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--host-inputs", action="store_true", help="hand HOST buffers to the C-ABI every step (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--sor", action="store_true", help="prefilter with the reference's LAUNCH defaults instead of BASELINE's: leaf 0.1 m, StatisticalOutlierRemoval "
+                    "mean_k 30 / stddev 1.2 (points_prefiltering.launch.xml:2-5) - a different workload, never the headline value; its line carries the SOR row")
     args = ap.parse_args()
 
     import torch
@@ -161,7 +166,11 @@ def main():
         streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in batches]  # LM iterations ahead of the (low-priority) indexing chains
         for b_, s_ in zip(batches, streams):
             b_.set_stream(s_.cuda_stream)
-    pre = L.prefilter_params(min_distance=1.0, leaf_size=args.leaf, mean_k=0)
+    if args.sor:
+        args.leaf = 0.1
+        pre = L.prefilter_params(min_distance=1.0, leaf_size=0.1, mean_k=30, stddev_mul=1.2)
+    else:
+        pre = L.prefilter_params(min_distance=1.0, leaf_size=args.leaf, mean_k=0)
     step_no = [0]
     pending = [None] * len(batches)
 
@@ -274,6 +283,7 @@ def main():
         "k_gicp_correspond_tile": float(n_src.sum()) * ktimes.get("k_gicp_correspond_tile", [0, 0])[1] / max(args.steps, 1),
         "k_gicp_error": float(n_src.sum()) * args.iters, "k_knn_cov_tile": n_pts, "k_voxel_centroids": n_raw,
         "sort_pairs(k_sort_*)": n_raw + n_pts, "hash_build(k_count_cells,k_table_clear,k_gather_insert)": n_pts,
+        "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)": n_pts,
     }
     gpu_ms_total = sum(v[0] for v in ktimes.values())
     by_kernel = {}
@@ -353,11 +363,13 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle_py as O
 
+        def cpu_prefilter(c):
+            c = O.voxel_grid(O.distance_filter(c, 1.0), args.leaf)[0]
+            return O.sor(c, 30, 1.2)[0] if args.sor else c
+
         def cpu_pair(k, gp):
             s, t, _ = base[k % N_BASE]
-            s2 = O.voxel_grid(O.distance_filter(s, 1.0), args.leaf)[0]
-            t2 = O.voxel_grid(O.distance_filter(t, 1.0), args.leaf)[0]
-            return O.gicp_align(s2, t2, gp)
+            return O.gicp_align(cpu_prefilter(s), cpu_prefilter(t), gp)
 
         # one process, OpenMP inside a pair: 4 threads = the reference's own configuration (lidar_scan_matcher.param.yaml:10), and
         # 16 (all hardware threads on ONE pair oversubscribe the memory system: 10 pairs/s at 128 vs 24 at 16 in round 1)
@@ -402,7 +414,7 @@ def main():
         # parity on the SAME input: pair 0 of the batch exactly as the GPU saw it (world-transformed), through the oracle
         gp = O.gicp_params(max_iterations=args.iters, force_iterations=1, num_threads=threads)
         s0, t0_ = src_d[0].cpu().numpy(), tgt_d[0].cpu().numpy()
-        ref0 = O.gicp_align(O.voxel_grid(O.distance_filter(s0, 1.0), args.leaf)[0], O.voxel_grid(O.distance_filter(t0_, 1.0), args.leaf)[0], gp)
+        ref0 = O.gicp_align(cpu_prefilter(s0), cpu_prefilter(t0_), gp)
         dt, dr = synth.pose_error(res[0]["T"], ref0["T"])
         if dt > TOL_ORACLE_T or dr > TOL_ORACLE_R:
             raise SystemExit(f"bench.py: GPU pose differs from the oracle's on the same pair by {dt:.2e} m / {dr:.2e} rad "
@@ -444,8 +456,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "inputs": "host buffers (PCIe-inclusive; NOT the headline)" if args.host_inputs else "resident in HBM",
+        **({"not_the_headline": "--sor: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2), not BASELINE configs[1]"} if args.sor else {}),
         "config": {
-            "workload": "BASELINE configs[1]: 64k-pt scan pairs, distance filter 1.0 m + voxel 0.2 m + GICP k=20, exactly 20 LM iterations, batched",
+            "workload": ("BASELINE configs[1]: 64k-pt scan pairs, distance filter 1.0 m + voxel 0.2 m + GICP k=20, exactly 20 LM iterations, batched" if not args.sor else
+                         "64k-pt scan pairs through the reference's launch-file prefilter (distance 1.0 m + voxel 0.1 m + SOR 30 / 1.2) + GICP k=20, exactly 20 LM iterations, batched"),
             "pairs_per_gpu_per_step": P,
             "batches_in_flight": len(batches),
             "raw_points_per_cloud": int(cap),

@@ -10,9 +10,11 @@ using namespace mi355;
 
 namespace mi355 {
 thread_local KernelTimers* g_timers = nullptr;
+thread_local int g_family_override = -1;
 const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
                                                  "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
-                                                 "k_gicp_error", "k_gicp_solve+k_gicp_decide", "k_fitness"};
+                                                 "k_gicp_error", "k_gicp_solve+k_gicp_decide", "k_fitness",
+                                                 "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)"};
 const Tuning& tuning() {
   static const Tuning t = [] {
     Tuning v;

@@ -364,6 +364,21 @@ __device__ __forceinline__ void covariance_of(int k, int method, Cov6* o, P&& po
   *o = cov6_pack((float)r.xx, (float)r.xy, (float)r.xz, (float)r.yy, (float)r.yz, (float)r.zz);
 }
 
+// pcl::StatisticalOutlierRemoval's statistic of one point (P2): the k = mean_k + 1 nearest neighbours include the point itself at
+// distance 0, which PCL skips (`for k = 1 .. mean_k: dist_sum += sqrt(nn_dists[k])`, double accumulation), so the mean over the
+// other mean_k is the sum over all k divided by mean_k.  point(t) returns the t-th neighbour.
+template <int KU, typename P>
+__device__ __forceinline__ float sor_mean_distance(int k, const float4& q, P&& point) {
+  double dist_sum = 0.0;
+#pragma unroll
+  for (int t = 0; t < KU; t++)
+    if (t < k) {
+      const float4 p = point(t);
+      dist_sum += sqrt((double)dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+    }
+  return (float)(dist_sum / (double)(k - 1));
+}
+
 // Steps 1+2, fast path: k-NN and covariance of every point by the wave-cooperative tile search (tile.hpp).  One wave =
 // 64 consecutive points of the Morton-sorted cloud.  The points of the grown tile box are gathered into LDS once; every
 // group of kSubQ consecutive lanes (a SUB-TILE: 16 points that are neighbours in the kd order of the tile) then gets its own list of
@@ -468,12 +483,14 @@ __device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int&
 
 // Launch: one-wave blocks, G per cloud (all on the cloud's XCD); a wave takes tiles from the cloud's counter until none
 // is left, so the waves of a cloud finish together whatever the tiles cost.
-template <int K>
+// SOR = true: the same search for pcl::StatisticalOutlierRemoval (P2) — k = mean_k + 1 neighbours including the point itself, and
+// instead of the covariance the mean of the mean_k non-zero-rank distances goes to mean_dist[] in the caller's point order.
+template <int K, bool SOR>
 __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
-                                                     Cov6* __restrict__ cov, int* __restrict__ queue, float* __restrict__ queue_hint,
-                                                     int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k,
-                                                     int method, int G, int B, float r_scale) {
+                                                     Cov6* __restrict__ cov, float* __restrict__ mean_dist, int* __restrict__ queue,
+                                                     float* __restrict__ queue_hint, int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap,
+                                                     size_t slots_cap, int k, int method, int G, int B, float r_scale) {
   __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
   __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
   int c, bx;
@@ -680,7 +697,11 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         }
         const bool exact = closed && (clear || pair);
         fb = fb || (act && !exact);
-        if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
+        if constexpr (SOR) {
+          if (exact) mean_dist[(size_t)c * cap + g.orig[i]] = sor_mean_distance<K>(k, q, [&](int t) { return cand[keys.v[t] & kOrdMask]; });
+        } else {
+          if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the lists
       }
     }
@@ -943,12 +964,12 @@ __global__ __launch_bounds__(64) void k_knn_cov_brick(const float4* __restrict__
 //      are still needed, lowest caller index first (the oracle's tie rule).
 // The covariance is fused: the k neighbours sit in k lanes, mean and covariance are wave reductions in fp64, and the raw
 // matrices of up to 64 queries are parked in LDS so that the regularisation (the expensive part) runs lane-parallel.
-template <int K>
+template <int K, bool SOR>
 // Occupancy: a query is a chain of dependent phases (cell lookups, two candidate walks, the LDS merge), so resident waves are what
 // hides it: 4 per SIMD (128 VGPRs, 288 B of scratch) 1.36 ms per 1 024-cloud launch, the compiler's own 161 VGPRs (3 waves) 1.68 ms,
 // 5 waves (460 B of scratch) 2.2 ms, 6: 1.67 ms.
 __global__ __launch_bounds__(64, (K <= 32 ? 4 : 1)) void k_knn_hard(const float4* __restrict__ pts, const int* __restrict__ orig, const HashSlot* __restrict__ table,
-                                                 const GridMeta* __restrict__ meta, Cov6* __restrict__ cov, const int* __restrict__ queue,
+                                                 const GridMeta* __restrict__ meta, Cov6* __restrict__ cov, float* __restrict__ mean_dist, const int* __restrict__ queue,
                                                  const float* __restrict__ queue_hint, const int* __restrict__ queue_n, size_t cap, size_t slots_cap,
                                                  int k, int method, int G, int B) {
   __shared__ uint32_t col[K + 1][kWave];  // per-lane sorted distance lists (column = lane)
@@ -1110,6 +1131,11 @@ __global__ __launch_bounds__(64, (K <= 32 ? 4 : 1)) void k_knn_hard(const float4
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
         return v;
       };
+      if constexpr (SOR) {  // the statistic of StatisticalOutlierRemoval instead (see sor_mean_distance)
+        const double ds = wsum((has && mine >= 0) ? sqrt((double)dist2f(q.x, q.y, q.z, p.x, p.y, p.z)) : 0.0);
+        if (lane == 0) mean_dist[(size_t)c * cap + g.orig[i]] = (float)(ds / (double)(k - 1));
+        continue;
+      }
       const double invk = 1.0 / (double)k;
       const double mx = wsum(has ? (double)p.x : 0.0) * invk, my = wsum(has ? (double)p.y : 0.0) * invk, mz = wsum(has ? (double)p.z : 0.0) * invk;
       const double x = has ? (double)p.x - mx : 0.0, y = has ? (double)p.y - my : 0.0, z = has ? (double)p.z - mz : 0.0;
@@ -1147,11 +1173,11 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
   });
 }
 
-template <int K>
-static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) {
+template <int K, bool SOR = false>
+static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, float* mean_dist = nullptr) {
   const int G = div_up((long)set.cap, 256);
   const Tuning& tn = tuning();
-  if (!tn.knn_tiles) {  // per-lane search for every point
+  if (!tn.knn_tiles && !SOR) {  // per-lane search for every point
     hipLaunchKernelGGL(k_knn_self<K>, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.nbr.p, set.cap,
                        set.slots_cap, k, G, set.B, tn.knn_need_div, (const int*)nullptr, (const int*)nullptr);
     hipLaunchKernelGGL(k_cov_from_knn, dim3(xcd_grid(G, set.B)), dim3(256), 0, s, set.pts.p, set.meta.p, set.nbr.p, set.cov.p, set.cap, k, method, G,
@@ -1165,7 +1191,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
   // about two resident waves per SIMD over the whole batch, at least 8 and at most one wave per tile of a cloud
   const int Gt = max(min(tn.tile_waves / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
   unsigned long long* d_stats = nullptr;
-  if (tn.knn_tiles >= 2) {  // cell bricks in LDS (MI355_KNN_TILES=2; measured slower than the sub-tile lists so far: DESIGN 4.4)
+  if (tn.knn_tiles >= 2 && !SOR) {  // cell bricks in LDS (MI355_KNN_TILES=2; measured slower than the sub-tile lists so far: DESIGN 4.4)
     TimedLaunch tl(KF_KNN_COV_TILE, s);
     if (tn.knn_stats) {
       set.knn_stats.ensure(8);
@@ -1181,14 +1207,14 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method) 
     }
   } else {
     TimedLaunch tl(KF_KNN_COV_TILE, s);
-    hipLaunchKernelGGL(k_knn_cov_tile<K>, dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                       set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
+    hipLaunchKernelGGL((k_knn_cov_tile<K, SOR>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
+                       mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
   }
   // the points the tile kernel handed over: one wave per point, covariance included
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
   TimedLaunch tl(KF_KNN_HARD, s);
-  hipLaunchKernelGGL(k_knn_hard<K>, dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                     (const int*)set.fbq.p, (const float*)set.fbhint.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, method, Gh, set.B);
+  hipLaunchKernelGGL((k_knn_hard<K, SOR>), dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
+                     mean_dist, (const int*)set.fbq.p, (const float*)set.fbhint.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, method, Gh, set.B);
   if (tn.knn_stats) {  // tuning aid: how much of the work the tile kernel handed over
     std::vector<int> fbn(set.B), cnt(set.B);
     MI_HIP(hipStreamSynchronize(s));
@@ -1603,19 +1629,30 @@ void sor_filter(hipStream_t s, Workspace& ws, CloudSet& set, const float4* in, c
                 int mean_k, double stddev_mul, float cell, uint8_t* d_keep, float* d_mean_dist) {
   if (mean_k < 1 || mean_k > 63) throw ArgError(MI355_EINVAL, "mean_k must be in [1, 63]");
   if (set.B != B || set.cap != cap) set.alloc(B, cap);
+  FamilyScope family(KF_SOR);
   build_grid(s, ws, in, cnt_in, set, cell);
   ws.fscratch.ensure((size_t)B * cap);
   ws.dscratch.ensure(B);
   float* md = d_mean_dist ? d_mean_dist : ws.fscratch.p;
   const dim3 grid(div_up((long)cap, 256), B);
   const int kk = mean_k + 1;
+  if (tuning().knn_tiles) {
+    // the (mean_k + 1)-NN of every point is the covariance kernels' search with another epilogue: wave-cooperative tiles, the
+    // wave-per-query kernel for what they hand over (round 2 walked the hash per lane here: 0.98 ms for ONE 64 k-ray cloud)
+    if (kk <= 8) launch_covariances<8, true>(s, set, kk, 0, md);
+    else if (kk <= 16) launch_covariances<16, true>(s, set, kk, 0, md);
+    else if (kk <= 32) launch_covariances<32, true>(s, set, kk, 0, md);
+    else launch_covariances<64, true>(s, set, kk, 0, md);
+  } else {
 #define MI_SOR(KK) hipLaunchKernelGGL(k_sor_meandist<KK>, grid, dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, md, cap, set.slots_cap, mean_k)
-  if (kk == 31) MI_SOR(31);
-  else if (kk <= 8) MI_SOR(8);
-  else if (kk <= 16) MI_SOR(16);
-  else if (kk <= 32) MI_SOR(32);
-  else MI_SOR(64);
+    if (kk == 31) MI_SOR(31);
+    else if (kk <= 8) MI_SOR(8);
+    else if (kk <= 16) MI_SOR(16);
+    else if (kk <= 32) MI_SOR(32);
+    else MI_SOR(64);
 #undef MI_SOR
+  }
+  TimedLaunch tl(KF_SOR, s);
   hipLaunchKernelGGL(k_sor_threshold, dim3(B), dim3(1024), 0, s, md, cnt_in, ws.dscratch.p, cap, stddev_mul);
   hipLaunchKernelGGL(k_sor_flags, grid, dim3(256), 0, s, md, cnt_in, ws.dscratch.p, ws.flags.p, d_keep, cap);
   scan_flags(s, ws, B, cap, cnt_in);

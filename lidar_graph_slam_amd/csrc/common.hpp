@@ -104,7 +104,7 @@ const Tuning& tuning();
 // (mi355_batch_set_timing).  The durations are read after the streams have been synchronised (mi355_batch_kernel_times).
 enum KernelFamily : int {
   KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_CORRESPOND_TILE, KF_LINEARIZE, KF_ERROR, KF_SOLVE_DECIDE,
-  KF_FITNESS, KF_COUNT
+  KF_FITNESS, KF_SOR, KF_COUNT
 };
 extern const char* const kKernelFamilyName[KF_COUNT];
 struct KernelTimers {
@@ -147,6 +147,7 @@ struct KernelTimers {
   }
 };
 extern thread_local KernelTimers* g_timers;  // set by the batch entry points while they enqueue work (api.hip)
+extern thread_local int g_family_override;   // >= 0: every bracket opened meanwhile counts for this family (FamilyScope)
 struct TimedLaunch {  // RAII bracket around the launches of one family on stream s
   KernelTimers* t = nullptr;
   long r = -1;
@@ -154,12 +155,17 @@ struct TimedLaunch {  // RAII bracket around the launches of one family on strea
   TimedLaunch(int fam, hipStream_t s_) : s(s_) {
     if (g_timers && g_timers->enabled) {
       t = g_timers;
-      r = t->open(fam, s);
+      r = t->open(g_family_override >= 0 ? g_family_override : fam, s);
     }
   }
   ~TimedLaunch() {
     if (r >= 0) t->close(r, s);
   }
+};
+struct FamilyScope {  // the launches of a composite stage (SOR = sort + hash + k-NN + threshold + compaction) under one name
+  int prev;
+  explicit FamilyScope(int fam) : prev(g_family_override) { g_family_override = fam; }
+  ~FamilyScope() { g_family_override = prev; }
 };
 struct TimerScope {
   KernelTimers* prev;

@@ -1097,9 +1097,19 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
   if (!st->active) return;
   const int l = threadIdx.x;
   if (l < kNAcc) {
+    // (block order: bitwise reproducible.  Unrolled so that the loads of 8 partials are in flight together — one pair alone spent
+    // most of this kernel's 15 us waiting for 32 loads one after the other)
     double s = 0;
     const double* p = partials + (size_t)pair * G * kPartStride + l;
-    for (int g = 0; g < G; g++) s += p[(size_t)g * kPartStride];
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(g + u) * kPartStride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; g < G; g++) s += p[(size_t)g * kPartStride];
     sums[l] = s;
   }
   __syncthreads();
@@ -1274,7 +1284,16 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
   const int l = threadIdx.x;
   if (l < P.lm_max_iterations) {
     double s = 0;
-    for (int g = 0; g < G; g++) s += partials[((size_t)pair * G + g) * kPartStride + kTrialSlot + l];
+    const double* p = partials + (size_t)pair * G * kPartStride + kTrialSlot + l;
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {  // (as in k_gicp_solve: 8 loads in flight, summed in block order)
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(g + u) * kPartStride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; g < G; g++) s += p[(size_t)g * kPartStride];
     yi[l] = s;
   }
   __syncthreads();
