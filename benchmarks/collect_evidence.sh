@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash benchmarks/collect_evidence.sh r01'): everything profiles/README.md cites, written
 # under gpurun_out/<round>/; benchmarks/summarize_evidence.py then distils it into profiles/.
 # rocprofv3 is given the program directly (no env/bash hop) and PMC passes carry --kernel-trace only.
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
@@ -11,6 +11,14 @@ timeout 600 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python bench.py --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.err"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_fetch.err"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_write.err"
+# VALU / LDS / wait counters of the hot kernels at the bench's full batch (two passes: 8 SQ slots each), --kernel-trace only
+G1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY"
+G2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR"
+timeout 600 rocprofv3 --kernel-trace --pmc $G1 --output-format csv -d "$O/pmc_sq1" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_sq1.err"
+timeout 600 rocprofv3 --kernel-trace --pmc $G2 --output-format csv -d "$O/pmc_sq2" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_sq2.err"
+timeout 600 python bench.py --sor --no-cpu-baseline --steps 5 --warmup 2 > "$O/bench_sor.json" 2> "$O/bench_sor.err"
+timeout 300 python benchmarks/single_pair.py > "$O/single_pair.txt" 2>&1
+timeout 300 python benchmarks/stream_profile.py 200 FAST_GICP > "$O/stream_profile.txt" 2>&1
 timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinputs.json" 2> "$O/bench_hostinputs.err"
 timeout 300 python bench.py --inflight 2 --pairs 512 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
 timeout 300 python bench.py --inflight 3 --pairs 512 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"

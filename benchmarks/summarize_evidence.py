@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", R)
 DST = os.path.join(ROOT, "profiles")
 
@@ -48,19 +48,58 @@ def pmc_per_kernel(counter_dir, counter):
     return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
 
 
+def pmc_sq_table():
+    """<round>_pmc_valu.csv: SQ counters per launch and kernel from the two --pmc passes of `python bench.py --steps 1 --warmup 1
+    --no-cpu-baseline` (the bench's full batch), plus the derived instructions per point-lane and issue share."""
+    names = collections.OrderedDict()
+    table = collections.defaultdict(dict)
+    launches = {}
+    for d in ("pmc_sq1", "pmc_sq2"):
+        files = sorted(glob.glob(os.path.join(SRC, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+        if not files:
+            return
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        disp = collections.defaultdict(set)
+        with open(files[-1]) as f:
+            for r in csv.DictReader(f):
+                k = r["Kernel_Name"]
+                if "mi355::" not in k:
+                    continue
+                per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[k].add(r["Dispatch_Id"])
+        for k, v in per.items():
+            launches[k] = len(disp[k])
+            for c, x in v.items():
+                table[k][c] = x / len(disp[k])
+                names[c] = 1
+    cols = list(names)
+    order = sorted(table, key=lambda k: -table[k].get("SQ_BUSY_CYCLES", 0) * launches[k])
+    with open(os.path.join(DST, f"{R}_pmc_valu.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel (per-launch averages; python bench.py --steps 1 --warmup 1 --no-cpu-baseline = 1 024 pairs; two rocprofv3 --pmc passes, "
+                    "--kernel-trace only)", "launches"] + cols + ["VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"])
+        for k in order[:24]:
+            t = table[k]
+            wc = max(t.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+            w.writerow([k[:90], launches[k]] + [round(t.get(c, 0.0), 1) for c in cols] + [round(t.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4), round(t.get("SQ_WAIT_ANY", 0.0) / wc, 4)])
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
     bench = last_json(os.path.join(SRC, "bench_default.json"))
     pairs = bench["config"]["pairs_per_gpu_per_step"]
-    for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu"):
+    for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu",
+                 "bench_sor"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p):
             with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:
                 f.write(json.dumps(last_json(p)) + "\n")
     shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(DST, f"{R}_kernel_stats_bench_default.csv"))
-    oc = os.path.join(SRC, "other_configs.txt")
-    if os.path.exists(oc):
-        shutil.copy(oc, os.path.join(DST, f"{R}_other_configs.txt"))
+    for txt in ("other_configs", "single_pair", "stream_profile"):
+        oc = os.path.join(SRC, txt + ".txt")
+        if os.path.exists(oc):
+            shutil.copy(oc, os.path.join(DST, f"{R}_{txt}.txt"))
+    pmc_sq_table()
     fetch = pmc_per_kernel("pmc_fetch", "FETCH_SIZE")
     write = pmc_per_kernel("pmc_write", "WRITE_SIZE")
     rows = []

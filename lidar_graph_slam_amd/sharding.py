@@ -37,10 +37,11 @@ def shard_by_target(tgt_of_src, world: int):
     return out
 
 
-def gather_rows(local_idx, rows, n_total: int, group=None) -> np.ndarray:
+def gather_rows(local_idx, rows, n_total: int, group=None, force_collective: bool = False) -> np.ndarray:
     """All-gather fixed-size per-pair records: `rows` is [n_local, C] float64 for the global pair indices `local_idx`; returns
     [n_total, C] on every rank (NaN rows for pairs nobody reported).  Ragged shards are padded to the largest one — the payload
-    is tiny (<= 20 doubles per pair), so ONE all_gather over RCCL / xGMI is the whole exchange step of the path."""
+    is tiny (<= 20 doubles per pair), so ONE all_gather over RCCL / xGMI is the whole exchange step of the path.
+    force_collective: run the all_gather even in a one-rank group (a probe that the backend executes it)."""
     import torch
     import torch.distributed as dist
 
@@ -50,7 +51,7 @@ def gather_rows(local_idx, rows, n_total: int, group=None) -> np.ndarray:
         rows = rows.reshape(len(local_idx), -1) if len(local_idx) else np.zeros((0, 0))
     C = rows.shape[1]
     out = np.full((n_total, C), np.nan)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         out[local_idx] = rows
         return out
     world = dist.get_world_size(group)

@@ -32,3 +32,24 @@ def test_two_ranks_register_their_shards_and_gather():
     # sharding must not change any result: same acceptance and accuracy as the single-rank run
     for k in ("accepted(fitness<0.3)", "within_5cm_of_truth", "median_pose_err_m", "mean_iterations"):
         assert two[k] == one[k], (k, two[k], one[k])
+
+
+def test_rccl_executes_the_gather_in_a_one_rank_group():
+    """`sharding.gather_rows` / `max_over_ranks` on their `nccl` branch: device tensors, all_gather + all_reduce through RCCL.  The pool's
+    boxes have ONE GPU, so the communicator has one rank (benchmarks/rccl_probe.py forces the collective that a one-rank group would skip)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(29900 + (os.getpid() % 90)))
+    r = subprocess.run([sys.executable, "benchmarks/rccl_probe.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK world=1 backend=nccl" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_rccl_with_two_ranks_needs_two_devices():
+    """Why the two-rank test above gathers over gloo: RCCL refuses two ranks on one device ("Duplicate GPU detected").  If a future RCCL
+    accepts them the probe must simply succeed."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), "benchmarks/rccl_probe.py"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode == 0:
+        assert "RCCL_OK world=2" in r.stdout
+    else:
+        assert "Duplicate GPU detected" in r.stderr + r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
