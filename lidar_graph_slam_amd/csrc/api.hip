@@ -34,6 +34,7 @@ const Tuning& tuning() {
     geti("MI355_KNN_NEED_DIV", v.knn_need_div);
     geti("MI355_TILE_WAVES", v.tile_waves);
     getf("MI355_TILE_RSCALE", v.tile_rscale);
+    getf("MI355_TILE_GATHER", v.tile_gather);
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
     getf("MI355_GRID_CELL", v.grid_cell);
     geti("MI355_KNN_STATS", v.knn_stats);

@@ -485,12 +485,14 @@ __device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int&
 // is left, so the waves of a cloud finish together whatever the tiles cost.
 // SOR = true: the same search for pcl::StatisticalOutlierRemoval (P2) — k = mean_k + 1 neighbours including the point itself, and
 // instead of the covariance the mean of the mean_k non-zero-rank distances goes to mean_dist[] in the caller's point order.
-template <int K, bool SOR>
+template <int K, bool SOR, bool STATS = false>
 __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
                                                      Cov6* __restrict__ cov, float* __restrict__ mean_dist, int* __restrict__ queue,
                                                      float* __restrict__ queue_hint, int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap,
-                                                     size_t slots_cap, int k, int method, int G, int B, float r_scale) {
+                                                     size_t slots_cap, int k, int method, int G, int B, float r_scale, float gather_scale,
+                                                     unsigned long long* __restrict__ stats = nullptr) {
+  int st_tiles = 0, st_segs = 0, st_rounds = 0, st_gathers = 0, st_cands = 0, st_build = 0, st_rank = 0, st_direct = 0;  // STATS only
   __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
   __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
   int c, bx;
@@ -505,7 +507,8 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   int tile = 0;
   if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
   const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
-  if (tile0 >= n) return;
+  if (tile0 >= n) break;
+  if constexpr (STATS) st_tiles++;
   int i = tile0 + lane;
   float4 q = g.pts[min(i, n - 1)];
   if (i >= n) q.x = q.y = q.z = INFINITY;  // past the end of the cloud: sorts to the last lanes, never active
@@ -520,6 +523,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
     const int nact = __popcll(__ballot(act));
     bool split = false;
     if (nact > 0) {
+      if constexpr (STATS) st_segs++;
       const TileBox bb = tile_bounds(act, q.x, q.y, q.z);
       const float eps = tile_eps(bb, rcap);
       float r0, e_max;  // first radius: k-NN radius of a surface with the segment's own point density
@@ -557,14 +561,19 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
       float R = -1.f;
       bool has_old = false, open = act;
       for (int round = 0;; round++) {
+        if constexpr (STATS) st_rounds++;
         // ---- tile list: grow the gathered box to the largest radius a working sub-tile asks for
-        const float Rn = uniform_f(wave_max_all(take ? rs : 0.f));
-        if (Rn > R) {
+        // (the FIRST gather reaches gather_scale x further than the sub-tiles ask for: a round is a chain of dependent loads - 64 hash
+        // probes, then the cell ranges - that two waves per SIMD cannot hide, and most tiles came back for a second one)
+        const float Rw = uniform_f(wave_max_all(take ? rs : 0.f));
+        const float Rn = (has_old || !(Rw > R)) ? Rw : fminf(gather_scale * Rw, rcap);
+        if (Rw > R) {
+          if constexpr (STATS) st_gathers++;
           const TileBox nb = grow(bb, Rn);
           const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
           const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
           if (n_new < 0) {  // over a budget: split the segment if nothing has been gathered yet, else hand the open lanes over
-            if (!has_old && Rn > rmin && Rn > 0.5f * e_max) {
+            if (!has_old && Rw > rmin && Rn > 0.5f * e_max) {
               // clustered points (far field): the density guess overshoots and the radius, not the segment's own extent,
               // makes the box too big - start smaller, the rounds grow it back where needed
               rs = fmaxf(0.5f * rs, rmin);
@@ -578,11 +587,13 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           ob = nb;
           has_old = true;
           R = Rn;
+          if constexpr (STATS) st_cands += n_new - n_ord;
           n_ord = n_new;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
         }
         bool redo = false;
         if (direct) {
+          if constexpr (STATS) st_direct += n_ord - n_done;
 #pragma unroll 4
           for (int o = n_done; o < n_ord; o++) {
             const float4 p = cand[o];
@@ -597,6 +608,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           // sub-tile its 8 hit bits, and the hits are appended to the sub-tile's list in candidate order.
           // (four steps per trip: the four LDS reads and box tests are independent, only the list offsets chain)
           for (int base = 0; base < n_ord; base += 4 * kSubQ) {
+            if constexpr (STATS) st_build++;
             bool in[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -631,6 +643,7 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
           const int from = sdone, to = slen;
           sdone = to;
           const int trip = wave_max_all_i(to - from);
+          if constexpr (STATS) st_rank += trip;
           const uint16_t* mine = sub[mysub] + from;
           const int cnt = to - from;
 #pragma unroll 4
@@ -723,6 +736,14 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
     }
   }
   }  // next tile
+  if constexpr (STATS) {
+    if (stats && lane == 0) {
+      atomicAdd(&stats[0], (unsigned long long)st_tiles); atomicAdd(&stats[1], (unsigned long long)st_segs);
+      atomicAdd(&stats[2], (unsigned long long)st_rounds); atomicAdd(&stats[3], (unsigned long long)st_gathers);
+      atomicAdd(&stats[4], (unsigned long long)st_cands); atomicAdd(&stats[5], (unsigned long long)st_build);
+      atomicAdd(&stats[6], (unsigned long long)st_rank); atomicAdd(&stats[7], (unsigned long long)st_direct);
+    }
+  }
 }
 
 // ---- the same by LDS-STAGED CELL BRICKS (round 3) ----------------------------------------------------------------------------
@@ -1205,10 +1226,23 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
                          set.cov.p, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
                          tn.brick_h, tn.brick_gather, (unsigned long long*)nullptr);
     }
+  } else if (tn.knn_stats && !SOR) {
+    set.knn_stats.ensure(8);
+    MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 8 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((k_knn_cov_tile<K, SOR, true>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
+                       mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
+                       tn.tile_gather, set.knn_stats.p);
+    MI_HIP(hipStreamSynchronize(s));
+    unsigned long long st[8];
+    MI_HIP(hipMemcpy(st, set.knn_stats.p, sizeof(st), hipMemcpyDeviceToHost));
+    const double tiles = (double)std::max(st[0], 1ull);
+    fprintf(stderr, "[mi355] k-NN sub-tile lists per tile: %.2f segments, %.2f rounds, %.2f gathers, %.0f candidates gathered, %.1f build trips (x 4 x 16 box tests), "
+            "%.1f rank steps per lane (+ %.1f direct)\n", st[1] / tiles, st[2] / tiles, st[3] / tiles, st[4] / tiles, st[5] / tiles, st[6] / tiles, st[7] / tiles);
   } else {
     TimedLaunch tl(KF_KNN_COV_TILE, s);
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
-                       mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale);
+                       mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
+                       tn.tile_gather);
   }
   // the points the tile kernel handed over: one wave per point, covariance included
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
