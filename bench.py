@@ -185,7 +185,7 @@ def main():
         batch = batches[k]
         out = None
         if pending[k]:
-            out = batch.results()  # waits for that batch's stream only
+            out = batch.results(raw=True)  # waits for that batch's stream only; the poses of all pairs, in host memory
             collect(batch)
             pending[k] = None
         if args.host_inputs:
@@ -206,7 +206,7 @@ def main():
         out = None
         for k, batch in enumerate(batches):
             if pending[k]:
-                out = batch.results()
+                out = batch.results(raw=True)
                 collect(batch)
                 pending[k] = None
         return out
@@ -263,10 +263,10 @@ def main():
     for p in range(P):
         W = world_T[p].astype(np.float64)
         T_expected = W @ base[p % N_BASE][2] @ np.linalg.inv(W)
-        errs.append(synth.pose_error(res[p]["T"], T_expected))
+        errs.append(synth.pose_error(res["T"][p], T_expected))
     errs = np.array(errs)
-    n_src = np.array([r["n_source"] for r in res])
-    n_tgt = np.array([r["n_target"] for r in res])
+    n_src = np.asarray(res["n_source"])
+    n_tgt = np.asarray(res["n_target"])
 
     if rank != 0:
         if world > 1:
@@ -415,7 +415,7 @@ def main():
         gp = O.gicp_params(max_iterations=args.iters, force_iterations=1, num_threads=threads)
         s0, t0_ = src_d[0].cpu().numpy(), tgt_d[0].cpu().numpy()
         ref0 = O.gicp_align(cpu_prefilter(s0), cpu_prefilter(t0_), gp)
-        dt, dr = synth.pose_error(res[0]["T"], ref0["T"])
+        dt, dr = synth.pose_error(res["T"][0], ref0["T"])
         if dt > TOL_ORACLE_T or dr > TOL_ORACLE_R:
             raise SystemExit(f"bench.py: GPU pose differs from the oracle's on the same pair by {dt:.2e} m / {dr:.2e} rad "
                              f"(tolerance {TOL_ORACLE_T} m / {TOL_ORACLE_R} rad)")

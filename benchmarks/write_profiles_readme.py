@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerate profiles/README.md from the committed profiles/<round>_* files (after summarize_evidence.py).
 
-usage: python benchmarks/write_profiles_readme.py r02 [gpurun_out/r02/bench_serial_streams.json]
+usage: python benchmarks/write_profiles_readme.py r03
 """
 import csv
 import json
@@ -9,8 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
-SERIAL = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", R, "bench_serial_streams.json")
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(ROOT, "profiles")
 
 NOTES = {
@@ -21,105 +20,138 @@ NOTES = {
     "sort_pairs(k_sort_*)": "in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
     "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order): one gather per lane, runs handed to their head lane by shuffles",
     "k_gicp_linearize": "F4, streaming: 80 algorithmic B per source point",
-    "k_gicp_error": "F5: all 10 LM trial costs in one pass",
+    "k_gicp_error": "F5: all 10 LM trial costs in one pass (fp64, FMAs fused since round 3)",
     "hash_build(k_count_cells,k_table_clear,k_gather_insert)": "multi-level voxel hash sized to the occupied cells",
     "k_gicp_solve+k_gicp_decide": "partials -> H, b -> all LM trial poses; accept / reject walk",
 }
 
 
 def load(name):
-    return json.load(open(os.path.join(P, f"{R}_{name}.json")))
+    with open(os.path.join(P, f"{R}_{name}.json")) as f:
+        return json.load(f)
+
+
+def maybe(name):
+    p = os.path.join(P, f"{R}_{name}.json")
+    return json.load(open(p)) if os.path.exists(p) else None
 
 
 def main():
-    b, tr, hi, i2, i3, p128, tj = (load(n) for n in ("bench_default", "bench_under_trace", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "traffic"))
-    ser = json.load(open(SERIAL)) if os.path.exists(SERIAL) else None
+    b, tr, tj = load("bench_default"), load("bench_under_trace"), load("traffic")
+    hi, i2, i3, p128, ser, sor = (maybe(n) for n in ("bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_serial_streams", "bench_sor"))
     rows = list(csv.DictReader(open(os.path.join(P, f"{R}_kernel_stats_bench_default.csv"))))
     tot_ns = sum(float(x["TotalDurationNs"]) for x in rows)
     rf, cpu, e2e = b["roofline"], b["cpu_baseline"], b["roofline"]["end_to_end"]
     pairs = b["config"]["pairs_per_gpu_per_step"]
     dom = rf["kernel"]
-    top = rows[0]
-    out = f"""# profiles/ — round 2 (MI355X, gfx950, ROCm 7.2)
+    top = next(x for x in rows if dom in x["Name"])
+    live = rf["timed_region_event_brackets"]
+    one = cpu["one_process"]["pairs_per_s_by_omp_threads"]
+    out = f"""# profiles/ — round 3 (MI355X, gfx950, ROCm 7.2)
 
 Everything here comes from ONE command family on a fresh 1-GPU box — `python bench.py` (defaults: {pairs} pairs per step = per
 batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel 0.2 m, k = 20, exactly
-20 LM iterations) — run by
-`benchmarks/collect_evidence.sh {R}` and distilled by `benchmarks/summarize_evidence.py` / `write_profiles_readme.py`.
-The `r01_*` files are round 1's, kept for the history.
+20 LM iterations) — run by `benchmarks/collect_evidence.sh {R}` and distilled by `benchmarks/summarize_evidence.py` /
+`write_profiles_readme.py`.  The `r01_*` / `r02_*` files are the earlier rounds', kept for the history.
 
 | file | what |
 |---|---|
-| `{R}_bench_default.json` | the JSON line of `python bench.py`: **{b['value']:.0f} pairs/s**, {b['ms_per_step']:.1f} ms/step; `roofline` on `{dom}` (frac {rf['frac']:.4f}), `roofline.end_to_end` {e2e['frac']:.3f}; `cpu_baseline` {cpu['pairs_per_s_by_threads']} pairs/s by OpenMP threads on {cpu['cpu_model']} |
+| `{R}_bench_default.json` | the JSON line of `python bench.py`: **{b['value']:.0f} pairs/s**, {b['ms_per_step']:.1f} ms/step; `roofline` on `{dom}` (frac {rf['frac']:.4f}), `roofline.end_to_end` {e2e['frac']:.3f}; `cpu_baseline` {cpu['value']:.1f} pairs/s on all {cpu['cores']} hardware threads of the host ({cpu['cpu_model']}) |
 | `{R}_kernel_stats_bench_default.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline` (its bench line: `{R}_bench_under_trace.json`, {tr['value']:.0f} pairs/s) |
 | `{R}_pmc_fetch_write.csv` | per-kernel HBM traffic from two separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE …` / `--pmc WRITE_SIZE …` of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` |
 | `{R}_traffic.json` | the `{tj['kernel']}` row of the above (FETCH_SIZE × 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), read by `bench.py` into `roofline.traffic` |
+| `{R}_pmc_valu.csv` | SQ counters per launch of every hot kernel at the bench's full batch ({pairs} pairs): `SQ_INSTS_VALU`, `SQ_ACTIVE_INST_VALU`, `SQ_INSTS_LDS`, `SQ_WAIT_ANY`, `SQ_WAVE_CYCLES`, `SQ_LDS_BANK_CONFLICT` … from two `--pmc` passes (`--kernel-trace` only) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` |
+| `{R}_knn_tile_counters.txt` | the k-NN tile kernel's own per-tile counters (`MI355_KNN_STATS=1`): segments, rounds, gathers, candidates, build trips, rank steps per lane |
+| `{R}_knn_brick_ab.txt`, `{R}_corr_brick_ab.txt`, `{R}_knn_tile_gather_ab.txt` | A/B logs of this round's kernel experiments that did NOT pay (cell bricks for the k-NN and for the correspondence tiles, a wider first gather): DESIGN §4.4 |
+| `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |
+| `{R}_bench_sor.json` | `python bench.py --sor`: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2) over the same {pairs}-pair batch — a different workload, never the headline; carries the SOR row |
 | `{R}_bench_hostinputs.json` | `python bench.py --host-inputs`: HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
-| `{R}_bench_inflight2.json` | `python bench.py --inflight 2 --pairs 512`: two batch objects on two streams used alternately, the memory of the default |
-| `{R}_bench_inflight3.json` | `python bench.py --inflight 3 --pairs 512` |
+| `{R}_bench_inflight2.json`, `{R}_bench_inflight3.json` | `python bench.py --inflight 2 / 3 --pairs 512`: batch objects on their own streams used alternately, the memory of the default |
 | `{R}_bench_serial_streams.json` | the default with `MI355_BATCH_SIDE_STREAMS=0`: the preparation chains one after the other |
 | `{R}_bench_128pairs.json` | `python bench.py --pairs 128` |
-| `{R}_other_configs.txt` | `python benchmarks/other_configs.py --scans 200`: the BASELINE configs that are not the bench line |
+| `{R}_other_configs.txt`, `{R}_single_pair.txt`, `{R}_stream_profile.txt` | the BASELINE configs that are not the bench line (`benchmarks/other_configs.py --scans 200`), one 64 k pair, a 200-scan odometry stream |
 
 ## The roofline block, recomputed from these files
 
-* dominant kernel family = the one with the largest isolated duration × launches per step: **`{dom}`** — also the top row of
+* dominant kernel family = the one with the largest own duration × launches per step: **`{dom}`** — also the top row of
   `{R}_kernel_stats_bench_default.csv` (`{top['Name'].split('(')[0].replace('void ', '')}`, {100 * float(top['TotalDurationNs']) / tot_ns:.1f} % of the kernel time).
 * algorithmic bytes per launch = 40 B per cloud point (16 B point read + 24 B covariance written, SURVEY §8d) × Σ points of the
   {pairs} clouds of a launch = **{rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB**;
-* mean launch duration: **{rf['avg_launch_ms']:.2f} ms** from HIP events on the launching stream inside `bench.py` ({rf['launches']} launches);
-  **{float(top['AverageNs']) / 1e6:.2f} ms** in the rocprofv3 kernel trace of the same command ({top['Calls']} launches: the warm-up and timed steps plus the 4 isolated launches
-  after the timed region, which pull the trace's average down) — they agree.  Both are durations
-  WHILE THE KERNEL SHARES THE GPU (targets and sources are indexed on two streams at the same time: two `{dom}` launches overlap); by itself
-  — `roofline.isolated`, two extra steps of one batch after the timed region — a launch takes **{rf['isolated']['avg_launch_ms']:.2f} ms = {100 * rf['isolated']['frac']:.2f} % of HBM peak**;
-* achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound, the
-  HBM roofline is simply the wrong ceiling for it, and the bench says so instead of picking a flattering kernel;
+* launch duration: **{rf['avg_launch_ms']:.2f} ms** — HIP events on the launching stream inside `bench.py`, around {rf['launches_measured']} launches that have the GPU
+  to themselves (two extra steps after the timed region, preparation chains serialised); **{float(top['AverageNs']) / 1e6:.2f} ms** average over the {top['Calls']} launches
+  of the rocprofv3 kernel trace of the same command (min {float(top['MinNs']) / 1e6:.2f}, max {float(top['MaxNs']) / 1e6:.2f}) — the two agree.  The event brackets of the TIMED
+  region sit on two concurrent side streams and read {live['avg_ms']:.2f} ms: that includes the time a launch waits for the other chain's k-NN to free
+  the CUs (both need 18 KB of LDS per wave) — a queueing figure, reported as `roofline.timed_region_event_brackets`, never used for `frac`;
+* achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound
+  (`{R}_pmc_valu.csv`), the HBM roofline is simply the wrong ceiling for it, and the bench says so instead of picking a flattering kernel;
 * PMC traffic per launch: FETCH_SIZE {tj['fetch_size_kb_raw'] / 1e3:.0f} MB raw × 2 + WRITE_SIZE {tj['write_size_kb'] / 1e3:.0f} MB = **{tj['hbm_bytes_per_launch'] / 1e6:.0f} MB = {tj['hbm_bytes_per_launch'] / rf['algorithmic_bytes_per_launch']:.2f} × algorithmic**
-  (the ×2 is the guide's correction for streaming reads; for this kernel's gathers it is an upper bound).  The writes are the
-  24-B covariances plus the hand-over queue; the reads are the tile gathers, each point fetched by every tile whose grown box holds it;
+  (the ×2 is the guide's correction for streaming reads; for this kernel's gathers it is an upper bound);
 * `roofline.end_to_end`: algorithmic bytes of the whole step ({e2e['algorithmic_bytes_per_step'] / 1e9:.2f} GB: prefilter 32 B/raw point, covariances 40 B/point,
   GICP 80 B/source point/iteration) ÷ {b['ms_per_step']:.1f} ms ÷ 8 TB/s = **{e2e['frac']:.3f}**.
 
 ## Where the step goes ({pairs} pairs/step)
 
-HIP-event totals per kernel family (`roofline.by_kernel`).  Targets and sources are prepared on two concurrent streams, so the
-durations of the kernels overlap (their sum exceeds the step); the isolated column is the same kernel with nothing beside it.
+HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel with nothing beside it (the rocprofv3-agreeing duration);
+"timed region" = brackets on the two concurrent preparation streams (they overlap: their sum exceeds the step).
 
-| kernel family | launches/step | live: ms/step (avg per launch) | isolated: ms per launch | frac of HBM peak, isolated (algorithmic bytes) | note |
-|---|---|---|---|---|---|
+| kernel family | launches/step | own: ms per launch | × launches = ms/step | frac of HBM peak, own (algorithmic bytes) | timed-region bracket ms/step | note |
+|---|---|---|---|---|---|---|
 """
     order = sorted(rf["by_kernel"].items(), key=lambda kv: -kv[1].get("isolated_avg_launch_ms", kv[1]["avg_launch_ms"]) * kv[1]["launches_per_step"])
+    total_own = 0.0
     for name, v in order:
         frac = v.get("isolated_frac_of_hbm_peak")
-        iso = v.get("isolated_avg_launch_ms")
-        out += (f"| `{name}` | {v['launches_per_step']:.0f} | {v['total_ms_per_step']:.2f} ({v['avg_launch_ms']:.3f}) | "
-                + (f"{iso:.3f} | " if iso is not None else "– | ") + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {NOTES.get(name, '')} |\n")
+        iso = v.get("isolated_avg_launch_ms", v["avg_launch_ms"])
+        total_own += iso * v["launches_per_step"]
+        out += (f"| `{name}` | {v['launches_per_step']:.0f} | {iso:.3f} | {iso * v['launches_per_step']:.2f} | "
+                + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {v['total_ms_per_step']:.2f} | {NOTES.get(name, '')} |\n")
+    out += f"\nSum of the own durations: {total_own:.1f} ms against {b['ms_per_step']:.1f} ms per step (the two preparation chains overlap a little).\n"
     if ser:
-        out += f"\nOne batch of 1 024 pairs with the preparation chains serialised (`{R}_bench_serial_streams.json`): {ser['ms_per_step']:.1f} ms/step.\n"
-    by_threads = ", ".join(f"{t} threads: {v}" for t, v in cpu["pairs_per_s_by_threads"].items())
-    oc = open(os.path.join(P, f"{R}_other_configs.txt")).read()
-    ocj = json.loads(oc)
+        out += f"One batch of {pairs} pairs with the preparation chains serialised (`{R}_bench_serial_streams.json`): {ser['ms_per_step']:.1f} ms/step.\n"
+    oc_path = os.path.join(P, f"{R}_other_configs.txt")
+    ocj = json.loads(open(oc_path).read()) if os.path.exists(oc_path) else {}
+    sp = open(os.path.join(P, f"{R}_single_pair.txt")).read().strip().replace("\n", "; ") if os.path.exists(os.path.join(P, f"{R}_single_pair.txt")) else ""
+    stp = open(os.path.join(P, f"{R}_stream_profile.txt")).read().strip().splitlines()[-1] if os.path.exists(os.path.join(P, f"{R}_stream_profile.txt")) else ""
     out += f"""
 ## Other measurements of the round
 
 | what | value |
 |---|---|
-| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 1: 11 572; boxes of the pool differ by a few per cent) |
-| `--inflight 2 --pairs 512` (two batches in flight, the same memory) | {i2['value']:.0f} pairs/s — the LM iterations of one batch overlap the indexing of the next; HIP-event brackets then include waiting for the other stream, so the default stays unpipelined |
-| `--inflight 3 --pairs 512` | {i3['value']:.0f} pairs/s |
-| `--pairs 128` | {p128['value']:.0f} pairs/s |
-| `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |
-| CPU oracle on the same host ({cpu['cpu_model']}, {cpu['host_hw_threads']} hardware threads) | {by_threads} pairs/s; `cpu_baseline.value` is the {cpu['cores']}-thread figure, 4 threads is the reference's configuration (`lidar_scan_matcher.param.yaml:10`) |
+| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 2: 14 383, round 1: 11 572; boxes of the pool differ by a few per cent) |
+"""
+    if i2:
+        out += f"| `--inflight 2 --pairs 512` (two batches in flight, the same memory) | {i2['value']:.0f} pairs/s — the LM iterations of one batch overlap the indexing of the next |\n"
+    if i3:
+        out += f"| `--inflight 3 --pairs 512` | {i3['value']:.0f} pairs/s |\n"
+    if p128:
+        out += f"| `--pairs 128` | {p128['value']:.0f} pairs/s |\n"
+    if hi:
+        out += f"| `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |\n"
+    if sor:
+        srow = next((v for k, v in sor["roofline"]["by_kernel"].items() if k.startswith("sor(")), None)
+        out += (f"| `--sor` (leaf 0.1 m + SOR 30 / 1.2: {sor['config']['points_after_voxel_src_mean']:.0f} points per cloud survive) | {sor['value']:.0f} pairs/s, {sor['ms_per_step']:.1f} ms/step; "
+                + (f"StatisticalOutlierRemoval of {pairs} clouds: {srow.get('isolated_avg_launch_ms', srow['avg_launch_ms']) * srow['launches_per_step'] / 2:.1f} ms "
+                   f"(own durations of its {srow['launches_per_step'] / 2:.0f} brackets: sort, hash, k = 31 search, threshold + compaction)" if srow else "") + " |\n")
+    out += f"""| CPU oracle on the same host ({cpu['cpu_model']}, {cpu['host_hw_threads']} hardware threads) | whole host, {cpu['cores'] // 4} workers × 4 OpenMP threads on independent pairs: **{cpu['value']:.1f} pairs/s** (`cpu_baseline.value`); one process, OpenMP inside a pair: {', '.join(f'{t} threads: {v}' for t, v in one.items())} pairs/s (4 = the reference's configuration, `lidar_scan_matcher.param.yaml:10`) |
 | GPU vs CPU pose of the same world-transformed pair | {cpu['gpu_vs_cpu_pose_dt_m'] * 1e9:.0f} nm / {cpu['gpu_vs_cpu_pose_dr_rad']:.1e} rad (bench.py aborts above 1 mm / 1e-4 rad) |
-| config 2, one 64 k pair (18 k / 20 k points after the voxel grid) | {ocj['config2_single_pair']['ms_median']:.2f} ms per align |
-| config 3, NDT: 65 k-point scan vs 1.05 M-point sub-map, 1.0 m cells | target build {ocj['config3_ndt_1M_submap']['set_target_ms']:.1f} ms, align {ocj['config3_ndt_1M_submap']['align_ms_median']:.2f} ms ({ocj['config3_ndt_1M_submap']['iterations']} iterations) |
-| config 4, 200-scan stream, window 20, FAST_GICP, key-frame covariances carried (C' = R C Rᵀ) | {ocj['config4_stream_FAST_GICP']['ms_per_scan']:.2f} ms/scan, end pose {ocj['config4_stream_FAST_GICP']['end_pose_err_vs_truth'][0]:.2f} m off after 160 m |
-| … covariances recomputed over the sub-map (the reference's arithmetic) | {ocj['config4_stream_FAST_GICP_covariances_recomputed']['ms_per_scan']:.2f} ms/scan, {ocj['config4_stream_FAST_GICP_covariances_recomputed']['end_pose_err_vs_truth'][0]:.2f} m |
-| … NDT_OMP (2.0 m cells, the node's default) | {ocj['config4_stream_NDT_OMP']['ms_per_scan']:.2f} ms/scan, {ocj['config4_stream_NDT_OMP']['end_pose_err_vs_truth'][0]:.2f} m (the 0.5 % scale bias of NDT on this scene, DESIGN §5) |
-| config 5 on one GPU, 512 candidates × 8 sub-maps through `LoopClosure`-style batches | {ocj['config5_loop_closure_batch']['pairs_per_s']:.0f} pairs/s incl. sub-map upload and indexing; registration alone: `benchmarks/config5.py` |
+| one 64 k pair (`{R}_single_pair.txt`) | {sp} |
+| 200-scan odometry stream, default (reference-arithmetic) mode (`{R}_stream_profile.txt`) | {stp} |
+"""
+    if ocj:
+        c4 = ocj.get("config4_stream_FAST_GICP", {})
+        c4o = ocj.get("config4_stream_FAST_GICP_carried_covariances_optin", {})
+        c4n = ocj.get("config4_stream_NDT_OMP", {})
+        c3 = ocj.get("config3_ndt_1M_submap", {})
+        c5 = ocj.get("config5_loop_closure_batch", {})
+        out += f"""| config 3, NDT: 65 k-point scan vs 1.05 M-point sub-map, 1.0 m cells | target build {c3.get('set_target_ms', 0):.1f} ms, align {c3.get('align_ms_median', 0):.2f} ms ({c3.get('iterations')} iterations) |
+| config 4, 200-scan stream, window 20, FAST_GICP, default: covariances recomputed over the sub-map (the reference's arithmetic) | {c4.get('ms_per_scan', 0):.2f} ms/scan, end pose {c4.get('end_pose_err_vs_truth', [0])[0]:.2f} m off after 160 m |
+| … opt-in: key-frame covariances carried (C' = R C Rᵀ) | {c4o.get('ms_per_scan', 0):.2f} ms/scan, {c4o.get('end_pose_err_vs_truth', [0])[0]:.2f} m |
+| … NDT_OMP (2.0 m cells, the node's default) | {c4n.get('ms_per_scan', 0):.2f} ms/scan, {c4n.get('end_pose_err_vs_truth', [0])[0]:.2f} m (the 0.5 % scale bias of NDT on this scene, DESIGN §5) |
+| config 4 at its stated 1 000 scans | `tests/test_gpu_fullsize.py::test_config4_at_its_stated_size_1000_scans` (both ground models): see `{R}_parity_deltas.txt` summary rows |
+| config 5 on one GPU, 512 candidates × 8 sub-maps through `LoopClosure`-style batches | {c5.get('pairs_per_s', 0):.0f} pairs/s incl. sub-map upload and indexing; registration alone: `benchmarks/config5.py` |
 """
     open(os.path.join(P, "README.md"), "w").write(out)
-    print(out[:800])
+    print(out[:600])
 
 
 if __name__ == "__main__":

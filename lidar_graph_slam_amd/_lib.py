@@ -147,6 +147,13 @@ EXPORTS_LOOP_CLOSURE = [
 ]
 
 
+# mi355_result as a NumPy record (same layout as `Result`): BatchRegistration.results(raw=True) hands the C array over without
+# building a dict per pair
+RESULT_DTYPE = np.dtype([("T", np.float32, (4, 4)), ("converged", np.int32), ("iterations", np.int32), ("error", np.float64), ("H", np.float64, (6, 6)),
+                         ("trans_probability", np.float64), ("n_source", np.int32), ("n_target", np.int32), ("n_inliers", np.int32), ("status", np.int32)],
+                        align=True)
+
+
 class LoopClosureParams(C.Structure):
     _fields_ = [
         ("search_key_frame_num", C.c_int),

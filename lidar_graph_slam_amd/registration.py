@@ -361,11 +361,14 @@ class BatchRegistration:
         self.ctx.check(self.ctx._lib.mi355_batch_align(self.handle, t.ctypes.data if t is not None else None, g.ctypes.data if g is not None else None,
                                                        1 if with_fitness else 0))
 
-    def results(self, with_fitness=False):
+    def results(self, with_fitness=False, raw=False):
+        """Synchronises and returns the n_sources results: a list of dicts, or (raw=True) ONE NumPy record array over the C structs
+        (fields T [4,4], converged, iterations, error, H [6,6], trans_probability, n_source, n_target, n_inliers, status) - what a
+        caller in a loop wants: building 1 024 dicts costs milliseconds of host time with the GPU idle."""
         res = (L.Result * self.n_sources)()
         fit = np.empty(self.n_sources) if with_fitness else None
         self.ctx.check(self.ctx._lib.mi355_batch_results(self.handle, res, fit.ctypes.data if fit is not None else None))
-        out = [r.to_dict() for r in res]
+        out = np.frombuffer(res, dtype=L.RESULT_DTYPE, count=self.n_sources) if raw else [r.to_dict() for r in res]
         return (out, fit) if with_fitness else out
 
     def set_side_streams(self, on: bool | None):
