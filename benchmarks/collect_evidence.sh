@@ -23,6 +23,7 @@ timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinpu
 timeout 300 python bench.py --inflight 2 --pairs 512 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
 timeout 300 python bench.py --inflight 3 --pairs 512 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"
 timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.json" 2> "$O/bench_128pairs.err"
+timeout 600 python bench.py --pairs 2048 --no-cpu-baseline --steps 10 --warmup 3 > "$O/bench_2048pairs.json" 2> "$O/bench_2048pairs.err"
 timeout 900 python benchmarks/other_configs.py --scans 200 > "$O/other_configs.txt" 2> "$O/other_configs.err"
 timeout 600 python benchmarks/config5.py --candidates 512 --submaps 8 > "$O/config5_1gpu.json" 2> "$O/config5_1gpu.err"
 MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"
