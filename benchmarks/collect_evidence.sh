@@ -27,4 +27,7 @@ timeout 600 python bench.py --pairs 2048 --no-cpu-baseline --steps 10 --warmup 3
 timeout 900 python benchmarks/other_configs.py --scans 200 > "$O/other_configs.txt" 2> "$O/other_configs.err"
 timeout 600 python benchmarks/config5.py --candidates 512 --submaps 8 > "$O/config5_1gpu.json" 2> "$O/config5_1gpu.err"
 MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"
-ls -la "$O"
+# distil on the box (the raw rocprofv3 output is hundreds of MB; gpurun copies back at most 64 MiB) and drop the raw traces
+EVIDENCE_DST="$O/profiles" python benchmarks/summarize_evidence.py $R > "$O/summarize.log" 2>&1
+rm -rf "$O/trace" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq1" "$O/pmc_sq2"
+du -sh "$O"; ls -la "$O" "$O/profiles"; tail -5 "$O"/*.err | tail -60

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", R)
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("EVIDENCE_DST") or os.path.join(ROOT, "profiles")  # on the GPU box: a small directory under gpurun_out/ (the raw traces stay there)
 
 
 def last_json(path):

@@ -284,6 +284,10 @@ int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
  * a caller that keeps ONE batch object for requests of varying size (LoopClosureCore, the lanes of mi355_multi) pays nothing for
  * the slots a request does not fill.  Invalidates the sources, targets and results that were set before. */
 int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets);
+/* Parity probe of update_correspondences (fast_gicp F3), after mi355_batch_align of a FAST_GICP batch: the correspondences the
+ * INCREMENTAL search holds at the final poses (margins, watch lists: DESIGN 4.3) against a search of every source point from scratch
+ * at the same poses.  *n_mismatch must be 0: the incremental search is exact, not approximate.  Leaves the results untouched. */
+int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_checked, long long* n_mismatch);
 /* Per-kernel-family timing for the benchmark's roofline block.  With timing enabled the library records HIP events on the
  * launching stream around every launch of the hot kernels (k_knn_cov_tile, k_gicp_correspond, k_gicp_linearize, ...; short
  * kernels that always run back to back, e.g. the 12 launches of one radix sort, share one bracket).

@@ -1304,6 +1304,15 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
   });
 }
 
+extern "C" int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_checked, long long* n_mismatch) {
+  if (!b || !n_checked || !n_mismatch) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    if (!b->aligned || b->method != MI355_METHOD_FAST_GICP) throw ArgError(MI355_ESTATE, "verify_correspondences: after mi355_batch_align of a FAST_GICP batch");
+    MI_HIP(hipSetDevice(b->ctx->device));
+    gicp_verify_correspondences(b->stream(), b->gb, b->src, b->tgt, b->gp, n_checked, n_mismatch);
+  });
+}
+
 extern "C" int mi355_batch_set_side_streams(mi355_batch* b, int mode) {
   if (!b || mode < -1 || mode > 1) return MI355_EINVAL;
   return guarded(b->ctx, [&] {

@@ -122,6 +122,8 @@ struct GicpBatch {
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
   DevBuf<Cov6> mahal;        // [S*cap] Mahalanobis matrices of the current linearisation
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
+  DevBuf<int> watch;         // [S*cap] watch lists of k_gicp_correspond: points close to their margin (gicp.hip, kWatchTau)
+  DevBuf<int> watch_meta;    // [S][8] list lengths, smallest slack of the unlisted points, max |p|: committed + accumulating
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;
   DevBuf<unsigned char> trials;  // [S][16] LmTrial (gicp.hip)
@@ -143,6 +145,9 @@ void gicp_fitness_values(hipStream_t s, GicpBatch& gb, double* fitness_out);
 void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
                 const float* guesses_host);
 void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb);  // Tuning::corr_stats only
+// parity probe: incremental correspondences at the final pose vs a from-scratch search (batches of >= 8 pairs: k_gicp_correspond)
+void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, long long* n_checked,
+                                 long long* n_mismatch);
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
                   const float* T16_host_all);
 void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, mi355_result* out, double* fitness_out);

@@ -371,6 +371,12 @@ class BatchRegistration:
         out = np.frombuffer(res, dtype=L.RESULT_DTYPE, count=self.n_sources) if raw else [r.to_dict() for r in res]
         return (out, fit) if with_fitness else out
 
+    def verify_correspondences(self):
+        """(points checked, mismatches) of the incremental correspondence search against a from-scratch search at the final poses."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self.ctx.check(self.ctx._lib.mi355_batch_verify_correspondences(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_side_streams(self, on: bool | None):
         """Prepare targets and sources on two overlapping side streams (True, the default), or one after the other on the batch's
         own stream (False: what a profiler wants); None = the library default."""

@@ -218,6 +218,46 @@ def test_batch_of_many_converging_pairs(R, small_pair):
         assert res[i]["converged"] == ref["converged"] and abs(res[i]["iterations"] - ref["iterations"]) <= 1, (i, res[i], ref)
 
 
+@pytest.mark.parametrize("force,iters", [(1, 20), (1, 6), (0, 30)])
+def test_incremental_correspondences_are_exact(R, medium_pair, force, iters):
+    """update_correspondences (fast_gicp F3) is INCREMENTAL here: a point keeps its correspondent while it provably cannot have
+    changed (margins), and once a pair has converged only the points close to their margin are tested at all (watch lists).  After
+    the last iteration the correspondences held that way must equal a search of every point from scratch at the same pose — for
+    pairs that ran 20 forced iterations (long watch-list phase), 6 (still moving) and an early-stopped run, incl. one pair that
+    starts at its optimum and one far off."""
+    src, tgt, T = medium_pair
+    s = O.voxel_grid(O.distance_filter(src, 1.0), 0.2)[0]
+    t = O.voxel_grid(O.distance_filter(tgt, 1.0), 0.2)[0]
+    nS = 12
+    cap = max(len(s), len(t)) + 5
+    srcs = np.zeros((nS, cap, 4), np.float32)
+    tgts = np.zeros((2, cap, 4), np.float32)
+    tgts[0, : len(t)] = t
+    tgts[1, : len(t) - 40] = t[40:]
+    ns = []
+    for i in range(nS):
+        D = synth.se3(0.04 * i, -0.03 * i, 0.01 * i, 0, 0, 0.003 * i) if i < nS - 1 else synth.se3(0.9, 0.5, 0.0, 0, 0, 0.04)
+        si = O.transform(s[: len(s) - 11 * i], D.astype(np.float32))
+        srcs[i, : len(si)] = si
+        ns.append(len(si))
+    opt = O.transform(s, np.asarray(T, np.float32))  # pair 5: starts (nearly) aligned
+    srcs[5] = 0
+    srcs[5, : len(opt)] = opt
+    ns[5] = len(opt)
+    b = R.BatchRegistration(nS, 2, cap, max_iterations=iters, force_iterations=force)
+    b.set_targets(tgts, [len(t), len(t) - 40])
+    b.set_sources(srcs, ns)
+    b.align([i % 2 for i in range(nS)])
+    res = b.results()
+    checked, bad = b.verify_correspondences()
+    assert checked == sum(ns) and bad == 0, (checked, bad)
+    res2 = b.results()  # the probe leaves the results alone
+    for r, r2 in zip(res, res2):
+        np.testing.assert_array_equal(r["T"], r2["T"])
+        assert r["iterations"] == r2["iterations"] and r["converged"] == r2["converged"]
+    b.close()
+
+
 def test_batch_flags_pairs_with_too_few_points(R, small_pair):
     """a cloud that holds fewer than k_correspondences points (here: handed over that way; in production a voxel
     filter can shrink a sparse key-frame sub-map that far) must not be registered with made-up neighbours: the pair reports
