@@ -285,7 +285,7 @@ int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
  * the slots a request does not fill.  Invalidates the sources, targets and results that were set before. */
 int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets);
 /* Parity probe of update_correspondences (fast_gicp F3), after mi355_batch_align of a FAST_GICP batch: the correspondences the
- * INCREMENTAL search holds at the final poses (margins, watch lists: DESIGN 4.3) against a search of every source point from scratch
+ * INCREMENTAL search holds at the final poses (margins: DESIGN 4.3) against a search of every source point from scratch
  * at the same poses.  *n_mismatch must be 0: the incremental search is exact, not approximate.  Leaves the results untouched. */
 int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_checked, long long* n_mismatch);
 /* Per-kernel-family timing for the benchmark's roofline block.  With timing enabled the library records HIP events on the

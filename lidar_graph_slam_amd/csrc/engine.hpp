@@ -122,8 +122,6 @@ struct GicpBatch {
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
   DevBuf<Cov6> mahal;        // [S*cap] Mahalanobis matrices of the current linearisation
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
-  DevBuf<int> watch;         // [S*cap] watch lists of k_gicp_correspond: points close to their margin (gicp.hip, kWatchTau)
-  DevBuf<int> watch_meta;    // [S][8] list lengths, smallest slack of the unlisted points, max |p|: committed + accumulating
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;
   DevBuf<unsigned char> trials;  // [S][16] LmTrial (gicp.hip)

@@ -26,24 +26,7 @@ struct GicpPairState {
   double last_error;
   int iter, trial, active, converged, n_inliers, lm_failed, need_error, status;
   double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
-  Pose x_check;      // pose of the last FULL margin check of k_gicp_correspond (watch lists, below)
 };
-
-// Watch lists: the margin test of k_gicp_correspond is 32 B per source point and iteration although, once a pair has converged,
-// hardly any point is anywhere near its margin.  A full check therefore also records, per pair, (a) the points whose remaining
-// slack (margin - distance moved since their last search) is below kWatchTau — the WATCH LIST — and (b) the smallest slack of all
-// the others.  While the pose has moved every source point by less than that (|dt| + |dR|_F * max|p|, from the pose of the full
-// check), none of the others can have used up its margin: the next launches test the watch list only.  As exact as the margins.
-// meta[pair][8]: 0 watch_n, 1 valid, 2 slack_min (float bits), 3 max |p| (float bits) — committed by k_gicp_solve from
-//                4 watch_n, 5 slack_min, 6 max |p| accumulated by the blocks of a full check, 7 = a full check has run.
-constexpr float kWatchTau = 1.0e-3f;
-constexpr int kWatchMeta = 8;
-__device__ __forceinline__ void watch_commit(GicpPairState* st, int* __restrict__ wm) {  // one thread, before the pose moves
-  if (!wm[7]) return;
-  wm[0] = wm[4]; wm[2] = wm[5]; wm[3] = wm[6]; wm[1] = 1;
-  st->x_check = st->x0;
-  wm[4] = 0; wm[5] = 0x7f800000; wm[6] = 0; wm[7] = 0;
-}
 
 // One Levenberg-Marquardt trial step.  step_lm's trial sequence is fully determined by (H, b, lambda): trial t uses
 // lambda_t = lambda * 2 * 4 * ... * 2^t, so ALL trial poses are computed up front, ONE pass over the points evaluates all
@@ -90,8 +73,6 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.corr.ensure((size_t)S * cap);
   gb.mahal.ensure((size_t)S * cap);
   gb.qsearch.ensure((size_t)S * cap);
-  gb.watch.ensure((size_t)S * cap);
-  gb.watch_meta.ensure((size_t)S * kWatchMeta);
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
   gb.trials.ensure((size_t)S * kMaxTrials * sizeof(LmTrial));
@@ -136,13 +117,9 @@ void gicp_fitness_values(hipStream_t s, GicpBatch& gb, double* fitness_out) {
 // scount / tcount (optional): a pair whose clouds hold fewer than k_min points after the prefilter is not registered —
 // its covariances would be built from missing neighbours — and reports MI355_PAIR_TOO_FEW_POINTS instead.
 __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses, int S, int has_guess, const int* __restrict__ scount,
-                            const int* __restrict__ tcount, const int* __restrict__ tgt_of_src, int k_min, int* __restrict__ watch_meta) {
+                            const int* __restrict__ tcount, const int* __restrict__ tgt_of_src, int k_min) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= S) return;
-  if (watch_meta) {
-    int* wm = watch_meta + kWatchMeta * p;
-    wm[0] = 0; wm[1] = 0; wm[2] = 0; wm[3] = 0; wm[4] = 0; wm[5] = 0x7f800000; wm[6] = 0; wm[7] = 0;
-  }
   GicpPairState s;
   s.x0 = has_guess ? pose_from_rowmajor4x4f(guesses + 16 * p) : pose_identity();  // Isometry3d(guess.cast<double>())
   s.xi = s.x0;
@@ -156,7 +133,6 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.status = MI355_PAIR_OK;
   if (scount && (scount[p] < k_min || tcount[tgt_of_src[p]] < k_min)) { s.active = 0; s.status = MI355_PAIR_TOO_FEW_POINTS; }
   s.last_step = 1.0e9;
-  s.x_check = s.x0;
   st[p] = s;
 }
 
@@ -635,8 +611,7 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                 float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
-                                                                int tiles_took_the_moving_pairs, double margin_step, int* __restrict__ watch,
-                                                                int* __restrict__ watch_meta) {
+                                                                int tiles_took_the_moving_pairs, double margin_step) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
   __shared__ int queue[kLinTile];
   __shared__ int qcount;
@@ -662,41 +637,7 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     Tf[4 * r + 3] = (float)x0.t[r];
   }
   const size_t so = (size_t)pair * scap;
-  // ---- watch lists (see kWatchTau): a pair in plain margin mode keeps them; any other mode invalidates them
-  int* wm = watch_meta + kWatchMeta * pair;
-  const bool watching = track_margin && !tile_pair;
-  bool watch_only = false;
-  if (watching && wm[1]) {
-    const Pose& xc = st->x_check;
-    double dt2 = 0, dR2 = 0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) dt2 += (x0.t[k] - xc.t[k]) * (x0.t[k] - xc.t[k]);
-#pragma unroll
-    for (int k = 0; k < 9; k++) dR2 += (x0.R[k] - xc.R[k]) * (x0.R[k] - xc.R[k]);
-    // how far the pose change since the full check can have moved ANY source point, plus the fp32 noise of two transforms
-    const float bound = (float)(sqrt(dt2) + sqrt(dR2) * (double)__int_as_float(wm[3])) * 1.0001f + 5.0e-5f;
-    watch_only = bound < __int_as_float(wm[2]);
-  }
-  if (!watching && bx == 0 && threadIdx.x == 0) wm[1] = 0;
-  const bool full_watch = watching && !watch_only;  // this launch is a full check that rebuilds the lists
-  if (full_watch && bx == 0 && threadIdx.x == 0) wm[7] = 1;
-  const int lane = lane_id();
-  const unsigned long long below = (1ull << lane) - 1ull;
-  float slack_min = INFINITY, rmax = 0.f;
-  // a point with `slack` left joins the watch list (wave-uniform call) or lowers the minimum of the others
-  auto account = [&](bool on, int i, float slack) {
-    const bool w = on && slack < kWatchTau;
-    const unsigned long long m = __ballot(w);
-    if (m) {
-      int at = 0;
-      if (lane == __builtin_ctzll(m)) at = atomicAdd(&wm[4], __popcll(m));
-      at = __builtin_amdgcn_readlane(at, __builtin_ctzll(m));
-      if (w) watch[so + at + __popcll(m & below)] = i;
-    }
-    if (on && !w) slack_min = fminf(slack_min, slack);
-  };
-  const int n_items = watch_only ? wm[0] : n;
-  for (int base = bx * kLinTile; base < n_items; base += G * kLinTile) {
+  for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
     // ---- phase 1: which points of this tile need a new nearest-neighbour search?  
     // The last full search of a point left, at query position qs.xyz, a margin qs.w: while the query has moved less
     // than that, its nearest neighbour provably cannot change (triangle inequality on the nearest / runner-up
@@ -706,9 +647,8 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
-      const int item = base + u * kGicpBlock + threadIdx.x;
-      const bool in = item < n_items;
-      const int i = in ? (watch_only ? watch[so + item] : item) : 0;
+      const int i = base + u * kGicpBlock + threadIdx.x;
+      if (i >= n) continue;
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
       const float4 qs = qsearch[so + i];
@@ -717,14 +657,10 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
       // NaN margin (never searched) -> search.  The margin also covers "still within max_corr" (search_point), so a point
       // that passes this test needs neither its correspondence index nor its correspondent: 32 B per point in steady state.
       const bool need_search = tile_pair ? (qs.w != qs.w) : !(moved < qs.w);
-      if (in && !finite_q) {
+      if (!finite_q) {
         corr[so + i] = -1;
-      } else if (in && need_search) {
+      } else if (need_search) {
         queue[atomicAdd(&qcount, 1)] = i;
-      }
-      if (full_watch) {
-        account(in && finite_q && !need_search, i, qs.w - moved);
-        if (in && finite_q) rmax = fmaxf(rmax, sqrtf(p.x * p.x + p.y * p.y + p.z * p.z));
       }
     }
     __syncthreads();
@@ -751,24 +687,15 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
         const NnState cs = coop_search(g, hx, hy, hz, reach_coop2);
         if (lane_id() == hl) { st = cs; was_hard = true; }
       }
-      float margin = 0.f;
       if (valid) {
         int j;
+        float margin;
         finish_search(st, max_corr_d2, track_margin || was_hard, j, margin);
         corr[so + i] = j;
         qsearch[so + i] = make_float4(qx, qy, qz, margin);
       }
-      if (full_watch) account(valid, i, margin);  // a fresh search: nothing of the new margin is used up
     }
     __syncthreads();  // correspondences written by other threads of this block are visible from here on
-  }
-  if (full_watch) {  // one atomic per wave: positive floats order like ints
-    slack_min = wave_min_all(slack_min);
-    rmax = wave_max_all(rmax);
-    if (lane == 0) {
-      atomicMin(&wm[5], __float_as_int(slack_min));
-      atomicMax(&wm[6], __float_as_int(rmax));
-    }
   }
 }
 
@@ -1160,7 +1087,7 @@ __device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParam
 }
 
 __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, LmTrial* __restrict__ trials, const double* __restrict__ partials,
-                                                   int G, GicpDevParams P, int* __restrict__ watch_meta) {
+                                                   int G, GicpDevParams P) {
   __shared__ double sums[kPartStride];
   __shared__ double sH[36], sb[6], slambda;
   __shared__ Pose sx0;
@@ -1169,7 +1096,6 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
   GicpPairState* st = state + pair;
   if (!st->active) return;
   const int l = threadIdx.x;
-  if (l == 0 && watch_meta) watch_commit(st, watch_meta + kWatchMeta * pair);  // the pose of this iteration's full check = x0, still unmoved
   if (l < kNAcc) {
     // (block order: bitwise reproducible.  Unrolled so that the loads of 8 partials are in flight together — one pair alone spent
     // most of this kernel's 15 us waiting for 32 loads one after the other)
@@ -1469,7 +1395,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     } else {
       hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                          tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step, gb.watch.p, gb.watch_meta.p);
+                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step);
     }
   }
   TimedLaunch tl(KF_LINEARIZE, s);
@@ -1493,7 +1419,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     MI_HIP(hipMemcpyAsync(gb.guesses.p, gb.h_guess.data(), (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   }
   hipLaunchKernelGGL(k_gicp_init, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, (const float*)gb.guesses.p, S, guesses_host ? 1 : 0,
-                     (const int*)src.count.p, (const int*)tgt.count.p, (const int*)gb.tgt_of_src.p, std::max(p.k_correspondences, 1), gb.watch_meta.p);
+                     (const int*)src.count.p, (const int*)tgt.count.p, (const int*)gb.tgt_of_src.p, std::max(p.k_correspondences, 1));
   // no previous correspondences yet, NaN margins: the first pass searches every point
   hipLaunchKernelGGL(k_gicp_reset_search, dim3(std::max(1, std::min(64, div_up((long)src.cap, 1024))), S), dim3(256), 0, s, (const int*)src.count.p, gb.corr.p,
                      gb.qsearch.p, src.cap);
@@ -1504,7 +1430,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
     launch_linearize(s, gb, src, tgt, P, it);
     {
       TimedLaunch tl(KF_SOLVE_DECIDE, s);
-      hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P, gb.watch_meta.p);
+      hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P);
     }
     if (p.optimizer == MI355_OPT_LM) {
       auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
@@ -1567,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_gicp_compare_corr(const int* __restrict
   if (checked) atomicAdd(&out[0], checked);
   if (bad) atomicAdd(&out[1], bad);
 }
-// After gicp_align: the correspondences the INCREMENTAL search (margins, watch lists) holds at the final pose against a search of
+// After gicp_align: the correspondences the INCREMENTAL search (margins) holds at the final pose against a search of
 // every point from scratch at the same pose.  They must be identical.
 void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, long long* n_checked,
                                  long long* n_mismatch) {
@@ -1583,10 +1509,10 @@ void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& s
   auto correspond = [&] {
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p, tgt.table.p,
                        tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2, gb.blocks_per_pair, S, 0,
-                       (double)tuning().margin_step, gb.watch.p, gb.watch_meta.p);
+                       (double)tuning().margin_step);
   };
   hipLaunchKernelGGL(k_gicp_set_active, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, S, 1, saved.p);
-  correspond();  // incremental: margins and watch lists as the last iteration left them, at the final pose
+  correspond();  // incremental: margins as the last iteration left them, at the final pose
   MI_HIP(hipMemcpyAsync(inc.p, gb.corr.p, (size_t)S * src.cap * sizeof(int), hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_gicp_reset_search, dim3(std::max(1, std::min(64, div_up((long)src.cap, 1024))), S), dim3(256), 0, s, (const int*)src.count.p, gb.corr.p,
                      gb.qsearch.p, src.cap);
@@ -1720,7 +1646,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
   MI_HIP(hipMemcpyAsync(gb.tgt_of_src.p, &zero, sizeof(int), hipMemcpyHostToDevice, s));
   MI_HIP(hipStreamSynchronize(s));
   hipLaunchKernelGGL(k_gicp_init, dim3(1), dim3(64), 0, s, gb.state.p, (const float*)nullptr, 1, 0, (const int*)nullptr, (const int*)nullptr,
-                     (const int*)nullptr, 0, gb.watch_meta.p);
+                     (const int*)nullptr, 0);
   Pose x;
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) x.R[3 * r + c] = T16[4 * r + c];
@@ -1753,7 +1679,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
       if (got[(size_t)i] != first[(size_t)i])
         throw ArgError(MI355_ESTATE, search == 1 ? "tile and per-lane correspondence searches disagree" : "group and per-lane correspondence searches disagree");
   }
-  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P, (int*)nullptr);
+  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P);
   MI_LAUNCH_CHECK();
   GicpPairState st;
   MI_HIP(hipMemcpyAsync(&st, gb.state.p, sizeof(st), hipMemcpyDeviceToHost, s));

@@ -221,10 +221,9 @@ def test_batch_of_many_converging_pairs(R, small_pair):
 @pytest.mark.parametrize("force,iters", [(1, 20), (1, 6), (0, 30)])
 def test_incremental_correspondences_are_exact(R, medium_pair, force, iters):
     """update_correspondences (fast_gicp F3) is INCREMENTAL here: a point keeps its correspondent while it provably cannot have
-    changed (margins), and once a pair has converged only the points close to their margin are tested at all (watch lists).  After
-    the last iteration the correspondences held that way must equal a search of every point from scratch at the same pose — for
-    pairs that ran 20 forced iterations (long watch-list phase), 6 (still moving) and an early-stopped run, incl. one pair that
-    starts at its optimum and one far off."""
+    changed (margins from the nearest / runner-up gap).  After the last iteration the correspondences held that way must equal a
+    search of every point from scratch at the same pose — for pairs that ran 20 forced iterations, 6 (still moving) and an
+    early-stopped run, incl. one pair that starts at its optimum and one far off."""
     src, tgt, T = medium_pair
     s = O.voxel_grid(O.distance_filter(src, 1.0), 0.2)[0]
     t = O.voxel_grid(O.distance_filter(tgt, 1.0), 0.2)[0]
