@@ -7,8 +7,8 @@ One *step* = one pass of the whole hot path over one batch of `--pairs` independ
 inputs already resident in HBM: distance filter + VoxelGrid 0.2 m on both clouds -> voxel-hash build -> k=20
 covariances -> exactly 20 Levenberg-Marquardt GICP iterations -> poses copied back.  Pairs are sharded across ranks with
 no data-path collective (weak scaling); the only collective is the MAX of the elapsed time.  BASELINE.json configs[1].
-Default: ONE batch of 1 024 pairs at a time — every kernel duration the roofline block reports is then what rocprofv3 reports
-for the same command.  `--inflight 2 --pairs 512` keeps two batch objects in flight on two HIP streams in the same memory
+Default: ONE batch of 2 048 pairs at a time (90 GB of HBM) — every kernel duration the roofline block reports is then what
+rocprofv3 reports for the same command.  `--inflight 2 --pairs 512` keeps two batch objects in flight on two HIP streams in the same memory
 (while one batch is in its latency- and bandwidth-bound LM iterations the next one is prefiltered and indexed by VALU-bound
 kernels): +8 % pairs/s, `--inflight 3`: +13 %; K steps are then still K whole batches, all finished inside the timed region, but
 HIP-event brackets around kernels of interleaved streams also contain the time a kernel waits for the other stream's.
@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step (= per batch)")
+    ap.add_argument("--pairs", type=int, default=2048, help="scan pairs per GPU per step (= per batch): 2 048 pairs = 90 GB of the 288 GB; 1 024 (the default of "
+                    "rounds 1-3, what DESIGN.md quotes per-launch figures at) is 4 %% slower per pair, 128: 33 %%")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--leaf", type=float, default=0.2)
     ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")

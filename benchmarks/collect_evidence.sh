@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 rm -rf "$O"; mkdir -p "$O"
 timeout 600 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python bench.py --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python bench.py --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.err"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_fetch.err"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$O/pmc_write.err"
 # VALU / LDS / wait counters of the hot kernels at the bench's full batch (two passes: 8 SQ slots each), --kernel-trace only
@@ -20,10 +20,11 @@ timeout 600 python bench.py --sor --no-cpu-baseline --steps 5 --warmup 2 > "$O/b
 timeout 300 python benchmarks/single_pair.py > "$O/single_pair.txt" 2>&1
 timeout 300 python benchmarks/stream_profile.py 200 FAST_GICP > "$O/stream_profile.txt" 2>&1
 timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinputs.json" 2> "$O/bench_hostinputs.err"
-timeout 300 python bench.py --inflight 2 --pairs 512 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
-timeout 300 python bench.py --inflight 3 --pairs 512 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"
+timeout 300 python bench.py --inflight 2 --pairs 1024 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
+timeout 300 python bench.py --inflight 3 --pairs 1024 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"
 timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.json" 2> "$O/bench_128pairs.err"
-timeout 600 python bench.py --pairs 2048 --no-cpu-baseline --steps 10 --warmup 3 > "$O/bench_2048pairs.json" 2> "$O/bench_2048pairs.err"
+timeout 600 python bench.py --pairs 1024 --no-cpu-baseline > "$O/bench_1024pairs.json" 2> "$O/bench_1024pairs.err"
+timeout 900 python bench.py --pairs 4096 --no-cpu-baseline --steps 6 --warmup 2 > "$O/bench_4096pairs.json" 2> "$O/bench_4096pairs.err"
 timeout 900 python benchmarks/other_configs.py --scans 200 > "$O/other_configs.txt" 2> "$O/other_configs.err"
 timeout 600 python benchmarks/config5.py --candidates 512 --submaps 8 > "$O/config5_1gpu.json" 2> "$O/config5_1gpu.err"
 MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"

@@ -39,6 +39,7 @@ def maybe(name):
 def main():
     b, tr, tj = load("bench_default"), load("bench_under_trace"), load("traffic")
     hi, i2, i3, p128, ser, sor = (maybe(n) for n in ("bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_serial_streams", "bench_sor"))
+    p1k, p4k = maybe("bench_1024pairs"), maybe("bench_4096pairs")
     rows = list(csv.DictReader(open(os.path.join(P, f"{R}_kernel_stats_bench_default.csv"))))
     tot_ns = sum(float(x["TotalDurationNs"]) for x in rows)
     rf, cpu, e2e = b["roofline"], b["cpu_baseline"], b["roofline"]["end_to_end"]
@@ -66,7 +67,7 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 | `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |
 | `{R}_bench_sor.json` | `python bench.py --sor`: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2) over the same {pairs}-pair batch — a different workload, never the headline; carries the SOR row |
 | `{R}_bench_hostinputs.json` | `python bench.py --host-inputs`: HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
-| `{R}_bench_inflight2.json`, `{R}_bench_inflight3.json` | `python bench.py --inflight 2 / 3 --pairs 512`: batch objects on their own streams used alternately, the memory of the default |
+| `{R}_bench_inflight2.json`, `{R}_bench_inflight3.json` | `python bench.py --inflight 2 / 3 --pairs 1024`: batch objects on their own streams used alternately (the memory of the default / 1.5 × it) |
 | `{R}_bench_serial_streams.json` | the default with `MI355_BATCH_SIDE_STREAMS=0`: the preparation chains one after the other |
 | `{R}_bench_128pairs.json` | `python bench.py --pairs 128` |
 | `{R}_other_configs.txt`, `{R}_single_pair.txt`, `{R}_stream_profile.txt` | the BASELINE configs that are not the bench line (`benchmarks/other_configs.py --scans 200`), one 64 k pair, a 200-scan odometry stream |
@@ -117,14 +118,18 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
 
 | what | value |
 |---|---|
-| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 2: 14 383, round 1: 11 572; boxes of the pool differ by a few per cent) |
+| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 2: 14 383 and round 1: 11 572, both at 1 024 pairs per step; boxes of the pool differ by a few per cent) |
 """
     if i2:
-        out += f"| `--inflight 2 --pairs 512` (two batches in flight, the same memory) | {i2['value']:.0f} pairs/s — the LM iterations of one batch overlap the indexing of the next |\n"
+        out += f"| `--inflight 2 --pairs 1024` (two batches in flight, the same memory) | {i2['value']:.0f} pairs/s — the LM iterations of one batch overlap the indexing of the next |\n"
     if i3:
-        out += f"| `--inflight 3 --pairs 512` | {i3['value']:.0f} pairs/s |\n"
+        out += f"| `--inflight 3 --pairs 1024` | {i3['value']:.0f} pairs/s |\n"
     if p128:
         out += f"| `--pairs 128` | {p128['value']:.0f} pairs/s |\n"
+    if p1k:
+        out += f"| `--pairs 1024` (the default of rounds 1-3; DESIGN.md quotes per-launch kernel figures at this size) | {p1k['value']:.0f} pairs/s, {p1k['ms_per_step']:.1f} ms/step |\n"
+    if p4k:
+        out += f"| `--pairs 4096` (180 GB) | {p4k['value']:.0f} pairs/s |\n"
     if hi:
         out += f"| `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |\n"
     if sor:
