@@ -155,8 +155,9 @@ struct mi355_batch {
   // are short or end in a thin tail (sort passes, the k-NN stragglers), so run together they fill each other's gaps.
   struct Side {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, knn_done = nullptr;
     bool pending = false;  // work enqueued since the last join
+    bool knn_pending = false;  // knn_done recorded since the last join
     Workspace ws;
     CloudSet sor_set;
     DevBuf<int> cnt_in;
@@ -179,6 +180,7 @@ struct mi355_batch {
       if (sd.stream) { (void)hipStreamSynchronize(sd.stream); (void)hipStreamDestroy(sd.stream); }
       if (sd.fork) (void)hipEventDestroy(sd.fork);
       if (sd.join) (void)hipEventDestroy(sd.join);
+      if (sd.knn_done) (void)hipEventDestroy(sd.knn_done);
     }
   }
 };
@@ -1102,6 +1104,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
       MI_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, prio_lo));
       MI_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
       MI_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+      MI_HIP(hipEventCreateWithFlags(&sd.knn_done, hipEventDisableTiming));
       ws_reserve(sd.ws, k == 0 ? n_targets : n_sources, capacity);
       sd.cnt_in.ensure(k == 0 ? n_targets : n_sources);
     }
@@ -1157,7 +1160,17 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     if (targets)
       for (int u = 0; u < B; u++) ndt_batch_set_target(s, sd.ws, *b->ndt, u, set.pts.p + (size_t)u * b->cap, (size_t)hc[(size_t)u], b->np);
   } else {
+    // The k-NN / covariance kernels of the two chains gain nothing from running at the same time (both are bound by the same VALU
+    // and LDS; at 1 024 clouds the second one simply queued behind the first, at 2 048 their blocks interleave and each takes
+    // twice as long): the chain that comes second starts its k-NN when the other's is done — its prefilter, sort and hash build
+    // still run beside that k-NN — and a kernel's duration is its own again (what rocprofv3 and the bench's roofline report).
+    auto& other = b->side[targets ? 1 : 0];
+    if (side_streams && other.knn_pending) MI_HIP(hipStreamWaitEvent(s, other.knn_done, 0));
     compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
+    if (side_streams) {
+      MI_HIP(hipEventRecord(sd.knn_done, s));
+      sd.knn_pending = true;
+    }
   }
   if (side_streams) {
     MI_HIP(hipEventRecord(sd.join, s));
@@ -1172,6 +1185,7 @@ static void batch_join(mi355_batch* b) {
       MI_HIP(hipStreamWaitEvent(b->stream(), sd.join, 0));
       sd.pending = false;
     }
+  for (auto& sd : b->side) sd.knn_pending = false;
 }
 
 extern "C" int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter) {
