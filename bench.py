@@ -318,8 +318,9 @@ def main():
     # The roofline numbers of the line come from the kernel's OWN duration: HIP events on the launching stream around launches
     # that have the GPU to themselves (the two extra steps above, preparation chains serialised).  That is the duration the
     # rocprofv3 kernel trace of this command reports for the kernel (profiles/README.md recomputes it).  The event brackets of
-    # the TIMED region sit on side streams that run concurrently, so they also contain the time a launch waits for the other
-    # chain's kernels to free the CUs - a queueing figure, kept under `timed_region_event_brackets`, never used for `frac`.
+    # the TIMED region sit on side streams that run concurrently: for kernels that overlap another chain's they also contain
+    # waiting / sharing (the k-NN kernels do not overlap each other: the library serialises them) - kept under
+    # `timed_region_event_brackets`, never used for `frac`.
     iso_ms = d.get("isolated_avg_launch_ms") or d["avg_launch_ms"]
     achieved = d["algorithmic_bytes_per_launch"] / (iso_ms * 1e-3) / 1e9
     roofline = {
@@ -334,7 +335,7 @@ def main():
         "launches_measured": int(iso.get(dom, [0, 0])[1]),
         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
         "timed_region_event_brackets": {"avg_ms": d["avg_launch_ms"], "launches": int(ktimes[dom][1]), "share_of_summed_brackets": d["share_of_timed_gpu_ms"],
-                                        "note": "brackets on concurrent side streams: include waiting for the other preparation chain; not a kernel duration"},
+                                        "note": "brackets on the concurrent side streams of the timed region; not used for frac"},
         "note": "kernel family with the largest own duration x launches per step (the ranking of the rocprofv3 kernel-stats CSV under profiles/); "
                 "achieved = algorithmic bytes per launch (SURVEY 8d x the units of one launch) / avg_launch_ms, measured live in this run "
                 "with HIP events on the launching stream while nothing else runs",

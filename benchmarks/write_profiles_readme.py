@@ -81,8 +81,10 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 * launch duration: **{rf['avg_launch_ms']:.2f} ms** — HIP events on the launching stream inside `bench.py`, around {rf['launches_measured']} launches that have the GPU
   to themselves (two extra steps after the timed region, preparation chains serialised); **{float(top['AverageNs']) / 1e6:.2f} ms** average over the {top['Calls']} launches
   of the rocprofv3 kernel trace of the same command (min {float(top['MinNs']) / 1e6:.2f}, max {float(top['MaxNs']) / 1e6:.2f}) — the two agree.  The event brackets of the TIMED
-  region sit on two concurrent side streams and read {live['avg_ms']:.2f} ms: that includes the time a launch waits for the other chain's k-NN to free
-  the CUs (both need 18 KB of LDS per wave) — a queueing figure, reported as `roofline.timed_region_event_brackets`, never used for `frac`;
+  region (`roofline.timed_region_event_brackets`) read {live['avg_ms']:.2f} ms: the preparation chains run on two concurrent side streams, but since
+  round 3 the chain that comes second starts its k-NN when the other's is done (`hipStreamWaitEvent`), so a launch neither queues behind
+  nor interleaves with the other one (at 2 048 clouds the two used to interleave and rocprofv3 saw 33.5 ms per launch: 3 % more pairs/s,
+  and a duration that was nobody's own); `frac` is still taken from the launches that have the GPU to themselves;
 * achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound
   (`{R}_pmc_valu.csv`), the HBM roofline is simply the wrong ceiling for it, and the bench says so instead of picking a flattering kernel;
 * PMC traffic per launch: FETCH_SIZE {tj['fetch_size_kb_raw'] / 1e3:.0f} MB raw × 2 + WRITE_SIZE {tj['write_size_kb'] / 1e3:.0f} MB = **{tj['hbm_bytes_per_launch'] / 1e6:.0f} MB = {tj['hbm_bytes_per_launch'] / rf['algorithmic_bytes_per_launch']:.2f} × algorithmic**
