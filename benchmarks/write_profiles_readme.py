@@ -62,6 +62,7 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 | `{R}_pmc_fetch_write.csv` | per-kernel HBM traffic from two separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE …` / `--pmc WRITE_SIZE …` of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` |
 | `{R}_traffic.json` | the `{tj['kernel']}` row of the above (FETCH_SIZE × 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), read by `bench.py` into `roofline.traffic` |
 | `{R}_pmc_valu.csv` | SQ counters per launch of every hot kernel at the bench's full batch ({pairs} pairs): `SQ_INSTS_VALU`, `SQ_ACTIVE_INST_VALU`, `SQ_INSTS_LDS`, `SQ_WAIT_ANY`, `SQ_WAVE_CYCLES`, `SQ_LDS_BANK_CONFLICT` … from two `--pmc` passes (`--kernel-trace` only) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` |
+| `{R}_knn_tile_ablation.txt` | `benchmarks/knn_ablate.sh`: the preparation chain alone (`knn_only.py`, 1 024 clouds) for the library and for timing-only variants of the tile kernel (no covariance epilogue, no kd order; the "norank" variants break the kernel's control flow and only show that) |
 | `{R}_knn_tile_counters.txt` | the k-NN tile kernel's own per-tile counters (`MI355_KNN_STATS=1`): segments, rounds, gathers, candidates, build trips, rank steps per lane |
 | `{R}_knn_brick_ab.txt`, `{R}_corr_brick_ab.txt`, `{R}_knn_tile_gather_ab.txt` | A/B logs of this round's kernel experiments that did NOT pay (cell bricks for the k-NN and for the correspondence tiles, a wider first gather): DESIGN §4.4 |
 | `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |

@@ -512,7 +512,9 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   int i = tile0 + lane;
   float4 q = g.pts[min(i, n - 1)];
   if (i >= n) q.x = q.y = q.z = INFINITY;  // past the end of the cloud: sorts to the last lanes, never active
+#ifndef KNN_ABL_NO_KD  // (KNN_ABL_*: timing ablations of benchmarks/knn_only.py, never defined in the product build)
   kd_order_tile(q.x, q.y, q.z, i);
+#endif
   const bool valid = i < n;
   const float rcap = 16.f * g.m.cell, rmin = 0.6f * g.m.cell;
   bool fb = false;  // this lane goes to the fallback queue
@@ -653,7 +655,11 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
             const uint32_t off = (uint32_t)mine[t];
             const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + off);
             const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
+#ifdef KNN_ABL_NO_RANK
+            keys.v[t & 1] = min(keys.v[t & 1], (t < cnt) ? ((d & ~kOrdMask) | (off >> 4)) : SmallestKeys<K + 2>::kEmpty);
+#else
             keys.insert((t < cnt) ? ((d & ~kOrdMask) | (off >> 4)) : SmallestKeys<K + 2>::kEmpty);
+#endif
           }
         }
         // ---- which lanes are done?  every point within rsafe of a query of the sub-tile has been seen by its lanes
@@ -713,7 +719,11 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
         if constexpr (SOR) {
           if (exact) mean_dist[(size_t)c * cap + g.orig[i]] = sor_mean_distance<K>(k, q, [&](int t) { return cand[keys.v[t] & kOrdMask]; });
         } else {
+#ifdef KNN_ABL_NO_COV
+          if (exact) cov[(size_t)c * cap + i] = cov6_pack(__uint_as_float(keys.v[0]), __uint_as_float(keys.v[1]), __uint_as_float(keys.v[K - 1]), 1.f, 0.f, 1.f);
+#else
           if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
+#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the lists
       }
