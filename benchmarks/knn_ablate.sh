@@ -5,6 +5,6 @@ cp lidar_graph_slam_amd/libmi355_lidar.so /tmp/base.so
 for f in /tmp/base.so lidar_graph_slam_amd/variants/*.so; do
   cp "$f" lidar_graph_slam_amd/libmi355_lidar.so
   echo "== $(basename $f)"
-  timeout 300 python benchmarks/knn_only.py 1024 2>&1 | tail -2
+  MI355_KNN_STATS=1 timeout 300 python benchmarks/knn_only.py 1024 2>&1 | grep -E "handed over|k_knn_cov_tile" | tail -2; timeout 300 python benchmarks/knn_only.py 1024 2>&1 | tail -1
 done
 cp /tmp/base.so lidar_graph_slam_amd/libmi355_lidar.so

@@ -396,7 +396,12 @@ __device__ __forceinline__ float sor_mean_distance(int k, const float4& q, P&& p
 // fallback queue and are done by k_knn_hard + k_cov_from_knn.  A tile whose own box is too large (it straddles a jump of
 // the Morton curve, or lies in the sparse far field) is split into halves, processed one after the other by the whole wave.
 constexpr int kOrdBits = 10;
-constexpr int kTileMaxCand = 768;            // candidates per tile segment (list positions; at most 2^kOrdBits)
+#ifndef KNN_TILE_CAND  // (KNN_*: overridable for A/B builds, benchmarks/build_variant.sh)
+#define KNN_TILE_CAND 768
+#define KNN_SUB_CAP 764
+#define KNN_TILE_WAVES_PER_SIMD 2
+#endif
+constexpr int kTileMaxCand = KNN_TILE_CAND;  // candidates per tile segment (list positions; at most 2^kOrdBits)
 constexpr uint32_t kOrdMask = (1u << kOrdBits) - 1u;
 constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
 constexpr int kSubQ = 16;                    // lanes (queries) per sub-tile (8: 10.9 + 1.8 ms per launch, 16: 10.7 + 1.7 ms, 32: 11.2 + 1.7 ms, 4: 12.3 + 2.5 ms)
@@ -411,7 +416,7 @@ constexpr int kNSub = kWave / kSubQ;
 // per-sub-tile BITMASKS over the 768-entry tile list (12.7 KB, 168 VGPRs): same hand-over, 11.0 ms (11.3 ms with two candidate
 // loads in flight) — walking set bits costs ~10 more VALU instructions per candidate than reading a 16-bit list entry, and the
 // rank loop is VALU-bound, so the extra wave does not pay for it.
-constexpr int kSubCap = 764;
+constexpr int kSubCap = KNN_SUB_CAP;
 constexpr int kSubRow = kSubCap + 4;         // row pitch: the 4-way unrolled rank loop may read (and ignore) up to 3 entries past the end
 
 // min / max over the aligned group of kSubQ lanes a lane belongs to (same value in all lanes of the group)
@@ -486,7 +491,7 @@ __device__ __forceinline__ void kd_order_tile(float& x, float& y, float& z, int&
 // SOR = true: the same search for pcl::StatisticalOutlierRemoval (P2) — k = mean_k + 1 neighbours including the point itself, and
 // instead of the covariance the mean of the mean_k non-zero-rank distances goes to mean_dist[] in the caller's point order.
 template <int K, bool SOR, bool STATS = false>
-__global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
+__global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(const float4* __restrict__ pts, const int* __restrict__ orig,
                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
                                                      Cov6* __restrict__ cov, float* __restrict__ mean_dist, int* __restrict__ queue,
                                                      float* __restrict__ queue_hint, int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap,
@@ -495,6 +500,10 @@ __global__ __launch_bounds__(64) void k_knn_cov_tile(const float4* __restrict__ 
   int st_tiles = 0, st_segs = 0, st_rounds = 0, st_gathers = 0, st_cands = 0, st_build = 0, st_rank = 0, st_direct = 0;  // STATS only
   __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
   __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
+#ifdef KNN_ABL_LDS_PAD  // (timing ablation: fewer resident waves per CU)
+  __shared__ int lds_pad[KNN_ABL_LDS_PAD / 4];
+  if (threadIdx.x == 0 && G < 0) lds_pad[G & 1] = 1;
+#endif
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
