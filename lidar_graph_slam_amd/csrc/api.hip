@@ -34,6 +34,7 @@ const Tuning& tuning() {
     geti("MI355_KNN_NEED_DIV", v.knn_need_div);
     geti("MI355_TILE_WAVES", v.tile_waves);
     getf("MI355_TILE_RSCALE", v.tile_rscale);
+    geti("MI355_TILE_ORDER", v.tile_order);
     getf("MI355_TILE_GATHER", v.tile_gather);
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
     getf("MI355_GRID_CELL", v.grid_cell);
@@ -1165,6 +1166,9 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     // twice as long): the chain that comes second starts its k-NN when the other's is done — its prefilter, sort and hash build
     // still run beside that k-NN — and a kernel's duration is its own again (what rocprofv3 and the bench's roofline report).
     auto& other = b->side[targets ? 1 : 0];
+    // (batches only: for ONE cloud - a registration object, the scan matcher's sub-map - the sort costs more than the search gains:
+    // measured 2.19 instead of 1.99 ms per scan on the config-4 stream)
+    build_tile_order(s, sd.ws, set);
     if (side_streams && other.knn_pending) MI_HIP(hipStreamWaitEvent(s, other.knn_done, 0));
     compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
     if (side_streams) {

@@ -20,6 +20,7 @@ void CloudSet::alloc(int B_, size_t cap_) {
   table.ensure((size_t)B * slots_cap);
   built = false;
   has_cov = false;
+  has_order = false;
 }
 
 // Threads per block of the one-thread-per-point kernels without block-level cooperation (keys, heads, centroids, cell counts,
@@ -258,6 +259,7 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   MI_LAUNCH_CHECK();
   out.built = true;
   out.has_cov = false;
+  out.has_order = false;
 }
 
 // ---- k-NN covariances (F2) --------------------------------------------------------------------------------------
@@ -496,8 +498,17 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
                                                      Cov6* __restrict__ cov, float* __restrict__ mean_dist, int* __restrict__ queue,
                                                      float* __restrict__ queue_hint, int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap,
                                                      size_t slots_cap, int k, int method, int G, int B, float r_scale, float gather_scale,
-                                                     unsigned long long* __restrict__ stats = nullptr) {
+                                                     const int* __restrict__ tile_order = nullptr, unsigned long long* __restrict__ stats = nullptr) {
   int st_tiles = 0, st_segs = 0, st_rounds = 0, st_gathers = 0, st_cands = 0, st_build = 0, st_rank = 0, st_direct = 0;  // STATS only
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // STATS only: shader clocks per phase of the tile loop
+  auto phase = [&](int w) {
+    if constexpr (STATS) {
+      const long long t = clock64();
+      ph[w] += t - ph_t;
+      ph_t = t;
+    }
+  };
+  if constexpr (STATS) ph_t = clock64();
   __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
   __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
 #ifdef KNN_ABL_LDS_PAD  // (timing ablation: fewer resident waves per CU)
@@ -518,13 +529,17 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
   const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
   if (tile0 >= n) break;
   if constexpr (STATS) st_tiles++;
+  int t_segs = 0, t_cands = 0, t_fail_cells = 0, t_fail_list = 0;  // STATS only
   int i = tile0 + lane;
+  if (tile_order && i < n) i = tile_order[(size_t)c * cap + i];  // tiles in an order of their own (launch_covariances)
   float4 q = g.pts[min(i, n - 1)];
   if (i >= n) q.x = q.y = q.z = INFINITY;  // past the end of the cloud: sorts to the last lanes, never active
 #ifndef KNN_ABL_NO_KD  // (KNN_ABL_*: timing ablations of benchmarks/knn_only.py, never defined in the product build)
-  kd_order_tile(q.x, q.y, q.z, i);
+  // along the curve of build_tile_order every aligned group of 16 lanes is a compact patch already (measured: 8.7 ms without this, 9.4 ms with)
+  if (!tile_order) kd_order_tile(q.x, q.y, q.z, i);
 #endif
   const bool valid = i < n;
+  phase(0);
   const float rcap = 16.f * g.m.cell, rmin = 0.6f * g.m.cell;
   bool fb = false;  // this lane goes to the fallback queue
   float hint = 0.f;  // ... with a radius that is known to hold its k nearest neighbours (0: not known)
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
     const int nact = __popcll(__ballot(act));
     bool split = false;
     if (nact > 0) {
-      if constexpr (STATS) st_segs++;
+      if constexpr (STATS) { st_segs++; t_segs++; }
       const TileBox bb = tile_bounds(act, q.x, q.y, q.z);
       const float eps = tile_eps(bb, rcap);
       float r0, e_max;  // first radius: k-NN radius of a surface with the segment's own point density
@@ -571,11 +586,12 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
       TileBox ob = bb;
       float R = -1.f;
       bool has_old = false, open = act;
+      phase(1);
       for (int round = 0;; round++) {
         if constexpr (STATS) st_rounds++;
         // ---- tile list: grow the gathered box to the largest radius a working sub-tile asks for
         // (the FIRST gather reaches gather_scale x further than the sub-tiles ask for: a round is a chain of dependent loads - 64 hash
-        // probes, then the cell ranges - that two waves per SIMD cannot hide, and most tiles came back for a second one)
+        // probes, then the cell ranges - that two waves per SIMD cannot hide)
         const float Rw = uniform_f(wave_max_all(take ? rs : 0.f));
         const float Rn = (has_old || !(Rw > R)) ? Rw : fminf(gather_scale * Rw, rcap);
         if (Rw > R) {
@@ -583,6 +599,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           const TileBox nb = grow(bb, Rn);
           const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
           const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
+          if constexpr (STATS) { if (!cells.ok) t_fail_cells++; else if (n_new < 0) t_fail_list++; }
           if (n_new < 0) {  // over a budget: split the segment if nothing has been gathered yet, else hand the open lanes over
             if (!has_old && Rw > rmin && Rn > 0.5f * e_max) {
               // clustered points (far field): the density guess overshoots and the radius, not the segment's own extent,
@@ -602,6 +619,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           n_ord = n_new;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
         }
+        phase(2);
         bool redo = false;
         if (direct) {
           if constexpr (STATS) st_direct += n_ord - n_done;
@@ -639,6 +657,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          phase(3);
           // a FIRST list that does not fit is rebuilt with half the radius (the growth rounds bring back what a lane needs);
           // a list that overflows while growing hands its open lanes over
           const bool over = slen > kSubCap;
@@ -671,6 +690,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
 #endif
           }
         }
+        phase(4);
         // ---- which lanes are done?  every point within rsafe of a query of the sub-tile has been seen by its lanes
         const float rsafe = redo ? 0.f : rs * 0.9999f - eps;
         const uint32_t kk = keys.at(k - 1);
@@ -706,6 +726,8 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           break;
         }
       }
+      phase(5);
+      if constexpr (STATS) { if (!split) t_cands += n_ord; }
       if (!split) {
         // closed lanes: exact unless truncation could have swapped the k-th and (k+1)-th candidates (or they tie exactly)
         const uint32_t kk = keys.at(k - 1), kn = keys.at(k);
@@ -735,6 +757,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
 #endif
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the lists
+        phase(6);
       }
     }
     if (split) {
@@ -754,6 +777,15 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
       queue_hint[(size_t)c * cap + base + __popcll(fm & below)] = hint;
     }
   }
+  phase(7);
+  if constexpr (STATS) {
+    if (stats && lane == 0) {
+      atomicAdd(&stats[16 + min(t_segs, 7)], 1ull);                       // tiles by number of segments processed (incl. split attempts)
+      if (t_segs > 1 && t_cands <= kTileMaxCand) atomicAdd(&stats[24], 1ull);  // ... split tiles whose segments' lists would fit one list together
+      atomicAdd(&stats[25], (unsigned long long)t_fail_cells); atomicAdd(&stats[26], (unsigned long long)t_fail_list);
+      if (t_segs > 1) atomicAdd(&stats[27], (unsigned long long)t_cands);
+    }
+  }
   }  // next tile
   if constexpr (STATS) {
     if (stats && lane == 0) {
@@ -761,6 +793,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
       atomicAdd(&stats[2], (unsigned long long)st_rounds); atomicAdd(&stats[3], (unsigned long long)st_gathers);
       atomicAdd(&stats[4], (unsigned long long)st_cands); atomicAdd(&stats[5], (unsigned long long)st_build);
       atomicAdd(&stats[6], (unsigned long long)st_rank); atomicAdd(&stats[7], (unsigned long long)st_direct);
+      for (int w = 0; w < 8; w++) atomicAdd(&stats[8 + w], (unsigned long long)ph[w]);
     }
   }
 }
@@ -1213,8 +1246,69 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
   });
 }
 
+// ---- the order in which the tile search takes the points (round 3) -----------------------------------------------------------
+// A tile of k_knn_cov_tile is 64 points that should be ONE compact patch of a surface: the wave gathers the neighbourhood of
+// their common box and every lane ranks what falls near its sub-tile.  64 consecutive points of the 3-D Morton order of the
+// voxel hash are not that: the curve interleaves the height with the ground axes at every level, so a run of it is a
+// CHUNK OF VOLUME — bits of the ground, of a wall and of what stands in front of it — and it jumps.  Measured on the bench's
+// clouds, the longest sub-tile list of a tile (what sets the trip count of the ranking loop) is 322 candidates on average
+// along the Morton order, 214 along a 3-D Hilbert curve, 141 along a 2-D Hilbert curve over the two long axes of the cloud,
+// 119 for an exact kd partition into leaves of 64 (benchmarks/tile_order_sim.py); 16 % / 3 % / 0.6 % / 0.3 % of the tiles
+// overflow the candidate list and are split.  A scan is a 2.5-D thing — ground, walls, poles: a small footprint on the
+// plane of the two long axes holds one patch of one surface, whatever the height does.
+// So the tiles are taken along a 2-D Hilbert curve (2^11 cells per axis) over the two longest axes of the cloud's bounding
+// box: one more sort of (key, index) pairs per cloud, 3 radix passes.  The order changes which points share a wave, never a
+// result: every point's neighbours are found exactly whatever its tile is.
+__device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {  // 11 bits per axis -> 22-bit index along the curve
+  uint32_t d = 0;
+#pragma unroll
+  for (int b = 10; b >= 0; b--) {
+    const uint32_t s = 1u << b;
+    const uint32_t rx = (x >> b) & 1u, ry = (y >> b) & 1u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (ry == 0u) {  // rotate the quadrant
+      if (rx == 1u) { x = (s - 1u) - (x & (s - 1u)); y = (s - 1u) - (y & (s - 1u)); }
+      const uint32_t t = x; x = y; y = t;
+    }
+    x &= s - 1u; y &= s - 1u;
+  }
+  return d;
+}
+__global__ __launch_bounds__(256) void k_tile_order_keys(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, uint32_t* __restrict__ keys,
+                                                         int* __restrict__ vals, size_t cap) {
+  const int c = blockIdx.y;
+  const GridMeta m = meta[c];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const float4 p = pts[(size_t)c * cap + i];
+  // the two longest axes of the bounding box (a, b), 2^11 cells over the longer one
+  const int drop = (m.dz <= m.dx && m.dz <= m.dy) ? 2 : ((m.dy <= m.dx) ? 1 : 0);
+  const float ua = (drop == 0) ? p.y - m.oy : p.x - m.ox, ub = (drop == 2) ? p.y - m.oy : p.z - m.oz;
+  const int da = (drop == 0) ? m.dy : m.dx, db = (drop == 2) ? m.dy : m.dz;
+  const float scale = 2047.0f / ((float)max(max(da, db), 1) * m.cell);
+  const uint32_t ia = (uint32_t)min(max((int)(ua * scale), 0), 2047), ib = (uint32_t)min(max((int)(ub * scale), 0), 2047);
+  keys[(size_t)c * cap + i] = hilbert2(ia, ib);
+  vals[(size_t)c * cap + i] = i;
+}
+__global__ __launch_bounds__(256) void k_copy_order(const int* __restrict__ vals, const int* __restrict__ counts, int* __restrict__ out, size_t cap) {
+  const int c = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < counts[c]) out[(size_t)c * cap + i] = vals[(size_t)c * cap + i];
+}
+// set.tile_order <- the sorted-array indices of every cloud along the 2-D Hilbert curve
+void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set) {
+  if (tuning().knn_tiles != 1 || !tuning().tile_order) return;
+  set.tile_order.ensure((size_t)set.B * set.cap);
+  const dim3 grid(div_up((long)set.cap, 256), set.B);
+  hipLaunchKernelGGL(k_tile_order_keys, grid, dim3(256), 0, s, set.pts.p, set.meta.p, ws.keys_a.p, ws.vals_a.p, set.cap);
+  sort_pairs(s, ws, set.B, set.cap, set.count.p, 3);
+  hipLaunchKernelGGL(k_copy_order, grid, dim3(256), 0, s, ws.vals_a.p, set.count.p, set.tile_order.p, set.cap);
+  MI_LAUNCH_CHECK();
+  set.has_order = true;
+}
+
 template <int K, bool SOR = false>
-static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, float* mean_dist = nullptr) {
+static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, float* mean_dist = nullptr, const int* tile_order = nullptr) {
   const int G = div_up((long)set.cap, 256);
   const Tuning& tn = tuning();
   if (!tn.knn_tiles && !SOR) {  // per-lane search for every point
@@ -1246,22 +1340,33 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
                          tn.brick_h, tn.brick_gather, (unsigned long long*)nullptr);
     }
   } else if (tn.knn_stats && !SOR) {
-    set.knn_stats.ensure(8);
-    MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 8 * sizeof(unsigned long long), s));
+    set.knn_stats.ensure(32);
+    MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 32 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR, true>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                        mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
-                       tn.tile_gather, set.knn_stats.p);
+                       tn.tile_gather, tile_order, set.knn_stats.p);
     MI_HIP(hipStreamSynchronize(s));
-    unsigned long long st[8];
+    unsigned long long st[32];
     MI_HIP(hipMemcpy(st, set.knn_stats.p, sizeof(st), hipMemcpyDeviceToHost));
     const double tiles = (double)std::max(st[0], 1ull);
+    fprintf(stderr, "[mi355] k-NN tiles by segments run (1..7+): %llu %llu %llu %llu %llu %llu %llu; split tiles whose lists fit one list together: %llu, candidates of split tiles %.0f each; "
+            "gathers over budget: %llu by cells / loads, %llu by list length\n", st[17], st[18], st[19], st[20], st[21], st[22], st[23], st[24],
+            (double)st[27] / std::max(1ull, st[18] + st[19] + st[20] + st[21] + st[22] + st[23]), st[25], st[26]);
+    {
+      double all = 0;
+      for (int w = 0; w < 8; w++) all += (double)st[8 + w];
+      fprintf(stderr, "[mi355] k-NN tile phases, shader clocks per tile (share): fetch+kd %.0f (%.1f%%), segment setup %.0f (%.1f%%), gather %.0f (%.1f%%), build %.0f (%.1f%%), "
+              "rank %.0f (%.1f%%), round end %.0f (%.1f%%), pair+covariance %.0f (%.1f%%), queue %.0f (%.1f%%)\n", st[8] / tiles, 100 * st[8] / all, st[9] / tiles,
+              100 * st[9] / all, st[10] / tiles, 100 * st[10] / all, st[11] / tiles, 100 * st[11] / all, st[12] / tiles, 100 * st[12] / all, st[13] / tiles, 100 * st[13] / all,
+              st[14] / tiles, 100 * st[14] / all, st[15] / tiles, 100 * st[15] / all);
+    }
     fprintf(stderr, "[mi355] k-NN sub-tile lists per tile: %.2f segments, %.2f rounds, %.2f gathers, %.0f candidates gathered, %.1f build trips (x 4 x 16 box tests), "
             "%.1f rank steps per lane (+ %.1f direct)\n", st[1] / tiles, st[2] / tiles, st[3] / tiles, st[4] / tiles, st[5] / tiles, st[6] / tiles, st[7] / tiles);
   } else {
     TimedLaunch tl(KF_KNN_COV_TILE, s);
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                        mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
-                       tn.tile_gather);
+                       tn.tile_gather, tile_order);
   }
   // the points the tile kernel handed over: one wave per point, covariance included
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
@@ -1291,11 +1396,12 @@ void compute_covariances(hipStream_t s, CloudSet& set, int k, int method) {
   if (k < 1 || k > 64) throw ArgError(MI355_EINVAL, "k_correspondences must be in [1, 64]");
   set.cov.ensure((size_t)set.B * set.cap);
   if (!tuning().knn_tiles) set.nbr.ensure((size_t)set.B * set.cap * k);  // neighbour lists exist only on the per-lane path
-  if (k == 20) launch_covariances<20>(s, set, k, method);
-  else if (k <= 8) launch_covariances<8>(s, set, k, method);
-  else if (k <= 16) launch_covariances<16>(s, set, k, method);
-  else if (k <= 32) launch_covariances<32>(s, set, k, method);
-  else launch_covariances<64>(s, set, k, method);
+  const int* order = set.has_order ? set.tile_order.p : nullptr;  // build_tile_order, if the caller ran it for this grid
+  if (k == 20) launch_covariances<20>(s, set, k, method, nullptr, order);
+  else if (k <= 8) launch_covariances<8>(s, set, k, method, nullptr, order);
+  else if (k <= 16) launch_covariances<16>(s, set, k, method, nullptr, order);
+  else if (k <= 32) launch_covariances<32>(s, set, k, method, nullptr, order);
+  else launch_covariances<64>(s, set, k, method, nullptr, order);
   MI_LAUNCH_CHECK();
   set.has_cov = true;
 }

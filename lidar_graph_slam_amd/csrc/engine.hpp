@@ -64,10 +64,11 @@ struct CloudSet {
   DevBuf<int> nbr;  // [B*cap*k] k-NN lists (sorted indices) between the search and the covariance kernels
   DevBuf<int> fbq, fbn;  // [B*cap] / [2B] points the tile k-NN hands over to k_knn_hard, their number per cloud (+ the tile counters)
   DevBuf<float> fbhint;  // [B*cap] radius known to hold the k nearest neighbours of a handed-over point (0: unknown)
+  DevBuf<int> tile_order;  // [B*cap] sorted-array indices in the order k_knn_cov_tile takes them (64 per tile)
   DevBuf<unsigned long long> knn_stats;  // Tuning::knn_stats only: counters of k_knn_cov_brick
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
-  bool built = false, has_cov = false;
+  bool built = false, has_cov = false, has_order = false;
   void alloc(int B_, size_t cap_);
 };
 
@@ -98,6 +99,9 @@ void sor_filter(hipStream_t s, Workspace& ws, CloudSet& scratch_set, const float
 void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell);
 // k-NN covariances with regularisation (F2) for every point of a built CloudSet.
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method);
+// Optional, between build_grid and compute_covariances: the order in which the tile search takes the points (2-D Hilbert curve over the
+// two long axes of the cloud: cloud.hip).  Changes which points share a wave, never a result.  ws: scratch of the sort.
+void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set);
 // Exact k-NN of queries (packed float4 [m]) in cloud 0 of a built set; idx in the caller's point order.
 void knn_query(hipStream_t s, const CloudSet& set, const float4* d_queries, int m, int k, int* d_idx, float* d_d2);
 void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, const float* T16_host);

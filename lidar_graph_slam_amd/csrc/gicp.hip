@@ -844,7 +844,8 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
                                                                      size_t tcap, size_t tslots, const int* __restrict__ tgt_of_src,
                                                                      const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                      float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S,
-                                                                     unsigned long long* __restrict__ stats, double margin_step) {
+                                                                     unsigned long long* __restrict__ stats, double margin_step,
+                                                                     const int* __restrict__ tile_order) {
   __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand];
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
@@ -870,8 +871,10 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
   const float R1 = one_round ? reach : r1, R1_2 = one_round ? reach2 : r1 * r1;
   constexpr int kWavesPerBlock = kGicpBlock / kWave;
   for (int tile = bx * kWavesPerBlock + wave_id(); tile * kWave < n; tile += G * kWavesPerBlock) {
-    const int i = tile * kWave + lane;
+    int i = tile * kWave + lane;
     const bool valid = i < n;
+    // the source's tiles in the order its k-NN search took them (cloud.hip, build_tile_order): compact patches, not runs of the Morton curve
+    if (tile_order && valid) i = tile_order[so + i];
     const float4 p = spts[so + (valid ? i : tile * kWave)];
     const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
     const bool finite_q = valid && isfinite(qx) && isfinite(qy) && isfinite(qz);
@@ -1383,7 +1386,8 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
       TimedLaunch tl(KF_CORRESPOND_TILE, s);
       hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
                          tgt.pts.p, tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p,
-                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p, (double)tn.margin_step);
+                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p, (double)tn.margin_step,
+                         (src.has_order && src.cap == gb.cap) ? (const int*)src.tile_order.p : (const int*)nullptr);
     }
     TimedLaunch tl(KF_CORRESPOND, s);
     if (groups && isfinite(P.max_corr_d2)) {
