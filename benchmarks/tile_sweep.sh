@@ -1,13 +1,9 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: knn_only.py for the tree's library under a few tunings, then for every variant under variants/.
+# Runs ON THE GPU BOX: knn_only.py for the tree's library (optionally under tunings given as arguments "A=1 B=2" ...), then for every variant under variants/.
 cd "$GRAFT_REPO_ROOT"
 run() { echo "== $*"; env "$@" MI355_KNN_STATS=1 timeout 300 python benchmarks/knn_only.py 1024 2>&1 | grep -E "lists per tile|handed" | tail -2; env "$@" timeout 300 python benchmarks/knn_only.py 1024 2>&1 | tail -1; }
 run A=0
-run MI355_TILE_RSCALE=0.85
-run MI355_TILE_RSCALE=1.15
-run MI355_TILE_GATHER=1.25
-run MI355_TILE_GATHER=1.5
-run MI355_TILE_RSCALE=1.15 MI355_TILE_GATHER=1.25
+for t in "$@"; do run $t; done
 cp lidar_graph_slam_amd/libmi355_lidar.so /tmp/base.so
 for f in lidar_graph_slam_amd/variants/*.so; do
   [ -f "$f" ] || continue
