@@ -90,7 +90,7 @@ struct Tuning {
   float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for
   int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
-  int corr_tiles = 2;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
+  int corr_tiles = 4;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)
   int corr_groups = 1;        // MI355_CORR_GROUPS       0 = per-lane correspondence search also for batches of < 8 pairs (no lane groups)
   float margin_step = 0.03f;  // MI355_MARGIN_STEP       a pair tracks search margins once its last accepted step moved it by less than this (m at a 50 m lever arm)

@@ -17,6 +17,7 @@
 #include "tile.hpp"
 
 namespace mi355 {
+constexpr int kCorrStatsN = 8 + 4 * 64;  // MI355_CORR_STATS: 8 counters of the tile kernel + per iteration (searched, close seeds, by the whole wave, tracking pairs)
 
 struct GicpPairState {
   Pose x0, xi, delta;
@@ -81,8 +82,8 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.fit_partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * 2);
   gb.fitness.ensure((size_t)S * 2);
   if (tn.corr_stats) {
-    gb.corr_stats.ensure(8);
-    MI_HIP(hipMemset(gb.corr_stats.p, 0, 8 * sizeof(unsigned long long)));
+    gb.corr_stats.ensure(kCorrStatsN);
+    MI_HIP(hipMemset(gb.corr_stats.p, 0, kCorrStatsN * sizeof(unsigned long long)));
   }
 }
 
@@ -611,9 +612,10 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                 float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
-                                                                int tiles_took_the_moving_pairs, double margin_step) {
+                                                                int tiles_took_the_moving_pairs, double margin_step,
+                                                                unsigned long long* __restrict__ stats = nullptr, int iteration = 0) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
-  __shared__ int queue[kLinTile];
+  __shared__ int queue[kLinTile + kGicpBlock];  // what is left of the earlier tiles (< one block's worth) + this tile's
   __shared__ int qcount;
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
@@ -637,14 +639,17 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     Tf[4 * r + 3] = (float)x0.t[r];
   }
   const size_t so = (size_t)pair * scap;
+  if (threadIdx.x == 0) qcount = 0;
+  __syncthreads();
   for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
     // ---- phase 1: which points of this tile need a new nearest-neighbour search?  
     // The last full search of a point left, at query position qs.xyz, a margin qs.w: while the query has moved less
     // than that, its nearest neighbour provably cannot change (triangle inequality on the nearest / runner-up
     // distances).  Points that do need a search are COMPACTED into an LDS queue so that the (divergent, latency-bound)
-    // search runs on dense waves instead of stalling every wave of the block behind a few lanes.
-    if (threadIdx.x == 0) qcount = 0;
-    __syncthreads();
+    // search runs on dense waves instead of stalling every wave of the block behind a few lanes: the queue is searched a
+    // whole block's worth at a time, what is left waits for the next tile's (when 1 - 10 % of the points have left their
+    // margins - the first iterations of margin tracking - a tile alone fills one or two of the block's four waves, partly).
+    const bool last_tile = base + G * kLinTile >= n;
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
@@ -665,11 +670,15 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     }
     __syncthreads();
     // ---- phase 2: dense search of the queued points
-    const int nq = qcount;
+    int nq = qcount;
+    if (stats && threadIdx.x == 0 && bx == 0 && base == 0 && track_margin && !tile_pair) atomicAdd(&stats[8 + 4 * min(iteration, 63) + 3], 1ull);
     const float reach_coop2 = search_reach2(g, max_corr_d2, true);
-    for (int t0 = 0; t0 < nq; t0 += kGicpBlock) {  // whole waves go round together: the cooperative part needs all 64 lanes
-      const int tq = t0 + threadIdx.x;
-      const bool valid = tq < nq;
+    while (nq >= kGicpBlock || (last_tile && nq > 0)) {  // whole waves go round together: the cooperative part needs all 64 lanes
+      const int take = min(nq, kGicpBlock);
+      if (stats && threadIdx.x == 0) atomicAdd(&stats[8 + 4 * min(iteration, 63)], (unsigned long long)take);
+      nq -= take;
+      const int tq = nq + threadIdx.x;
+      const bool valid = (int)threadIdx.x < take;
       const int i = valid ? queue[tq] : 0;
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
@@ -678,6 +687,7 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
       if (valid) st = lane_search(g, qx, qy, qz, corr[so + i], max_corr_d2, track_margin);
       // the queries the fine levels could not finish, one at a time, by the whole wave
       unsigned long long hard = __ballot(valid && !st.complete);
+      if (stats && lane_id() == 0 && hard) atomicAdd(&stats[8 + 4 * min(iteration, 63) + 2], (unsigned long long)__popcll(hard));
       while (hard) {
         const int hl = __builtin_ctzll(hard);
         hard &= hard - 1;
@@ -695,7 +705,9 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
         qsearch[so + i] = make_float4(qx, qy, qz, margin);
       }
     }
-    __syncthreads();  // correspondences written by other threads of this block are visible from here on
+    __syncthreads();  // the searched entries have been read: the next tile appends behind what is left
+    if (threadIdx.x == 0) qcount = nq;
+    __syncthreads();
   }
 }
 
@@ -1399,7 +1411,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     } else {
       hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                          tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step);
+                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step, gb.corr_stats.p, iteration);
     }
   }
   TimedLaunch tl(KF_LINEARIZE, s);
@@ -1513,7 +1525,7 @@ void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& s
   auto correspond = [&] {
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p, tgt.table.p,
                        tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2, gb.blocks_per_pair, S, 0,
-                       (double)tuning().margin_step);
+                       (double)tuning().margin_step, (unsigned long long*)nullptr, 0);
   };
   hipLaunchKernelGGL(k_gicp_set_active, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, S, 1, saved.p);
   correspond();  // incremental: margins as the last iteration left them, at the final pose
@@ -1579,7 +1591,7 @@ __global__ void k_fitness_final(const double* __restrict__ fit_partials, double*
 
 void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb) {
   if (!gb.corr_stats.p) return;
-  unsigned long long h[8];
+  unsigned long long h[kCorrStatsN];
   MI_HIP(hipMemcpyAsync(h, gb.corr_stats.p, sizeof(h), hipMemcpyDeviceToHost, s));
   MI_HIP(hipStreamSynchronize(s));
   MI_HIP(hipMemsetAsync(gb.corr_stats.p, 0, sizeof(h), s));
@@ -1587,6 +1599,10 @@ void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb) {
   fprintf(stderr, "[mi355] correspondence tiles: %llu, %.0f points in round-1 cells each (%llu not run); round 2: %llu of them, %.1f lanes, "
                   "%.0f points in cells each (%llu not run); %llu lanes to the per-lane search\n",
           h[0], (double)h[1] / t, h[2], h[3], (double)h[4] / (double)std::max(1ull, h[3]), (double)h[5] / (double)std::max(1ull, h[3]), h[6], h[7]);
+  fprintf(stderr, "[mi355] per-lane correspondence search by iteration (points searched / of them by the whole wave / pairs tracking margins):");
+  for (int it = 0; it < 64; it++)
+    if (h[8 + 4 * it] || h[8 + 4 * it + 3]) fprintf(stderr, " %d: %llu / %llu / %llu;", it, h[8 + 4 * it], h[8 + 4 * it + 2], h[8 + 4 * it + 3]);
+  fprintf(stderr, "\n");
 }
 
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
