@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 from . import _lib as L
 
@@ -47,6 +48,8 @@ class Context:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:

@@ -4,6 +4,7 @@ this file only marshals."""
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -75,6 +76,8 @@ class LoopClosure:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:

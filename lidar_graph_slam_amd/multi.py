@@ -5,6 +5,7 @@ one-process-per-GPU form of the same partition, with the results all-gathered ov
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -63,6 +64,8 @@ class MultiDevice:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:

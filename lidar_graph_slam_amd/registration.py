@@ -8,6 +8,7 @@ getFitnessScore plus the engine-specific setters.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -67,6 +68,8 @@ class DeviceCloud:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:
@@ -158,6 +161,8 @@ class _Registration:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:
@@ -399,6 +404,8 @@ class BatchRegistration:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -52,6 +53,8 @@ class LidarScanMatcher:
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():  # the HIP runtime may be gone already: leave the handles to the process teardown
+            return
         try:
             self.close()
         except Exception:
