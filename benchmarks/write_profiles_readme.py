@@ -13,11 +13,11 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(ROOT, "profiles")
 
 NOTES = {
-    "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles, 16-lane sub-tile candidate lists in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); VALU-bound",
+    "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles taken along a 2-D Hilbert curve over the cloud's two long axes, 16-lane sub-tile candidate lists in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); VALU-bound",
     "k_gicp_correspond": "F3, incremental and exact: per-lane walks of the voxel hash, margins (DESIGN §4.3); latency-bound",
-    "k_gicp_correspond_tile": "F3 for the first two iterations, when every point moves: 64-point tiles, packed distance/ordinal keys",
-    "k_knn_hard": "the 1.0 % of the points the tiles hand over (far field, ties), one wave per query",
-    "sort_pairs(k_sort_*)": "in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
+    "k_gicp_correspond_tile": "F3 while a pair still moves >= 3 cm per step (launched in the first four iterations; the fourth finds no such pair here): 64-point tiles in the k-NN tile order, packed distance/ordinal keys",
+    "k_knn_hard": "the 0.3 % of the points the tiles hand over (far field, ties), one wave per query",
+    "sort_pairs(k_sort_*)": "per cloud three sorts - voxel index, Morton code of the hash, 2-D Hilbert index of the tile order: in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
     "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order): one gather per lane, runs handed to their head lane by shuffles",
     "k_gicp_linearize": "F4, streaming: 80 algorithmic B per source point",
     "k_gicp_error": "F5: all 10 LM trial costs in one pass (fp64, FMAs fused since round 3)",
@@ -63,6 +63,8 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 | `{R}_traffic.json` | the `{tj['kernel']}` row of the above (FETCH_SIZE × 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), read by `bench.py` into `roofline.traffic` |
 | `{R}_pmc_valu.csv` | SQ counters per launch of every hot kernel at the bench's full batch ({pairs} pairs): `SQ_INSTS_VALU`, `SQ_ACTIVE_INST_VALU`, `SQ_INSTS_LDS`, `SQ_WAIT_ANY`, `SQ_WAVE_CYCLES`, `SQ_LDS_BANK_CONFLICT` … from two `--pmc` passes (`--kernel-trace` only) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` |
 | `{R}_knn_tile_ablation.txt` | `benchmarks/knn_ablate.sh`: the preparation chain alone (`knn_only.py`, 1 024 clouds) for the library and for timing-only variants of the tile kernel (no covariance epilogue, no kd order; the "norank" variants break the kernel's control flow and only show that) |
+| `{R}_tile_order_ab.txt` | `benchmarks/tile_order_ab.sh` / `tile_sweep.sh`: the k-NN tile kernel with its tiles along the Morton order of the voxel hash and along the 2-D Hilbert curve (phase clocks, split statistics, tunings, 3-wave variants, the union-of-boxes gather that was removed): DESIGN §4.4 |
+| `{R}_corr_tiles_sweep.txt` | `benchmarks/corr_tiles_sweep.sh`: tile search of the correspondences in the first 2 … 5 iterations, per-iteration search counters, before / after the per-lane kernel searched its queue a block's worth at a time: DESIGN §4.3 |
 | `{R}_knn_tile_counters.txt` | the k-NN tile kernel's own per-tile counters (`MI355_KNN_STATS=1`): segments, rounds, gathers, candidates, build trips, rank steps per lane |
 | `{R}_knn_brick_ab.txt`, `{R}_corr_brick_ab.txt`, `{R}_knn_tile_gather_ab.txt` | A/B logs of this round's kernel experiments that did NOT pay (cell bricks for the k-NN and for the correspondence tiles, a wider first gather): DESIGN §4.4 |
 | `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |
@@ -109,7 +111,7 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
         total_own += iso * v["launches_per_step"]
         out += (f"| `{name}` | {v['launches_per_step']:.0f} | {iso:.3f} | {iso * v['launches_per_step']:.2f} | "
                 + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {v['total_ms_per_step']:.2f} | {NOTES.get(name, '')} |\n")
-    out += f"\nSum of the own durations: {total_own:.1f} ms against {b['ms_per_step']:.1f} ms per step (the two preparation chains overlap a little).\n"
+    out += f"\nSum of the own durations: {total_own:.1f} ms against {b['ms_per_step']:.1f} ms per step (the rest: the small kernels outside these families - keys, scans, bounds, copies - and gaps; the two preparation chains hardly overlap: `k_sort_tile` needs a CU's whole LDS and waits for the other chain's k-NN, DESIGN §3 / §8).\n"
     if ser:
         out += f"One batch of {pairs} pairs with the preparation chains serialised (`{R}_bench_serial_streams.json`): {ser['ms_per_step']:.1f} ms/step.\n"
     oc_path = os.path.join(P, f"{R}_other_configs.txt")
