@@ -210,7 +210,7 @@ def test_config4_at_its_stated_size_1000_scans(ground_max_range):
             # on, after which they are two valid odometry runs and only their drift is comparable
             if same_history:
                 bt, br, dt_o, dr_o = parity.deltas(o["pose"], gold["pose"][i])
-                parity._log(f"config4_1000/gmr{ground_max_range}/vs_golden/scan{i}", band_t=bt, band_r=br, dt=dt_o, dr=dr_o, scale=1.0)
+                parity._log(f"config4_1000/gmr{ground_max_range}/vs_golden/scan{i}", band_t=bt, band_r=br, dt=dt_o, dr=dr_o, scale=2.0)
                 if bool(gold["new_key_frame"][i]) != o["new_key_frame"] or not gold["converged"][i]:
                     same_history = False
                     first_split = i
@@ -236,7 +236,7 @@ def test_config4_at_its_stated_size_1000_scans(ground_max_range):
     ate_gold = float(np.sqrt(np.mean(err_gold**2)))
     parity._log(f"config4_1000/gmr{ground_max_range}/summary", ate_m=ate, end_err_m=float(err[-1]), key_frames=n_kf, path_m=0.8 * (n - 1),
                 oracle_ate_m=ate_gold, oracle_end_err_m=float(err_gold[-1]), oracle_key_frames=int(gold["new_key_frame"].sum()) - 1,
-                same_history_until_scan=(n if same_history else first_split))
+                same_history_until_scan=(n if same_history else first_split), scans_over_one_band=int(over_one_band))
     assert over_one_band <= n // 100, over_one_band
     assert ate < max(1.25 * ate_gold, ate_gold + 0.05), (ate, ate_gold)
     assert abs(n_kf - (int(gold["new_key_frame"].sum()) - 1)) <= 5
