@@ -1150,7 +1150,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
   if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
     run_prefilter(s, sd.ws, sd.sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, sd.cnt_in.p, sd.ws.stage_a, sd.ws.stage_b, sd.ws.count_a,
                   sd.ws.count_b, &pts, &cnt);
-  build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell);
+  build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell, b->method == MI355_METHOD_FAST_GICP);
   if (b->method == MI355_METHOD_NDT_OMP) {
     // NDT: the sources are just points; every target gets its voxel Gaussians (N1).  The leaf builder sizes its launches on
     // the host, so the counts after the prefilter are read back here (one sync per set call, none per alignment).

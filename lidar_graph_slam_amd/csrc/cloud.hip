@@ -208,9 +208,36 @@ __device__ __forceinline__ HashSlot* table_insert(HashSlot* t, const GridMeta& m
   }
 }
 
+__device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {  // 11 bits per axis -> 22-bit index along the curve
+  uint32_t d = 0;
+#pragma unroll
+  for (int b = 10; b >= 0; b--) {
+    const uint32_t s = 1u << b;
+    const uint32_t rx = (x >> b) & 1u, ry = (y >> b) & 1u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (ry == 0u) {  // rotate the quadrant
+      if (rx == 1u) { x = (s - 1u) - (x & (s - 1u)); y = (s - 1u) - (y & (s - 1u)); }
+      const uint32_t t = x; x = y; y = t;
+    }
+    x &= s - 1u; y &= s - 1u;
+  }
+  return d;
+}
+// key of a point in the order the tile searches take the points of a cloud in (build_tile_order below): 2-D Hilbert index over the
+// two longest axes of the bounding box (a, b), 2^11 cells over the longer one
+__device__ __forceinline__ uint32_t tile_order_key(const GridMeta& m, const float4& p) {
+  const int drop = (m.dz <= m.dx && m.dz <= m.dy) ? 2 : ((m.dy <= m.dx) ? 1 : 0);
+  const float ua = (drop == 0) ? p.y - m.oy : p.x - m.ox, ub = (drop == 2) ? p.y - m.oy : p.z - m.oz;
+  const int da = (drop == 0) ? m.dy : m.dx, db = (drop == 2) ? m.dy : m.dz;
+  const float scale = 2047.0f / ((float)max(max(da, db), 1) * m.cell);
+  const uint32_t ia = (uint32_t)min(max((int)(ua * scale), 0), 2047), ib = (uint32_t)min(max((int)(ub * scale), 0), 2047);
+  return hilbert2(ia, ib);
+}
+
 __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
                                                        const GridMeta* __restrict__ meta, float4* __restrict__ pts, int* __restrict__ orig,
-                                                       HashSlot* __restrict__ table, size_t cap, size_t slots_cap, int G, int B) {
+                                                       HashSlot* __restrict__ table, size_t cap, size_t slots_cap, int G, int B,
+                                                       uint32_t* __restrict__ order_keys, int* __restrict__ order_vals) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = meta[c];
@@ -218,8 +245,13 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
   if (i >= m.n) return;
   const size_t o = (size_t)c * cap;
   const int v = vals[o + i];
-  pts[o + i] = in[o + v];
+  const float4 pv = in[o + v];
+  pts[o + i] = pv;
   orig[o + i] = v;
+  if (order_keys) {  // the (key, index) pairs build_tile_order sorts next, while the point is in a register
+    order_keys[o + i] = tile_order_key(m, pv);
+    order_vals[o + i] = i;
+  }
   const uint32_t key = keys[o + i];
   const uint32_t kprev = (i > 0) ? keys[o + i - 1] : 0u, knext = (i < m.n - 1) ? keys[o + i + 1] : 0u;
   HashSlot* tab = table + (size_t)c * slots_cap;
@@ -239,7 +271,7 @@ __global__ void k_copy_counts(const int* in, int* out, int B) {
   if (i < B) out[i] = in[i];
 }
 
-void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell) {
+void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell, bool tile_order_keys) {
   const int B = out.B;
   const size_t cap = out.cap;
   ws_reserve(ws, B, cap);
@@ -254,12 +286,18 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap);
   const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = div_up((long)cap, kHashBlock);
   hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
+  const bool okeys = tile_order_keys && tuning().knn_tiles == 1 && tuning().tile_order;
   hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(kHashBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
-                     out.table.p, cap, out.slots_cap, Gi, B);
+                     out.table.p, cap, out.slots_cap, Gi, B, okeys ? ws.keys_b.p : (uint32_t*)nullptr, okeys ? ws.vals_b.p : (int*)nullptr);
   MI_LAUNCH_CHECK();
+  if (okeys) {  // sort_pairs reads the *_a buffers
+    std::swap(ws.keys_a.p, ws.keys_b.p); std::swap(ws.keys_a.n, ws.keys_b.n);
+    std::swap(ws.vals_a.p, ws.vals_b.p); std::swap(ws.vals_a.n, ws.vals_b.n);
+  }
   out.built = true;
   out.has_cov = false;
   out.has_order = false;
+  out.order_keys_in_ws = okeys;
 }
 
 // ---- k-NN covariances (F2) --------------------------------------------------------------------------------------
@@ -1259,51 +1297,30 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
 // So the tiles are taken along a 2-D Hilbert curve (2^11 cells per axis) over the two longest axes of the cloud's bounding
 // box: one more sort of (key, index) pairs per cloud, 3 radix passes.  The order changes which points share a wave, never a
 // result: every point's neighbours are found exactly whatever its tile is.
-__device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {  // 11 bits per axis -> 22-bit index along the curve
-  uint32_t d = 0;
-#pragma unroll
-  for (int b = 10; b >= 0; b--) {
-    const uint32_t s = 1u << b;
-    const uint32_t rx = (x >> b) & 1u, ry = (y >> b) & 1u;
-    d += s * s * ((3u * rx) ^ ry);
-    if (ry == 0u) {  // rotate the quadrant
-      if (rx == 1u) { x = (s - 1u) - (x & (s - 1u)); y = (s - 1u) - (y & (s - 1u)); }
-      const uint32_t t = x; x = y; y = t;
-    }
-    x &= s - 1u; y &= s - 1u;
-  }
-  return d;
-}
 __global__ __launch_bounds__(256) void k_tile_order_keys(const float4* __restrict__ pts, const GridMeta* __restrict__ meta, uint32_t* __restrict__ keys,
                                                          int* __restrict__ vals, size_t cap) {
   const int c = blockIdx.y;
   const GridMeta m = meta[c];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
-  const float4 p = pts[(size_t)c * cap + i];
-  // the two longest axes of the bounding box (a, b), 2^11 cells over the longer one
-  const int drop = (m.dz <= m.dx && m.dz <= m.dy) ? 2 : ((m.dy <= m.dx) ? 1 : 0);
-  const float ua = (drop == 0) ? p.y - m.oy : p.x - m.ox, ub = (drop == 2) ? p.y - m.oy : p.z - m.oz;
-  const int da = (drop == 0) ? m.dy : m.dx, db = (drop == 2) ? m.dy : m.dz;
-  const float scale = 2047.0f / ((float)max(max(da, db), 1) * m.cell);
-  const uint32_t ia = (uint32_t)min(max((int)(ua * scale), 0), 2047), ib = (uint32_t)min(max((int)(ub * scale), 0), 2047);
-  keys[(size_t)c * cap + i] = hilbert2(ia, ib);
+  keys[(size_t)c * cap + i] = tile_order_key(m, pts[(size_t)c * cap + i]);
   vals[(size_t)c * cap + i] = i;
-}
-__global__ __launch_bounds__(256) void k_copy_order(const int* __restrict__ vals, const int* __restrict__ counts, int* __restrict__ out, size_t cap) {
-  const int c = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < counts[c]) out[(size_t)c * cap + i] = vals[(size_t)c * cap + i];
 }
 // set.tile_order <- the sorted-array indices of every cloud along the 2-D Hilbert curve
 void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set) {
   if (tuning().knn_tiles != 1 || !tuning().tile_order) return;
-  set.tile_order.ensure((size_t)set.B * set.cap);
-  const dim3 grid(div_up((long)set.cap, 256), set.B);
-  hipLaunchKernelGGL(k_tile_order_keys, grid, dim3(256), 0, s, set.pts.p, set.meta.p, ws.keys_a.p, ws.vals_a.p, set.cap);
+  set.tile_order.ensure((size_t)set.B * set.cap);  // (like the workspace's value buffers: the two change hands below)
+  if (!set.order_keys_in_ws) {  // (build_grid(..., tile_order_keys = true) on the same workspace has left them there already)
+    const dim3 grid(div_up((long)set.cap, 256), set.B);
+    hipLaunchKernelGGL(k_tile_order_keys, grid, dim3(256), 0, s, set.pts.p, set.meta.p, ws.keys_a.p, ws.vals_a.p, set.cap);
+  }
+  set.order_keys_in_ws = false;
   sort_pairs(s, ws, set.B, set.cap, set.count.p, 3);
-  hipLaunchKernelGGL(k_copy_order, grid, dim3(256), 0, s, ws.vals_a.p, set.count.p, set.tile_order.p, set.cap);
   MI_LAUNCH_CHECK();
+  // the sorted values ARE the order: the set takes the buffer, the workspace gets the set's old one (no copy pass; everything
+  // that reads either is ordered behind this call on the stream)
+  std::swap(set.tile_order.p, ws.vals_a.p);
+  std::swap(set.tile_order.n, ws.vals_a.n);
   set.has_order = true;
 }
 

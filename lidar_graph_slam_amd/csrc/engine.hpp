@@ -69,6 +69,7 @@ struct CloudSet {
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false, has_order = false;
+  bool order_keys_in_ws = false;  // build_grid(..., tile_order_keys = true) -> build_tile_order, nothing in between on that workspace
   void alloc(int B_, size_t cap_);
 };
 
@@ -96,7 +97,8 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
 void sor_filter(hipStream_t s, Workspace& ws, CloudSet& scratch_set, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B,
                 size_t cap, int mean_k, double stddev_mul, float cell, uint8_t* d_keep, float* d_mean_dist);
 // Build the NN voxel-hash over `in` (any order): sorted points, orig map, hash table.
-void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell);
+// tile_order_keys: the caller runs build_tile_order on the same workspace next — the gather pass leaves the keys of that sort in it
+void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, CloudSet& out, float cell, bool tile_order_keys = false);
 // k-NN covariances with regularisation (F2) for every point of a built CloudSet.
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method);
 // Optional, between build_grid and compute_covariances: the order in which the tile search takes the points (2-D Hilbert curve over the
