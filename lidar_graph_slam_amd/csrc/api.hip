@@ -503,6 +503,7 @@ extern "C" int mi355_covariances(mi355_ctx* ctx, const mi355_cloud_view* pts, in
     FilterScratch& fs = oc.fs;
     if (fs.set.B != 1 || fs.set.cap != oc.cap()) fs.set.alloc(1, oc.cap());
     build_grid(ctx->stream, fs.ws, fs.a.p, fs.na.p, fs.set, ctx->grid_cell);
+    build_tile_order(ctx->stream, fs.ws, fs.set, true);
     compute_covariances(ctx->stream, fs.set, k, method);
     std::vector<Cov6> c(oc.n);
     std::vector<int> orig(oc.n);
@@ -902,6 +903,7 @@ extern "C" int mi355_cloud_compute_covariances(mi355_cloud* cloud, int k, int me
     MI_HIP(hipStreamSynchronize(ctx->stream));  // &ni
     if (fs.set.B != 1 || fs.set.cap != cloud->n) fs.set.alloc(1, cloud->n);
     build_grid(ctx->stream, fs.ws, cloud->pts.p, fs.na.p, fs.set, ctx->grid_cell);
+    build_tile_order(ctx->stream, fs.ws, fs.set, true);
     compute_covariances(ctx->stream, fs.set, k, method);
     cloud->cov.ensure(cloud->n);
     cov_to_caller_order(ctx->stream, fs.set, cloud->n, cloud->cov.p);

@@ -223,9 +223,46 @@ __device__ __forceinline__ uint32_t hilbert2(uint32_t x, uint32_t y) {  // 11 bi
   }
   return d;
 }
+// 7 bits per axis -> 21-bit index along the 3-D Hilbert curve (Skilling's transpose form)
+__device__ __forceinline__ uint32_t hilbert3(uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t X[3] = {x, y, z};
+  constexpr uint32_t M = 1u << 6;
+#pragma unroll
+  for (uint32_t Q = M; Q > 1u; Q >>= 1) {
+    const uint32_t P = Q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+#pragma unroll
+  for (uint32_t Q = M; Q > 1u; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1u;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  uint32_t h = 0;
+#pragma unroll
+  for (int b = 6; b >= 0; b--) h = (h << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+  return h;
+}
 // key of a point in the order the tile searches take the points of a cloud in (build_tile_order below): 2-D Hilbert index over the
-// two longest axes of the bounding box (a, b), 2^11 cells over the longer one
+// two longest axes of the bounding box (a, b), 2^11 cells over the longer one - a scan is 2.5-D.  A cloud that is not (its shortest
+// extent more than half of the middle one: an object, a volume) gets the 3-D curve, 2^7 cells over the longest axis.
 __device__ __forceinline__ uint32_t tile_order_key(const GridMeta& m, const float4& p) {
+  const int d_min = min(m.dx, min(m.dy, m.dz)), d_max = max(m.dx, max(m.dy, m.dz)), d_mid = m.dx + m.dy + m.dz - d_min - d_max;
+  if (2 * d_min > d_mid) {
+    const float scale = 127.0f / ((float)max(d_max, 1) * m.cell);
+    auto q = [&](float v) { return (uint32_t)min(max((int)(v * scale), 0), 127); };
+    return hilbert3(q(p.x - m.ox), q(p.y - m.oy), q(p.z - m.oz));
+  }
   const int drop = (m.dz <= m.dx && m.dz <= m.dy) ? 2 : ((m.dy <= m.dx) ? 1 : 0);
   const float ua = (drop == 0) ? p.y - m.oy : p.x - m.ox, ub = (drop == 2) ? p.y - m.oy : p.z - m.oz;
   const int da = (drop == 0) ? m.dy : m.dx, db = (drop == 2) ? m.dy : m.dz;
@@ -1307,8 +1344,8 @@ __global__ __launch_bounds__(256) void k_tile_order_keys(const float4* __restric
   vals[(size_t)c * cap + i] = i;
 }
 // set.tile_order <- the sorted-array indices of every cloud along the 2-D Hilbert curve
-void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set) {
-  if (tuning().knn_tiles != 1 || !tuning().tile_order) return;
+void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set, bool single_cloud) {
+  if (tuning().knn_tiles != 1 || tuning().tile_order < (single_cloud ? 2 : 1)) return;
   set.tile_order.ensure((size_t)set.B * set.cap);  // (like the workspace's value buffers: the two change hands below)
   if (!set.order_keys_in_ws) {  // (build_grid(..., tile_order_keys = true) on the same workspace has left them there already)
     const dim3 grid(div_up((long)set.cap, 256), set.B);

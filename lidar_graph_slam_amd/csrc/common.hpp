@@ -85,7 +85,7 @@ struct Tuning {
   float brick_gather = 1.0f;  // MI355_BRICK_GATHER      first gather radius of a tile as a multiple of the largest first cube
   int knn_need_div = 2;       // MI355_KNN_NEED_DIV      start level heuristic of the per-lane search
   int tile_waves = 8192;      // MI355_TILE_WAVES        resident one-wave blocks of k_knn_cov_tile over the batch
-  int tile_order = 1;         // MI355_TILE_ORDER        1 = tiles of k_knn_cov_tile along a 2-D Hilbert curve (one more sort per cloud), 0 = along the voxel hash's Morton order
+  int tile_order = 1;         // MI355_TILE_ORDER        1 = batches take the tiles of k_knn_cov_tile along a Hilbert curve (one more sort per cloud), 0 = along the voxel hash's Morton order, 2 = single clouds too (tests)
   float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
   float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for
   int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream

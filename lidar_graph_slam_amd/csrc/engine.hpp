@@ -103,7 +103,9 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
 void compute_covariances(hipStream_t s, CloudSet& set, int k, int method);
 // Optional, between build_grid and compute_covariances: the order in which the tile search takes the points (2-D Hilbert curve over the
 // two long axes of the cloud: cloud.hip).  Changes which points share a wave, never a result.  ws: scratch of the sort.
-void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set);
+// single_cloud: a caller with ONE cloud (registration object, cloud handle): only with MI355_TILE_ORDER=2 — there the sort costs more
+// than the search gains; the switch exists so that the parity tests of the covariances can run on this path.
+void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set, bool single_cloud = false);
 // Exact k-NN of queries (packed float4 [m]) in cloud 0 of a built set; idx in the caller's point order.
 void knn_query(hipStream_t s, const CloudSet& set, const float4* d_queries, int m, int k, int* d_idx, float* d_d2);
 void transform_points(hipStream_t s, const float4* in, float4* out, size_t n, const float* T16_host);
