@@ -1843,7 +1843,9 @@ void sor_filter(hipStream_t s, Workspace& ws, CloudSet& set, const float4* in, c
   if (mean_k < 1 || mean_k > 63) throw ArgError(MI355_EINVAL, "mean_k must be in [1, 63]");
   if (set.B != B || set.cap != cap) set.alloc(B, cap);
   FamilyScope family(KF_SOR);
-  build_grid(s, ws, in, cnt_in, set, cell);
+  build_grid(s, ws, in, cnt_in, set, cell, B > 1);
+  build_tile_order(s, ws, set, B == 1);  // batches: the tiles of the search along the Hilbert curve, like the covariances'
+  const int* order = set.has_order ? set.tile_order.p : nullptr;
   ws.fscratch.ensure((size_t)B * cap);
   ws.dscratch.ensure(B);
   float* md = d_mean_dist ? d_mean_dist : ws.fscratch.p;
@@ -1852,10 +1854,10 @@ void sor_filter(hipStream_t s, Workspace& ws, CloudSet& set, const float4* in, c
   if (tuning().knn_tiles) {
     // the (mean_k + 1)-NN of every point is the covariance kernels' search with another epilogue: wave-cooperative tiles, the
     // wave-per-query kernel for what they hand over (round 2 walked the hash per lane here: 0.98 ms for ONE 64 k-ray cloud)
-    if (kk <= 8) launch_covariances<8, true>(s, set, kk, 0, md);
-    else if (kk <= 16) launch_covariances<16, true>(s, set, kk, 0, md);
-    else if (kk <= 32) launch_covariances<32, true>(s, set, kk, 0, md);
-    else launch_covariances<64, true>(s, set, kk, 0, md);
+    if (kk <= 8) launch_covariances<8, true>(s, set, kk, 0, md, order);
+    else if (kk <= 16) launch_covariances<16, true>(s, set, kk, 0, md, order);
+    else if (kk <= 32) launch_covariances<32, true>(s, set, kk, 0, md, order);
+    else launch_covariances<64, true>(s, set, kk, 0, md, order);
   } else {
 #define MI_SOR(KK) hipLaunchKernelGGL(k_sor_meandist<KK>, grid, dim3(256), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, md, cap, set.slots_cap, mean_k)
     if (kk == 31) MI_SOR(31);
