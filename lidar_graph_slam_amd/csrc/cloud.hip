@@ -598,16 +598,27 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
   const int mysub = lane / kSubQ, sublane = lane % kSubQ;
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int z = lane; z < kNSub * kSubRow; z += kWave) (&sub[0][0])[z] = 0;
+  // The chain tile counter -> (tile order ->) points of a tile is three dependent memory operations, 5 % of a tile's time when it
+  // runs at the top of the loop.  A wave therefore claims its NEXT tile while it starts on the current one, reads that tile's slice of
+  // the order once its own first gather is back, and the points when it enters the covariance epilogue: all three arrive under work.
+  int tile_nx = 0;
+  if (lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);
+  int i_nx = 0, pf = 0;  // next tile: this lane's point index (pf >= 1), its point (pf == 2)
+  float4 q_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch_index = [&](int t0) {
+    int j = t0 + lane;
+    if (tile_order && j < n) j = tile_order[(size_t)c * cap + j];  // tiles in an order of their own (build_tile_order)
+    return j;
+  };
   for (;;) {
-  int tile = 0;
-  if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
-  const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
+  const int tile0 = __builtin_amdgcn_readfirstlane(tile_nx) * kWave;
   if (tile0 >= n) break;
   if constexpr (STATS) st_tiles++;
   int t_segs = 0, t_cands = 0, t_fail_cells = 0, t_fail_list = 0;  // STATS only
-  int i = tile0 + lane;
-  if (tile_order && i < n) i = tile_order[(size_t)c * cap + i];  // tiles in an order of their own (launch_covariances)
-  float4 q = g.pts[min(i, n - 1)];
+  int i = pf >= 1 ? i_nx : fetch_index(tile0);
+  float4 q = pf == 2 ? q_nx : g.pts[min(i, n - 1)];
+  pf = 0;
+  if (lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);  // (a wave's last claim is a tile that does not exist)
   if (i >= n) q.x = q.y = q.z = INFINITY;  // past the end of the cloud: sorts to the last lanes, never active
 #ifndef KNN_ABL_NO_KD  // (KNN_ABL_*: timing ablations of benchmarks/knn_only.py, never defined in the product build)
   // along the curve of build_tile_order every aligned group of 16 lanes is a compact patch already (measured: 8.7 ms without this, 9.4 ms with)
@@ -690,6 +701,11 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           ob = nb;
           has_old = true;
           R = Rn;
+          if (pf == 0) {  // the counter's answer has been back for a while: the next tile's slice of the order goes out now
+            const int t0 = __builtin_amdgcn_readfirstlane(tile_nx) * kWave;
+            i_nx = t0 < n ? fetch_index(t0) : n;
+            pf = 1;
+          }
           if constexpr (STATS) st_cands += n_new - n_ord;
           n_ord = n_new;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes
@@ -802,6 +818,10 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
         }
       }
       phase(5);
+      if (pf == 1) {
+        if (i_nx < n) q_nx = g.pts[i_nx];
+        pf = 2;
+      }
       if constexpr (STATS) { if (!split) t_cands += n_ord; }
       if (!split) {
         // closed lanes: exact unless truncation could have swapped the k-th and (k+1)-th candidates (or they tie exactly)
