@@ -1418,7 +1418,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
     MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 32 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR, true>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                        mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
-                       tn.tile_gather, tile_order, set.knn_stats.p);
+                       tile_order ? tn.tile_gather : 1.0f, tile_order, set.knn_stats.p);
     MI_HIP(hipStreamSynchronize(s));
     unsigned long long st[32];
     MI_HIP(hipMemcpy(st, set.knn_stats.p, sizeof(st), hipMemcpyDeviceToHost));
@@ -1440,7 +1440,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
     TimedLaunch tl(KF_KNN_COV_TILE, s);
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                        mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
-                       tn.tile_gather, tile_order);
+                       tile_order ? tn.tile_gather : 1.0f, tile_order);
   }
   // the points the tile kernel handed over: one wave per point, covariance included
   const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves

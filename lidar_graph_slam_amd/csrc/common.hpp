@@ -87,7 +87,7 @@ struct Tuning {
   int tile_waves = 8192;      // MI355_TILE_WAVES        resident one-wave blocks of k_knn_cov_tile over the batch
   int tile_order = 1;         // MI355_TILE_ORDER        1 = batches take the tiles of k_knn_cov_tile along a Hilbert curve (one more sort per cloud), 0 = along the voxel hash's Morton order, 2 = single clouds too (tests)
   float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
-  float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for
+  float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for, when the tiles follow build_tile_order (along the Morton order a wider gather was measured slower: 1.0)
   int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
   int corr_tiles = 4;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
