@@ -473,6 +473,10 @@ __device__ __forceinline__ float sor_mean_distance(int k, const float4& q, P&& p
 // fallback queue and are done by k_knn_hard + k_cov_from_knn.  A tile whose own box is too large (it straddles a jump of
 // the Morton curve, or lies in the sparse far field) is split into halves, processed one after the other by the whole wave.
 constexpr int kOrdBits = 10;
+#ifndef KNN_TILE_PREFETCH
+#define KNN_TILE_PREFETCH 1
+#endif
+constexpr bool kTilePrefetch = KNN_TILE_PREFETCH != 0;  // fetch the next tile under the current one (k_knn_cov_tile)
 #ifndef KNN_TILE_CAND  // (KNN_*: overridable for A/B builds, benchmarks/build_variant.sh)
 #define KNN_TILE_CAND 768
 #define KNN_SUB_CAP 764
@@ -601,8 +605,11 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
   // The chain tile counter -> (tile order ->) points of a tile is three dependent memory operations, 5 % of a tile's time when it
   // runs at the top of the loop.  A wave therefore claims its NEXT tile while it starts on the current one, reads that tile's slice of
   // the order once its own first gather is back, and the points when it enters the covariance epilogue: all three arrive under work.
+  // (Only where a wave takes several tiles: claiming ahead with one tile per wave - a lone 16 k-point cloud - leaves every second wave
+  // without one: 262 instead of 211 us for that launch.)
+  const bool ahead = kTilePrefetch && n > 4 * kWave * G;
   int tile_nx = 0;
-  if (lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);
+  if (ahead && lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);
   int i_nx = 0, pf = 0;  // next tile: this lane's point index (pf >= 1), its point (pf == 2)
   float4 q_nx = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch_index = [&](int t0) {
@@ -611,6 +618,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
     return j;
   };
   for (;;) {
+  if (!ahead && lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);
   const int tile0 = __builtin_amdgcn_readfirstlane(tile_nx) * kWave;
   if (tile0 >= n) break;
   if constexpr (STATS) st_tiles++;
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
   int i = pf >= 1 ? i_nx : fetch_index(tile0);
   float4 q = pf == 2 ? q_nx : g.pts[min(i, n - 1)];
   pf = 0;
-  if (lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);  // (a wave's last claim is a tile that does not exist)
+  if (ahead && lane == 0) tile_nx = atomicAdd(&tile_ctr[c], 1);  // (a wave's last claim is a tile that does not exist)
   if (i >= n) q.x = q.y = q.z = INFINITY;  // past the end of the cloud: sorts to the last lanes, never active
 #ifndef KNN_ABL_NO_KD  // (KNN_ABL_*: timing ablations of benchmarks/knn_only.py, never defined in the product build)
   // along the curve of build_tile_order every aligned group of 16 lanes is a compact patch already (measured: 8.7 ms without this, 9.4 ms with)
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           ob = nb;
           has_old = true;
           R = Rn;
-          if (pf == 0) {  // the counter's answer has been back for a while: the next tile's slice of the order goes out now
+          if (ahead && pf == 0) {  // the counter's answer has been back for a while: the next tile's slice of the order goes out now
             const int t0 = __builtin_amdgcn_readfirstlane(tile_nx) * kWave;
             i_nx = t0 < n ? fetch_index(t0) : n;
             pf = 1;
