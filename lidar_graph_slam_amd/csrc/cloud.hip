@@ -1729,20 +1729,56 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ i
   vals[(size_t)c * cap + i] = i;
 }
 
-__global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict__ keys, const GridMeta* __restrict__ vmeta, int* __restrict__ flags,
-                                                     size_t cap, const float4* __restrict__ in, double min_distance) {
+// Is sorted element i the head of a voxel's run (or, when the index overflowed and VoxelGrid passes its input through - "Leaf size
+// is too small" -, a point the fused distance filter keeps; all keys are empty then and the stable sort left the points in order)?
+__device__ __forceinline__ int voxel_head(const GridMeta& m, const uint32_t* __restrict__ k, const float4* __restrict__ in, int i, uint32_t prev,
+                                          double min_distance) {
+  if (m.overflow) return passes_distance(in[i], min_distance) ? 1 : 0;
+  const uint32_t kk = k[i];
+  return (kk != kEmptyKey && (i == 0 || kk != prev)) ? 1 : 0;
+}
+// First stage of the scan of those head flags (sort.hip, k_scan_local) with the flags derived on the fly: writing them out and
+// reading them back cost a kernel and 1 GB per 2 048-cloud launch.  Output as k_scan_local's: ws.scan_local, ws.scan_block.
+__global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __restrict__ keys, const GridMeta* __restrict__ vmeta, const float4* __restrict__ in,
+                                                          int* __restrict__ local, int* __restrict__ blocksum, size_t cap, int nblk, double min_distance) {
+  __shared__ int wsum[4];
   const int c = blockIdx.y;
   const GridMeta m = vmeta[c];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
+  const int n = m.n;
+  const int base = blockIdx.x * kScanTile;
+  if (base >= n) {
+    if (threadIdx.x == 0) blocksum[(size_t)c * nblk + blockIdx.x] = 0;
+    return;
+  }
   const size_t o = (size_t)c * cap;
-  const uint32_t k = keys[o + i];
-  int f;
-  // overflow ("Leaf size is too small"): VoxelGrid passes its input through — with the fused distance filter that input is what
-  // the filter keeps (all keys are empty then, so the stable sort left the points in their original order)
-  if (m.overflow) f = passes_distance(in[o + i], min_distance) ? 1 : 0;
-  else f = (k != kEmptyKey) && (i == 0 || keys[o + i - 1] != k);
-  flags[o + i] = f;
+  const uint32_t* k = keys + o;
+  int* lo = local + o;
+  const int i0 = base + threadIdx.x * 4;
+  int v[4];
+  uint32_t prev = (i0 > 0 && i0 - 1 < n) ? k[i0 - 1] : kEmptyKey;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    v[j] = (i0 + j < n) ? voxel_head(m, k, in + o, i0 + j, prev, min_distance) : 0;
+    prev = (i0 + j < n) ? k[i0 + j] : kEmptyKey;
+  }
+  const int s = v[0] + v[1] + v[2] + v[3];
+  int incl = s;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int t = __shfl_up(incl, off, kWave);
+    if (lane_id() >= off) incl += t;
+  }
+  if (lane_id() == kWave - 1) wsum[wave_id()] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wave_id(); w++) wbase += wsum[w];
+  int run = wbase + incl - s;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (i0 + j < n) lo[i0 + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == 255) blocksum[(size_t)c * nblk + blockIdx.x] = wbase + incl;
 }
 
 // One thread per sorted point; the thread at the head of a voxel's run adds the run in ascending point-index order (the
@@ -1752,9 +1788,10 @@ __global__ __launch_bounds__(256) void k_voxel_heads(const uint32_t* __restrict_
 // handed to its head by lane shuffles.
 __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                          const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
-                                                         const int* __restrict__ flags, const int* __restrict__ local,
+                                                         const int* __restrict__ local,
                                                          const int* __restrict__ blockoff, const int* __restrict__ totals,
-                                                         float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G, int B) {
+                                                         float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G, int B,
+                                                         double min_distance) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = vmeta[c];
@@ -1763,7 +1800,7 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
   if (bx * (int)blockDim.x >= m.n) return;  // whole block past the end of the cloud
   const size_t o = (size_t)c * cap;
   const bool valid = i < m.n;
-  const bool head = valid && flags[o + i] != 0;
+  const bool head = valid && voxel_head(m, keys + o, in + o, i, i > 0 ? keys[o + i - 1] : kEmptyKey, min_distance) != 0;
   if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (k_voxel_heads flagged what passes through)
     if (head) out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = in[o + i];
     return;
@@ -1820,12 +1857,15 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   const dim3 grid(div_up((long)cap, kPointBlock), B);
   hipLaunchKernelGGL(k_voxel_keys, grid, dim3(kPointBlock), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap, min_distance);
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
-  hipLaunchKernelGGL(k_voxel_heads, grid, dim3(kPointBlock), 0, s, ws.keys_a.p, ws.vmeta.p, ws.flags.p, cap, in, min_distance);
-  scan_flags(s, ws, B, cap, cnt_in);
+  const int nblk = div_up((long)cap, kScanTile);
+  ws.scan_local.ensure((size_t)B * cap);
+  ws.scan_block.ensure((size_t)B * nblk);
+  hipLaunchKernelGGL(k_voxel_scan_heads, dim3(nblk, B), dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, in, ws.scan_local.p, ws.scan_block.p, cap, nblk, min_distance);
+  scan_blocks(s, ws, B, cap);
   const int Gv = div_up((long)cap, kPointBlock);
   TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
-  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kPointBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.flags.p, ws.scan_local.p,
-                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, div_up((long)cap, kScanTile), Gv, B);
+  hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kPointBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.scan_local.p,
+                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, nblk, Gv, B, min_distance);
   MI_LAUNCH_CHECK();
 }
 

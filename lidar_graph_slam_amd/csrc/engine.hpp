@@ -81,6 +81,7 @@ struct CloudSet {
 void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes = nullptr);
 // Exclusive scan of ws.flags per cloud: position(i) = ws.scan_local[i] + ws.scan_block[c*nblk + i/1024]; totals[c].
 void scan_flags(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts);
+void scan_blocks(hipStream_t s, Workspace& ws, int B, size_t cap);  // the second stage alone (the caller's kernel did the first)
 constexpr int kScanTile = 1024;
 
 // ---- cloud.hip -----------------------------------------------------------------------------------------------

@@ -440,6 +440,14 @@ __global__ __launch_bounds__(256) void k_scan_blocks(int* __restrict__ blocksum,
   if (threadIdx.x == 255) totals[blockIdx.x] = wbase + incl;
 }
 
+// Second stage alone: for a caller whose own kernel has produced ws.scan_local / ws.scan_block the way k_scan_local does.
+void scan_blocks(hipStream_t s, Workspace& ws, int B, size_t cap) {
+  const int nblk = div_up((long)cap, kScanTile);
+  ws.totals.ensure(B);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(B), dim3(256), 0, s, ws.scan_block.p, ws.totals.p, nblk);
+  MI_LAUNCH_CHECK();
+}
+
 void scan_flags(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts) {
   const int nblk = div_up((long)cap, kScanTile);
   ws.scan_local.ensure((size_t)B * cap);
