@@ -415,7 +415,9 @@ extern "C" int mi355_sor(mi355_ctx* ctx, const mi355_cloud_view* in, int mean_k,
 // distance -> voxel -> SOR on device; returns the buffer holding the result (a or b of `fs`-like scratch)
 static void run_prefilter(hipStream_t s, Workspace& ws, CloudSet& sor_set, float grid_cell, const mi355_prefilter_params& p, int B, size_t cap,
                           const float4* in, const int* cnt_in, DevBuf<float4>& a, DevBuf<float4>& b, DevBuf<int>& na, DevBuf<int>& nb,
-                          const float4** out, const int** cnt_out) {
+                          const float4** out, const int** cnt_out, CloudSet* index_next = nullptr) {
+  // index_next: the set the caller indexes the result into next, on the same workspace (voxel_grid prepares that index's keys when
+  // it is the last stage)
   a.ensure((size_t)B * cap); b.ensure((size_t)B * cap);
   na.ensure(B); nb.ensure(B);
   const float4* cur = in;
@@ -433,7 +435,7 @@ static void run_prefilter(hipStream_t s, Workspace& ws, CloudSet& sor_set, float
   }
   if (p.leaf_size > 0) {
     next(&dst, &ndst);
-    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size, fused ? p.min_distance : -1.0);
+    voxel_grid(s, ws, cur, ncur, dst, ndst, B, cap, (float)p.leaf_size, fused ? p.min_distance : -1.0, p.mean_k > 0 ? nullptr : index_next, grid_cell);
     cur = dst; ncur = ndst;
   }
   if (p.mean_k > 0) {
@@ -1151,7 +1153,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
   const int* cnt = sd.cnt_in.p;
   if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
     run_prefilter(s, sd.ws, sd.sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, sd.cnt_in.p, sd.ws.stage_a, sd.ws.stage_b, sd.ws.count_a,
-                  sd.ws.count_b, &pts, &cnt);
+                  sd.ws.count_b, &pts, &cnt, &set);
   build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell, b->method == MI355_METHOD_FAST_GICP);
   if (b->method == MI355_METHOD_NDT_OMP) {
     // NDT: the sources are just points; every target gets its voxel Gaussians (N1).  The leaf builder sizes its launches on

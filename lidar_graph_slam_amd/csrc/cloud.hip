@@ -325,11 +325,15 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   const int B = out.B;
   const size_t cap = out.cap;
   ws_reserve(ws, B, cap);
-  compute_bounds(s, ws, in, cnt_in, B, cap);
-  hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, out.meta.p, B, cell, ws.sort_passes.p);
-  hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
   const dim3 grid(div_up((long)cap, kHashBlock), B);
-  hipLaunchKernelGGL(k_cell_keys, grid, dim3(kHashBlock), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
+  if (out.cell_keys_in_ws) {  // voxel_grid(..., index_next = &out) on this workspace has left meta, keys and sort passes behind
+    out.cell_keys_in_ws = false;
+  } else {
+    compute_bounds(s, ws, in, cnt_in, B, cap);
+    hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, out.meta.p, B, cell, ws.sort_passes.p);
+    hipLaunchKernelGGL(k_cell_keys, grid, dim3(kHashBlock), 0, s, in, out.meta.p, ws.keys_a.p, ws.vals_a.p, cap);
+  }
+  hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
   TimedLaunch tl(KF_HASH_BUILD, s);
   hipLaunchKernelGGL(k_count_cells, grid, dim3(kHashBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
@@ -1791,7 +1795,8 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
                                                          const int* __restrict__ local,
                                                          const int* __restrict__ blockoff, const int* __restrict__ totals,
                                                          float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G, int B,
-                                                         double min_distance) {
+                                                         double min_distance, const GridMeta* __restrict__ next_meta, uint32_t* __restrict__ next_keys,
+                                                         int* __restrict__ next_vals) {
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = vmeta[c];
@@ -1801,8 +1806,17 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
   const size_t o = (size_t)c * cap;
   const bool valid = i < m.n;
   const bool head = valid && voxel_head(m, keys + o, in + o, i, i > 0 ? keys[o + i - 1] : kEmptyKey, min_distance) != 0;
-  if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (k_voxel_heads flagged what passes through)
-    if (head) out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = in[o + i];
+  // next_meta: the voxel hash that indexes this filter's output next (voxel_grid's `index_next`) - the output point's cell key is
+  // written while the point is in a register, so build_grid needs neither a bounds pass nor a key pass over the output
+  auto emit = [&](int pos, const float4& pt) {
+    out[o + pos] = pt;
+    if (next_meta) {
+      next_keys[o + pos] = cell_key(next_meta[c], pt.x, pt.y, pt.z);
+      next_vals[o + pos] = pos;
+    }
+  };
+  if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (what the fused distance filter keeps)
+    if (head) emit(local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile], in[o + i]);
     return;
   }
   // EVERY lane fetches the point at its sorted position (one gather per lane, all in flight together); a head then adds the
@@ -1846,11 +1860,11 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
     }
   }
   const float fc = (float)cnt;
-  out[o + local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile]] = make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc);
+  emit(local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile], make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc));
 }
 
 void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf,
-                double min_distance) {
+                double min_distance, CloudSet* index_next, float index_cell) {
   ws_reserve(ws, B, cap);
   compute_bounds(s, ws, in, cnt_in, B, cap, min_distance);
   hipLaunchKernelGGL(k_voxel_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, ws.vmeta.p, B, leaf, ws.sort_passes.p);
@@ -1862,11 +1876,23 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   ws.scan_block.ensure((size_t)B * nblk);
   hipLaunchKernelGGL(k_voxel_scan_heads, dim3(nblk, B), dim3(256), 0, s, ws.keys_a.p, ws.vmeta.p, in, ws.scan_local.p, ws.scan_block.p, cap, nblk, min_distance);
   scan_blocks(s, ws, B, cap);
+  if (index_next) {
+    // The voxel hash of the OUTPUT gets its geometry now - from the bounds of what goes into the centroids (they lie inside) and the
+    // output counts the scan has just produced - so that the centroid pass can write the cell keys of build_grid's sort.
+    if (index_next->B != B || index_next->cap != cap) throw ArgError(MI355_EINVAL, "voxel_grid: index_next has another shape");
+    hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, ws.totals.p, index_next->meta.p, B, index_cell, ws.sort_passes.p);
+  }
   const int Gv = div_up((long)cap, kPointBlock);
   TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
   hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kPointBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.scan_local.p,
-                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, nblk, Gv, B, min_distance);
+                     ws.scan_block.p, ws.totals.p, out, cnt_out, cap, nblk, Gv, B, min_distance,
+                     index_next ? (const GridMeta*)index_next->meta.p : (const GridMeta*)nullptr, ws.keys_b.p, ws.vals_b.p);
   MI_LAUNCH_CHECK();
+  if (index_next) {  // sort_pairs reads the *_a buffers
+    std::swap(ws.keys_a.p, ws.keys_b.p); std::swap(ws.keys_a.n, ws.keys_b.n);
+    std::swap(ws.vals_a.p, ws.vals_b.p); std::swap(ws.vals_a.n, ws.vals_b.n);
+    index_next->cell_keys_in_ws = true;
+  }
 }
 
 // ---- P2: pcl::StatisticalOutlierRemoval -------------------------------------------------------------------------

@@ -69,6 +69,7 @@ struct CloudSet {
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false, has_order = false;
+  bool cell_keys_in_ws = false;   // voxel_grid(..., index_next = this) -> build_grid, nothing in between on that workspace
   bool order_keys_in_ws = false;  // build_grid(..., tile_order_keys = true) -> build_tile_order, nothing in between on that workspace
   void alloc(int B_, size_t cap_);
 };
@@ -92,8 +93,10 @@ void distance_filter(hipStream_t s, Workspace& ws, const float4* in, const int* 
                      double min_distance);
 // VoxelGrid (P1): in -> out centroids in ascending voxel index.  min_distance >= 0 fuses the distance filter (A1) in front of
 // it: the points the filter drops take no part (same output as filter-then-grid, without the flag / scan / compact passes).
+// index_next (optional): the CloudSet that build_grid indexes this filter's output into NEXT, on the same workspace with nothing in between
+// (base cell index_cell): its geometry is fixed here and the centroid pass leaves the cell keys of build_grid's sort in the workspace.
 void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf,
-                double min_distance = -1.0);
+                double min_distance = -1.0, CloudSet* index_next = nullptr, float index_cell = 0.f);
 // SOR (P2): in -> out, order preserved.  Optional diagnostics (device pointers, [B*cap]).
 void sor_filter(hipStream_t s, Workspace& ws, CloudSet& scratch_set, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B,
                 size_t cap, int mean_k, double stddev_mul, float cell, uint8_t* d_keep, float* d_mean_dist);
