@@ -596,6 +596,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
                                                      size_t slots_cap, int k, int method, int G, int B, float r_scale, float gather_scale,
                                                      const int* __restrict__ tile_order = nullptr, unsigned long long* __restrict__ stats = nullptr) {
   int st_tiles = 0, st_segs = 0, st_rounds = 0, st_gathers = 0, st_cands = 0, st_build = 0, st_rank = 0, st_direct = 0;  // STATS only
+  int st_fb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // STATS only: lanes handed over, by reason
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // STATS only: shader clocks per phase of the tile loop
   auto phase = [&](int w) {
     if constexpr (STATS) {
@@ -720,7 +721,10 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
               continue;
             }
             if (!has_old && len > 8) split = true;
-            else fb = fb || open;
+            else {
+              if constexpr (STATS) st_fb[0] += __popcll(__ballot(open && !fb));
+              fb = fb || open;
+            }
             break;
           }
           ob = nb;
@@ -782,6 +786,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
             slen = 0;
             rs = fmaxf(0.5f * rs, rmin);
           } else if (over) {
+            if constexpr (STATS) st_fb[1] += __popcll(__ballot(open && !fb));
             fb = fb || open;
             slen = kSubCap;
           }
@@ -817,6 +822,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
         const unsigned long long om = __ballot(open);
         if (!om) break;
         if (round >= 6) {
+          if constexpr (STATS) st_fb[2] += __popcll(__ballot(open && !fb));
           fb = fb || open;
           break;
         }
@@ -830,6 +836,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           float want = (near > 0.f) ? near : far;
           want = fminf(fmaxf(want, 1.02f * rs), rcap);
           if (!(want > rs)) {  // at the radius cap: the open lanes of this sub-tile are handed over
+            if constexpr (STATS) st_fb[3] += __popcll(__ballot(open && !fb));
             fb = fb || open;
             take = false;
           } else {
@@ -866,6 +873,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           }
         }
         const bool exact = closed && (clear || pair);
+        if constexpr (STATS) st_fb[4] += __popcll(__ballot((act && !exact) && !fb));
         fb = fb || (act && !exact);
         if constexpr (SOR) {
           if (exact) mean_dist[(size_t)c * cap + g.orig[i]] = sor_mean_distance<K>(k, q, [&](int t) { return cand[keys.v[t] & kOrdMask]; });
@@ -914,6 +922,8 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
       atomicAdd(&stats[4], (unsigned long long)st_cands); atomicAdd(&stats[5], (unsigned long long)st_build);
       atomicAdd(&stats[6], (unsigned long long)st_rank); atomicAdd(&stats[7], (unsigned long long)st_direct);
       for (int w = 0; w < 8; w++) atomicAdd(&stats[8 + w], (unsigned long long)ph[w]);
+      for (int w = 0; w < 4; w++) atomicAdd(&stats[28 + w], (unsigned long long)st_fb[w]);
+      atomicAdd(&stats[15], 0ull);
     }
   }
 }
@@ -1451,6 +1461,8 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
     fprintf(stderr, "[mi355] k-NN tiles by segments run (1..7+): %llu %llu %llu %llu %llu %llu %llu; split tiles whose lists fit one list together: %llu, candidates of split tiles %.0f each; "
             "gathers over budget: %llu by cells / loads, %llu by list length\n", st[17], st[18], st[19], st[20], st[21], st[22], st[23], st[24],
             (double)st[27] / std::max(1ull, st[18] + st[19] + st[20] + st[21] + st[22] + st[23]), st[25], st[26]);
+    fprintf(stderr, "[mi355] k-NN lanes handed over by reason: gather over budget after the first round / a segment of 8 %llu, sub-list overflow while growing %llu, "
+            "round limit %llu, radius cap %llu, (not exact: ties / truncation: the rest)\n", st[28], st[29], st[30], st[31]);
     {
       double all = 0;
       for (int w = 0; w < 8; w++) all += (double)st[8 + w];
