@@ -75,7 +75,7 @@ inline int div_up(long a, long b) { return (int)((a + b - 1) / b); }
 // ---- tuning knobs ------------------------------------------------------------------------------------------------
 // Launch-geometry knobs, read ONCE per process from MI355_* environment variables (api.hip).  Results never depend on them.
 struct Tuning {
-  int blocks_per_pair = 0;    // MI355_BLOCKS_PER_PAIR   k_gicp_correspond blocks per pair (0 = from the batch size: 16 .. 64)
+  int blocks_per_pair = 0;    // MI355_BLOCKS_PER_PAIR   k_gicp_correspond blocks per pair (0 = from the batch size: 2 .. 64)
   int corr_ppt = 1;           // MI355_PPT               points per thread and pass in k_gicp_correspond (1 or 4)
   int blocks_lin = 0;         // MI355_BLOCKS_LIN        blocks per pair of the streaming kernels (0 = from the batch size)
   int lin_ppt = 1;            // MI355_LIN_PPT           points per thread and tile in k_gicp_linearize (1, 2, 4)

@@ -56,13 +56,15 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.ppt = tn.corr_ppt == 1 ? 1 : 4;
   gb.S = S;
   gb.cap = cap;
-  // One pair is worked on by 16 - 64 blocks of 256 threads that all land on one XCD (primitives.hpp): about 16 k blocks over the
-  // batch.  In steady state a block's life is a chain of dependent loads (pair state, points, stored queries) around very little
+  // One pair is worked on by 2 - 64 blocks of 256 threads that all land on one XCD (primitives.hpp).  In steady state a block's life is a chain of dependent loads (pair state, points, stored queries) around very little
   // work, so a big batch wants fewer blocks that each walk several tiles — measured at 1 024 pairs: 64 blocks per pair 74.5 ms per
   // step (k_gicp_correspond 12.9, the tile kernel 8.2), 16: 72.1 ms (12.2 / 7.4), 8: 72.4, 4: 73.5; at 128 pairs 64 is best
-  // (12.7 ms per step against 13.2 at 16).
+  // (12.7 ms per step against 13.2 at 16).  Round 3, with the per-lane kernel searching its queue a block's worth at a time (a block
+  // that walks several tiles fills its queue) - about 8 k blocks over the batch: 1 024 pairs 16 / 8 / 6 blocks per pair 60.6 / 59.9 /
+  // 59.6 ms per step, 2 048 pairs 16 / 8 / 4 / 2: 114.1 / 112.8 / 112.0 / 112.0 ms, 4 096 pairs 16 / 4 / 2: 222.4 / 215.2 / 214.8 ms
+  // (benchmarks/bpp_sweep.sh).
   (void)compute_units;
-  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(16, std::min(64, 16384 / std::max(S, 1)));
+  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(2, std::min(64, 8192 / std::max(S, 1)));
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
