@@ -69,8 +69,12 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.blocks_per_pair = G;
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
   // few, long-lived blocks: each block streams several tiles (software-pipelined) and pays ONE 29-value fp64 reduction;
-  // about 512 blocks over the batch, at least 4 per pair, never more than the tiles a cloud can have
-  gb.blocks_lin = std::max(1, std::min(std::max(4, std::min(32, 512 / std::max(S, 1))), div_up((long)cap, kGicpBlock * 2)));
+  // about 512 blocks over the batch for a few pairs; big batches 6 per pair (3 from 4 096 pairs on), never more than the tiles a cloud
+  // can have.  (6 / 3 rather than the 4 of round 2: k_gicp_linearize holds 3 blocks per CU, 768 over the chip, and a launch of
+  // pairs x 4 blocks ends in a part-filled last round - measured at 512 / 1 024 / 2 048 / 4 096 pairs, 4 against the value chosen:
+  // 33.2 / 32.7, 59.2 / 58.8, 111.2 / 110.5, 214.6 / 212.7 ms per step, benchmarks/geometry_sweep.sh)
+  const int per_pair = std::max(S <= 2048 ? 6 : 3, std::min(32, 512 / std::max(S, 1)));
+  gb.blocks_lin = std::max(1, std::min(per_pair, div_up((long)cap, kGicpBlock * 2)));
   if (tn.blocks_lin > 0) gb.blocks_lin = tn.blocks_lin;
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
