@@ -1431,8 +1431,10 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
   set.fbhint.ensure((size_t)set.B * set.cap);
   set.fbn.ensure((size_t)2 * set.B);  // [0, B) fallback queue lengths, [B, 2B) tile counters
   MI_HIP(hipMemsetAsync(set.fbn.p, 0, sizeof(int) * 2 * set.B, s));
-  // about two resident waves per SIMD over the whole batch, at least 8 and at most one wave per tile of a cloud
-  const int Gt = max(min(tn.tile_waves / max(set.B, 1), div_up((long)set.cap, kWave)), 8);
+  // about two resident waves per SIMD over the whole batch, at most one wave per tile of a cloud, at least 16 per cloud (8 until
+  // round 3; per 2 048-cloud launch 4 / 8 / 16 / 32 waves per cloud: 16.8 / 16.5 / 16.1 / 16.3 ms on the knn_only clouds - the waves
+  // of a cloud finish together, so more of them shorten the tail each cloud leaves on its XCD).  MI355_TILE_WAVES < 0: that many per cloud.
+  const int Gt = tn.tile_waves < 0 ? -tn.tile_waves : max(min(tn.tile_waves / max(set.B, 1), div_up((long)set.cap, kWave)), 16);
   unsigned long long* d_stats = nullptr;
   if (tn.knn_tiles >= 2 && !SOR) {  // cell bricks in LDS (MI355_KNN_TILES=2; measured slower than the sub-tile lists so far: DESIGN 4.4)
     TimedLaunch tl(KF_KNN_COV_TILE, s);
