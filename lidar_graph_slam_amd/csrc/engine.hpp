@@ -129,6 +129,7 @@ struct GicpBatch {
   int S = 0;           // sources (= pairs)
   size_t cap = 0;
   int blocks_per_pair = 0;   // k_gicp_correspond geometry
+  int blocks_tile = 1;  // blocks per pair of k_gicp_correspond_tile
   int blocks_lin = 0;        // streaming kernels geometry
   DevBuf<int> tgt_of_src;
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point

@@ -67,6 +67,8 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(2, std::min(64, 8192 / std::max(S, 1)));
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
+  // (the tile search likes twice as many: 2 048 pairs 4 / 8 / 16 blocks per pair 16.0 / 15.7 / 15.9 ms per step, 4 096 pairs 2 / 6: 30.8 / 30.2)
+  gb.blocks_tile = tn.blocks_per_pair > 0 ? G : std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cap, kGicpBlock)));
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
   // few, long-lived blocks: each block streams several tiles (software-pipelined) and pays ONE 29-value fp64 reduction;
   // about 512 blocks over the batch for a few pairs; big batches 6 per pair (3 from 4 096 pairs on), never more than the tiles a cloud
@@ -1402,9 +1404,9 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     const bool groups = search >= 0 ? search == 2 : (gb.S < 8 && tn.corr_groups != 0);
     if (tiles) {
       TimedLaunch tl(KF_CORRESPOND_TILE, s);
-      hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
+      hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_tile, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
                          tgt.pts.p, tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p,
-                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_per_pair, gb.S, gb.corr_stats.p, (double)tn.margin_step,
+                         gb.qsearch.p, P.max_corr_d2, tn.corr_r1, gb.blocks_tile, gb.S, gb.corr_stats.p, (double)tn.margin_step,
                          (src.has_order && src.cap == gb.cap) ? (const int*)src.tile_order.p : (const int*)nullptr);
     }
     TimedLaunch tl(KF_CORRESPOND, s);
