@@ -169,7 +169,7 @@ struct mi355_batch {
   GicpBatch gb;
   KernelTimers timers;  // mi355_batch_set_timing / mi355_batch_kernel_times
   int side_streams = -1;  // mi355_batch_set_side_streams: -1 = the library default (Tuning::side_streams), 0 / 1 = off / on
-  DevBuf<float4> host_stage;
+  DevBuf<float4> host_stage_tgt, host_stage_src;  // device copies of host inputs, one per side: a side's next upload is ordered behind the align that joined its last chain
   DevBuf<float4> cloud_stage_src, cloud_stage_tgt;  // mi355_batch_set_*_clouds: the slots assembled on the device
   hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
   bool has_own_stream = false;
@@ -1219,18 +1219,25 @@ static int batch_set_host(mi355_batch* b, bool targets, const float* points, con
   return guarded(b->ctx, [&] {
     MI_HIP(hipSetDevice(b->ctx->device));
     const int B = targets ? b->n_targets : b->n_sources;
-    b->host_stage.ensure((size_t)B * b->cap);
+    DevBuf<float4>& stage = targets ? b->host_stage_tgt : b->host_stage_src;
+    stage.ensure((size_t)B * b->cap);
+    {  // a second set call of the same side without an align in between: its last chain may still read the buffer
+      auto& sd = b->side[targets ? 0 : 1];
+      if (sd.pending) MI_HIP(hipStreamWaitEvent(b->stream(), sd.join, 0));
+    }
     // only the filled part of every segment crosses PCIe (sources of 64 k points in segments sized for 300 k-point sub-maps)
     size_t widest = 0;
     if (counts)
       for (int i = 0; i < B; i++)
         if (counts[i] > 0) widest = std::max(widest, std::min((size_t)counts[i], b->cap));
     if (widest > 0)
-      MI_HIP(hipMemcpy2DAsync(b->host_stage.p, b->cap * sizeof(float4), points, b->cap * sizeof(float4), widest * sizeof(float4), (size_t)B,
+      MI_HIP(hipMemcpy2DAsync(stage.p, b->cap * sizeof(float4), points, b->cap * sizeof(float4), widest * sizeof(float4), (size_t)B,
                               hipMemcpyHostToDevice, b->stream()));
-    MI_HIP(hipStreamSynchronize(b->stream()));
-    batch_set(b, targets, b->host_stage.p, counts, pf);
-    MI_HIP(hipStreamSynchronize(b->side[targets ? 0 : 1].stream));  // host_stage is reused by the next call
+    MI_HIP(hipStreamSynchronize(b->stream()));  // the caller's buffer is free when this call returns
+    // The chain runs on the side's own stream and this call returns: the other side's upload crosses PCIe while it runs (with ONE
+    // staging buffer the call had to wait for the chain - 186 ms per 2 048-pair step of host inputs instead of ~160).  The buffer is
+    // written again by this side's next upload, on the batch's stream behind the align that joined this chain.
+    batch_set(b, targets, stage.p, counts, pf);
     if (targets) b->has_tgt = true; else b->has_src = true;
     b->aligned = false;
   });
