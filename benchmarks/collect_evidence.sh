@@ -20,6 +20,7 @@ timeout 600 python bench.py --sor --no-cpu-baseline --steps 5 --warmup 2 > "$O/b
 timeout 300 python benchmarks/single_pair.py > "$O/single_pair.txt" 2>&1
 timeout 300 python benchmarks/stream_profile.py 200 FAST_GICP > "$O/stream_profile.txt" 2>&1
 timeout 300 python bench.py --host-inputs --no-cpu-baseline > "$O/bench_hostinputs.json" 2> "$O/bench_hostinputs.err"
+timeout 300 python bench.py --host-inputs --inflight 2 --pairs 1024 --no-cpu-baseline > "$O/bench_hostinputs_inflight2.json" 2> "$O/bench_hostinputs_inflight2.err"
 timeout 300 python bench.py --inflight 2 --pairs 1024 --no-cpu-baseline > "$O/bench_inflight2.json" 2> "$O/bench_inflight2.err"
 timeout 300 python bench.py --inflight 3 --pairs 1024 --no-cpu-baseline > "$O/bench_inflight3.json" 2> "$O/bench_inflight3.err"
 timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.json" 2> "$O/bench_128pairs.err"

@@ -89,7 +89,7 @@ def main():
     bench = last_json(os.path.join(SRC, "bench_default.json"))
     pairs = bench["config"]["pairs_per_gpu_per_step"]
     for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu",
-                 "bench_sor", "bench_1024pairs", "bench_4096pairs"):
+                 "bench_sor", "bench_1024pairs", "bench_4096pairs", "bench_hostinputs_inflight2"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p):
             with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:

@@ -69,7 +69,7 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 | `{R}_knn_brick_ab.txt`, `{R}_corr_brick_ab.txt`, `{R}_knn_tile_gather_ab.txt` | A/B logs of this round's kernel experiments that did NOT pay (cell bricks for the k-NN and for the correspondence tiles, a wider first gather): DESIGN §4.4 |
 | `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |
 | `{R}_bench_sor.json` | `python bench.py --sor`: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2) over the same {pairs}-pair batch — a different workload, never the headline; carries the SOR row |
-| `{R}_bench_hostinputs.json` | `python bench.py --host-inputs`: HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
+| `{R}_bench_hostinputs.json`, `{R}_bench_hostinputs_inflight2.json` | `python bench.py --host-inputs` (and `--inflight 2 --pairs 1024`): HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
 | `{R}_bench_inflight2.json`, `{R}_bench_inflight3.json` | `python bench.py --inflight 2 / 3 --pairs 1024`: batch objects on their own streams used alternately (the memory of the default / 1.5 × it) |
 | `{R}_bench_serial_streams.json` | the default with `MI355_BATCH_SIDE_STREAMS=0`: the preparation chains one after the other |
 | `{R}_bench_128pairs.json` | `python bench.py --pairs 128` |
@@ -137,6 +137,9 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
         out += f"| `--pairs 4096` (180 GB) | {p4k['value']:.0f} pairs/s |\n"
     if hi:
         out += f"| `--host-inputs` ({pairs} pairs × 2 clouds × 1 MiB pageable host memory per step through `mi355_batch_set_sources/targets`) | {hi['value']:.0f} pairs/s — the PCIe-inclusive rate |\n"
+        hi2 = maybe("bench_hostinputs_inflight2")
+        if hi2:
+            out += f"| `--host-inputs --inflight 2 --pairs 1024` (the uploads of one batch under the kernels of the other) | {hi2['value']:.0f} pairs/s, {hi2['ms_per_step']:.1f} ms per 1 024-pair step |\n"
     if sor:
         srow = next((v for k, v in sor["roofline"]["by_kernel"].items() if k.startswith("sor(")), None)
         out += (f"| `--sor` (leaf 0.1 m + SOR 30 / 1.2: {sor['config']['points_after_voxel_src_mean']:.0f} points per cloud survive) | {sor['value']:.0f} pairs/s, {sor['ms_per_step']:.1f} ms/step; "
