@@ -56,19 +56,26 @@ ALG_BYTES = {
 }
 TOL_TRUTH_T, TOL_TRUTH_R = 0.015, 1.0e-3   # vs ground truth on the 2 cm-noise scene
 TOL_ORACLE_T, TOL_ORACLE_R = 1.0e-3, 1.0e-4  # vs the oracle on the SAME input, same iteration count
-N_BASE = 4  # distinct ray-cast scenes/poses; every pair of the batch is a differently placed copy of one of them
+N_BASE = 32      # distinct ray-cast pairs per rank: own street scene, own sensor pose, own relative motion (synth.bench_pair_spec);
+                 # pair p of the batch is pair p % N_BASE under its own world transform (which re-bins every voxel grid)
+N_ORACLE = 8     # pairs of the timed batch that the oracle registers again, from the same world-transformed clouds
 
 
-def base_pairs(rank: int):
+def base_pairs(rank: int, n_base: int):
+    """The distinct ray-cast pairs of this rank.  Ray casting is single-threaded NumPy (~1.5 s per pair): a pool of SPAWNED
+    workers casts them side by side (fresh interpreters: nothing of this process's GPU state travels)."""
+    import multiprocessing as mp
+
     from lidar_graph_slam_amd import synth
 
-    out = []
-    for i in range(N_BASE):
-        T_gt = synth.se3(1.0 - 0.1 * i, 0.1 + 0.05 * i, 0.0, 0.0, 0.0, np.deg2rad(2.0 - 0.4 * i))
-        T_tgt = synth.se3(7.0 * i + 3.0 * rank, 0.3 * i, 0.0, 0.0, 0.0, 0.02 * i)
-        src, tgt, _ = synth.make_pair(T_gt=T_gt, T_target=T_tgt, seed=11 + 17 * i + 101 * rank)
-        out.append((src, tgt, T_gt))
-    return out
+    specs = [synth.bench_pair_spec(i, rank) for i in range(n_base)]
+    workers = max(1, min(n_base, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if workers == 1:
+        pairs = [synth.make_pair_job(sp) for sp in specs]
+    else:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pairs = pool.map(synth.make_pair_job, specs)
+    return [(src, tgt, T_gt) for (src, tgt, T_gt) in pairs]
 
 
 def main():
@@ -83,6 +90,8 @@ def main():
     ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")
     ap.add_argument("--inflight", type=int, default=1, help="batch objects in flight, each on its own HIP stream (double buffering): while one batch is in "
                     "its LM iterations the next one is prefiltered and indexed (--inflight 2 --pairs 512: +8 %% pairs/s in the same memory)")
+    ap.add_argument("--bases", type=int, default=N_BASE, help="distinct ray-cast pairs per rank (each is its own scene, pose and motion)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the h2d_inclusive block (3 extra steps from host buffers after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="A/B aid: no HIP events around the kernels (the JSON line then has no roofline block)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -90,6 +99,9 @@ def main():
     ap.add_argument("--sor", action="store_true", help="prefilter with the reference's LAUNCH defaults instead of BASELINE's: leaf 0.1 m, StatisticalOutlierRemoval "
                     "mean_k 30 / stddev 1.2 (points_prefiltering.launch.xml:2-5) - a different workload, never the headline value; its line carries the SOR row")
     args = ap.parse_args()
+    n_base = max(1, args.bases)
+    rank_env = int(os.environ.get("RANK", "0"))
+    base = base_pairs(rank_env, n_base)  # before anything touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -132,7 +144,6 @@ def main():
 
     # ---- synthetic inputs, resident in HBM -----------------------------------------------------------------------
     P = args.pairs
-    base = base_pairs(rank)
     cap = base[0][0].shape[0]
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     src_d = torch.empty((P, cap, 4), dtype=torch.float32, device=dev)
@@ -141,7 +152,7 @@ def main():
     base_tgt = [torch.from_numpy(b[1]).to(dev) for b in base]
     world_T = []
     for p in range(P):
-        k = p % N_BASE
+        k = p % n_base
         yaw = float(torch.rand(1, generator=g)) * 2 * np.pi
         tx, ty = (float(torch.rand(1, generator=g)) - 0.5) * 40.0, (float(torch.rand(1, generator=g)) - 0.5) * 40.0
         W = torch.from_numpy(synth.se3(tx, ty, 0.0, 0.0, 0.0, yaw).astype(np.float32)).to(dev)
@@ -252,18 +263,47 @@ def main():
             b0.set_targets_dev(tgt_d.data_ptr(), counts, pre)
             b0.set_sources_dev(src_d.data_ptr(), counts, pre)
             b0.align()
-            b0.results()
+            b0.results(raw=True)
             for name, (ms, nl) in b0.kernel_times().items():
                 e = iso.setdefault(name, [0.0, 0])
                 e[0] += ms
                 e[1] += nl
         b0.set_side_streams(None)
 
+    # ---- what the timed batch looked like: iterations-to-convergence per pair (the iteration at which fast_gicp's is_converged
+    # first held - the bench forces exactly --iters iterations, so this is what each pair would have run without forcing) and
+    # the share of the points the k-NN tile search handed over to the one-wave-per-query kernel
+    diag = batches[(step_no[0] - 1) % len(batches)].diagnostics() if rank == 0 else None
+
+    # ---- the PCIe-inclusive rate (SURVEY 8d "H2D included and also reported separately"): three more steps, the same batch handed
+    # over as HOST buffers (pageable memory) through mi355_batch_set_targets / _sources.  Never the headline value.
+    h2d = None
+    if rank == 0 and not args.no_h2d and not args.host_inputs:
+        b0 = batches[0]
+        src_h, tgt_h = src_d.cpu().numpy(), tgt_d.cpu().numpy()
+        n_h2d = 3
+        for it in range(n_h2d + 1):
+            if it == 1:
+                torch.cuda.synchronize()
+                th0 = time.perf_counter()
+            b0.set_targets(tgt_h, counts, pre)
+            b0.set_sources(src_h, counts, pre)
+            b0.align()
+            res_h = b0.results(raw=True)
+        th = (time.perf_counter() - th0) / n_h2d
+        b0.kernel_times()  # (drop the brackets of these steps)
+        same = bool(np.array_equal(np.asarray(res_h["T"]), np.asarray(res["T"]))) if len(batches) == 1 else None
+        h2d = {"value": round(P / th, 2), "unit": "pairs/s", "ms_per_step": round(th * 1e3, 3), "steps": n_h2d,
+               "bytes_per_step": int(2 * P * cap * 16), "poses_bit_equal_to_the_timed_region": same,
+               "note": "the same batch from HOST buffers (pageable memory) through mi355_batch_set_targets/_sources: upload + the whole step, one batch at a time; "
+                       "not the headline value"}
+        del src_h, tgt_h
+
     # ---- correctness of what was timed: pose error vs ground truth for every pair of this rank ------------------------
     errs = []
     for p in range(P):
         W = world_T[p].astype(np.float64)
-        T_expected = W @ base[p % N_BASE][2] @ np.linalg.inv(W)
+        T_expected = W @ base[p % n_base][2] @ np.linalg.inv(W)
         errs.append(synth.pose_error(res["T"][p], T_expected))
     errs = np.array(errs)
     n_src = np.asarray(res["n_source"])
@@ -361,6 +401,22 @@ def main():
         raise SystemExit(f"bench.py: pose error vs ground truth {errs[:, 0].max():.4f} m / {errs[:, 1].max():.2e} rad exceeds "
                          f"{TOL_TRUTH_T} m / {TOL_TRUTH_R} rad - refusing to report a throughput for wrong poses")
 
+    fc = diag["first_converged"]
+    conv = fc[fc >= 0]
+    batch_stats = {
+        "iterations_to_convergence": {
+            "min": int(conv.min()) if len(conv) else None, "median": float(np.median(conv)) if len(conv) else None,
+            "mean": round(float(conv.mean()), 3) if len(conv) else None, "max": int(conv.max()) if len(conv) else None,
+            "histogram": {str(int(v)): int(c) for v, c in zip(*np.unique(conv, return_counts=True))},
+            "never_within_the_forced_iterations": int((fc < 0).sum()),
+            "note": "the iteration count at which fast_gicp's is_converged first held for a pair; the bench runs exactly --iters iterations for every pair",
+        },
+        "knn_hand_over_fraction": {"targets": round(float(diag["knn_handed_over"][0]) / max(float(diag["knn_points"][0]), 1.0), 6),
+                                   "sources": round(float(diag["knn_handed_over"][1]) / max(float(diag["knn_points"][1]), 1.0), 6),
+                                   "note": "points the k-NN tile search handed over to k_knn_hard (one wave per query), of all points after the prefilter"},
+        "points_after_prefilter": {"min": int(min(n_src.min(), n_tgt.min())), "max": int(max(n_src.max(), n_tgt.max()))},
+    }
+
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle_py as O
@@ -370,7 +426,7 @@ def main():
             return O.sor(c, 30, 1.2)[0] if args.sor else c
 
         def cpu_pair(k, gp):
-            s, t, _ = base[k % N_BASE]
+            s, t, _ = base[k % n_base]
             return O.gicp_align(cpu_prefilter(s), cpu_prefilter(t), gp)
 
         # one process, OpenMP inside a pair: 4 threads = the reference's own configuration (lidar_scan_matcher.param.yaml:10), and
@@ -413,14 +469,21 @@ def main():
         whole_host = (sum(done), time.perf_counter() - tw0)
         threads = max(by_threads, key=lambda t: by_threads[t][0] / by_threads[t][1])
         n_done, tc = by_threads[threads]
-        # parity on the SAME input: pair 0 of the batch exactly as the GPU saw it (world-transformed), through the oracle
-        gp = O.gicp_params(max_iterations=args.iters, force_iterations=1, num_threads=threads)
-        s0, t0_ = src_d[0].cpu().numpy(), tgt_d[0].cpu().numpy()
-        ref0 = O.gicp_align(cpu_prefilter(s0), cpu_prefilter(t0_), gp)
-        dt, dr = synth.pose_error(res["T"][0], ref0["T"])
+        # parity on the SAME input: N_ORACLE pairs of the timed batch, spread over the batch and over the distinct scenes, exactly
+        # as the GPU saw them (world-transformed), through the oracle
+        gp = O.gicp_params(max_iterations=args.iters, force_iterations=1, num_threads=min(16, hw))
+        sample = sorted({((k * P) // N_ORACLE + k) % P for k in range(N_ORACLE)})
+        dts, drs = [], []
+        for p_ in sample:
+            s0, t0_ = src_d[p_].cpu().numpy(), tgt_d[p_].cpu().numpy()
+            ref0 = O.gicp_align(cpu_prefilter(s0), cpu_prefilter(t0_), gp)
+            dt_, dr_ = synth.pose_error(res["T"][p_], ref0["T"])
+            dts.append(dt_)
+            drs.append(dr_)
+        dt, dr = max(dts), max(drs)
         if dt > TOL_ORACLE_T or dr > TOL_ORACLE_R:
             raise SystemExit(f"bench.py: GPU pose differs from the oracle's on the same pair by {dt:.2e} m / {dr:.2e} rad "
-                             f"(tolerance {TOL_ORACLE_T} m / {TOL_ORACLE_R} rad)")
+                             f"(pairs {sample}; tolerance {TOL_ORACLE_T} m / {TOL_ORACLE_R} rad)")
         model = "unknown"
         try:
             with open("/proc/cpuinfo") as f:
@@ -442,6 +505,8 @@ def main():
             "cpu_model": model,
             "gpu_vs_cpu_pose_dt_m": round(dt, 9),
             "gpu_vs_cpu_pose_dr_rad": round(dr, 9),
+            "gpu_vs_cpu_pairs_compared": sample,
+            "gpu_vs_cpu_pose_dt_m_by_pair": [round(v, 9) for v in dts],
         }
 
     out = {
@@ -463,6 +528,7 @@ def main():
             "workload": ("BASELINE configs[1]: 64k-pt scan pairs, distance filter 1.0 m + voxel 0.2 m + GICP k=20, exactly 20 LM iterations, batched" if not args.sor else
                          "64k-pt scan pairs through the reference's launch-file prefilter (distance 1.0 m + voxel 0.1 m + SOR 30 / 1.2) + GICP k=20, exactly 20 LM iterations, batched"),
             "pairs_per_gpu_per_step": P,
+            "distinct_ray_cast_pairs": n_base,
             "batches_in_flight": len(batches),
             "raw_points_per_cloud": int(cap),
             "points_after_voxel_src_mean": float(n_src.mean()),
@@ -475,8 +541,11 @@ def main():
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "h2d_inclusive": h2d,
+        "batch": batch_stats,
         "accuracy": {
             "pose_err_vs_truth_dt_m_max": round(float(errs[:, 0].max()), 5),
+            "pose_err_vs_truth_dt_m_median": round(float(np.median(errs[:, 0])), 5),
             "pose_err_vs_truth_dr_rad_max": round(float(errs[:, 1].max()), 6),
         },
     }

@@ -21,6 +21,12 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct of this header changes layout or an entry point changes meaning: 2 = mi355_pointcloud2 gained
+ * `data_size` (mandatory) and a non-FLOAT32 intensity field is ignored as pcl::fromROSMsg ignores it; 3 = mi355_batch_diagnostics,
+ * mi355_multi_lane_allocations, mi355_multi_batch_register_clouds (additions only).  mi355_abi_version() returns the library's. */
+#define MI355_ABI_VERSION 3
+int mi355_abi_version(void);
+
 #define MI355_OK 0
 #define MI355_EINVAL (-1)   /* bad argument */
 #define MI355_EHIP (-2)     /* HIP runtime error (text in mi355_last_error) */
@@ -244,7 +250,8 @@ typedef struct mi355_pointcloud2 {
   uint8_t intensity_datatype;
   uint8_t is_bigendian;  /* must be 0 (every ROS 2 platform is little-endian) */
   size_t data_size;      /* msg.data.size(): must cover row_step * height bytes (MI355_EINVAL otherwise - an inconsistent message
-                            is refused, not read past its end) */
+                            is refused, not read past its end).  ABI note: this field was appended in round 3 (MI355_ABI_VERSION 2);
+                            a caller built against the older struct, or one that leaves it 0, is refused for every non-empty message */
 } mi355_pointcloud2;
 mi355_cloud* mi355_cloud_from_pointcloud2(mi355_ctx* ctx, const mi355_pointcloud2* msg);
 /* pcl::toROSMsg(pcl::PointCloud<pcl::PointXYZI>): point_step 32, x@0 y@4 z@8 (data[3] = 1.0f @12) intensity@16, padding 0;
@@ -288,6 +295,12 @@ int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets);
  * INCREMENTAL search holds at the final poses (margins: DESIGN 4.3) against a search of every source point from scratch
  * at the same poses.  *n_mismatch must be 0: the incremental search is exact, not approximate.  Leaves the results untouched. */
 int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_checked, long long* n_mismatch);
+/* Diagnostics of the last mi355_batch_align of a FAST_GICP batch, for the benchmark log (synchronises the batch; every output is
+ * optional).  first_converged[n_sources]: the iterations a pair had run when fast_gicp's is_converged (lsq_registration_impl.hpp,
+ * SURVEY F9) first held, -1 = never - with force_iterations that is what the pair would have run without it.
+ * knn_points[2] / knn_handed_over[2] (0 = targets, 1 = sources): the points of each side's last covariance launch and how many
+ * of them the wave-cooperative tile search handed over to the one-wave-per-query kernel. */
+int mi355_batch_diagnostics(mi355_batch* b, int* first_converged, long long* knn_points, long long* knn_handed_over);
 /* Per-kernel-family timing for the benchmark's roofline block.  With timing enabled the library records HIP events on the
  * launching stream around every launch of the hot kernels (k_knn_cov_tile, k_gicp_correspond, k_gicp_linearize, ...; short
  * kernels that always run back to back, e.g. the 12 launches of one radix sort, share one bracket).
@@ -320,8 +333,10 @@ int mi355_batch_set_stream(mi355_batch* batch, void* hip_stream, int use_context
  * lanes on one device.  Pairs are dealt to lanes by target (sub-map) so that every sub-map is uploaded, filtered and indexed
  * once: targets by descending pair count (ties: lower target id), each to the least-loaded lane (ties: lower lane) — the rule
  * of lidar_graph_slam_amd/sharding.py, whose torchrun form (one process per GPU, results all-gathered over RCCL) produces the
- * same partition.  Here the process is one, so the only exchange step — the 80-byte results — is a D2H copy per lane; every
- * lane is driven by its own host thread.  No pair crosses lanes: results are those of a single batch, pair for pair. */
+ * same partition.  Here the process is one, so the only exchange step between lanes — the fixed-size mi355_result
+ * records, 392 bytes per pair — is a D2H copy per lane; every lane is driven by its own host thread.  (This host-view entry point
+ * also uploads every source and target cloud of the call to its lane; callers whose clouds are device-resident use
+ * mi355_multi_context + mi355_cloud_* + mi355_multi_batch_register_clouds and pay that once.)  No pair crosses lanes: results are those of a single batch, pair for pair. */
 typedef struct mi355_multi mi355_multi;
 mi355_multi* mi355_multi_create(const int* device_ids, int n_devices);
 void mi355_multi_destroy(mi355_multi* m);
@@ -329,6 +344,9 @@ const char* mi355_multi_last_error(const mi355_multi* m);
 int mi355_multi_device_count(const mi355_multi* m);
 /* lane i's context (for device clouds / filters on that device); owned by the multi object */
 mi355_ctx* mi355_multi_context(mi355_multi* m, int lane);
+/* how many times lane i's batch object has been (re)created: 1 after the first registration and unchanged while later requests
+ * fit what it was sized for and ask for the same method / parameters (monitoring; -1 = bad lane) */
+int mi355_multi_lane_allocations(const mi355_multi* m, int lane);
 /* the partition alone (host only): lane_of_pair[p] for n_pairs pairs over n_lanes lanes */
 int mi355_multi_shard_by_target(const int* tgt_of_src, int n_pairs, int n_lanes, int* lane_of_pair);
 /* mi355_batch_* over all lanes in one call: pair p aligns sources[p] to targets[tgt_of_src[p]] (host views, any stride) from

@@ -120,7 +120,7 @@ class Result(C.Structure):
 
 # every symbol include/mi355_lidar.h declares (tests/test_abi.py checks the library exports each one)
 EXPORTS = [
-    "mi355_gicp_default_params", "mi355_ndt_default_params", "mi355_prefilter_default_params", "mi355_icp_default_params", "mi355_gicp_bfgs_default_params",
+    "mi355_abi_version", "mi355_gicp_default_params", "mi355_ndt_default_params", "mi355_prefilter_default_params", "mi355_icp_default_params", "mi355_gicp_bfgs_default_params",
     "mi355_create", "mi355_destroy", "mi355_last_error", "mi355_set_stream", "mi355_synchronize", "mi355_set_grid_cell", "mi355_device_info",
     "mi355_distance_filter", "mi355_voxel_grid", "mi355_sor", "mi355_prefilter", "mi355_transform",
     "mi355_knn", "mi355_covariances",
@@ -131,9 +131,9 @@ EXPORTS = [
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
     "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
-    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams", "mi355_batch_set_live", "mi355_batch_verify_correspondences",
+    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams", "mi355_batch_set_live", "mi355_batch_verify_correspondences", "mi355_batch_diagnostics",
     "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_last_error", "mi355_multi_device_count", "mi355_multi_context",
-    "mi355_multi_shard_by_target", "mi355_multi_batch_register",
+    "mi355_multi_shard_by_target", "mi355_multi_batch_register", "mi355_multi_lane_allocations",
 ]
 # include/mi355_scan_matcher.h
 EXPORTS_SCAN_MATCHER = [
@@ -304,6 +304,7 @@ def lib():
         L.mi355_loop_closure_create_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(LoopClosureParams)]
         L.mi355_batch_set_live.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mi355_batch_verify_correspondences.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.mi355_batch_diagnostics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_multi_create.restype = C.c_void_p
         L.mi355_multi_create.argtypes = [C.c_void_p, C.c_int]
         L.mi355_multi_destroy.argtypes = [C.c_void_p]
@@ -313,6 +314,7 @@ def lib():
         L.mi355_multi_device_count.argtypes = [C.c_void_p]
         L.mi355_multi_context.restype = C.c_void_p
         L.mi355_multi_context.argtypes = [C.c_void_p, C.c_int]
+        L.mi355_multi_lane_allocations.argtypes = [C.c_void_p, C.c_int]
         L.mi355_multi_shard_by_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mi355_multi_batch_register.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.POINTER(PrefilterParams), C.POINTER(PrefilterParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -39,8 +39,6 @@ const Tuning& tuning() {
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
     getf("MI355_GRID_CELL", v.grid_cell);
     geti("MI355_KNN_STATS", v.knn_stats);
-    getf("MI355_BRICK_H", v.brick_h);
-    getf("MI355_BRICK_GATHER", v.brick_gather);
     return v;
   }();
   return t;
@@ -190,6 +188,8 @@ struct CtxExtras {
   FilterScratch fs;
 };
 static CtxExtras* extras(mi355_ctx* ctx);
+
+extern "C" int mi355_abi_version(void) { return MI355_ABI_VERSION; }
 
 // ---- defaults ------------------------------------------------------------------------------------------------------
 extern "C" void mi355_gicp_default_params(mi355_gicp_params* p) {
@@ -1339,6 +1339,31 @@ extern "C" int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_c
     if (!b->aligned || b->method != MI355_METHOD_FAST_GICP) throw ArgError(MI355_ESTATE, "verify_correspondences: after mi355_batch_align of a FAST_GICP batch");
     MI_HIP(hipSetDevice(b->ctx->device));
     gicp_verify_correspondences(b->stream(), b->gb, b->src, b->tgt, b->gp, n_checked, n_mismatch);
+  });
+}
+
+extern "C" int mi355_batch_diagnostics(mi355_batch* b, int* first_converged, long long* knn_points, long long* knn_handed_over) {
+  if (!b) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    if (b->method != MI355_METHOD_FAST_GICP) throw ArgError(MI355_ESTATE, "mi355_batch_diagnostics: a FAST_GICP batch");
+    if (first_converged && !b->aligned) throw ArgError(MI355_ESTATE, "mi355_batch_diagnostics: after mi355_batch_align");
+    MI_HIP(hipSetDevice(b->ctx->device));
+    MI_HIP(hipStreamSynchronize(b->stream()));
+    for (auto& sd : b->side)
+      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    if (first_converged) gicp_first_converged(b->stream(), b->gb, first_converged);
+    for (int k = 0; k < 2; k++) {
+      CloudSet& set = k == 0 ? b->tgt : b->src;
+      long long np = 0, nf = 0;
+      if (set.has_cov && set.fbn.p) {  // [0, B): the hand-over queue lengths of the set's last covariance launch
+        std::vector<int> fbn((size_t)set.B), cnt((size_t)set.B);
+        MI_HIP(hipMemcpy(fbn.data(), set.fbn.p, sizeof(int) * (size_t)set.B, hipMemcpyDeviceToHost));
+        MI_HIP(hipMemcpy(cnt.data(), set.count.p, sizeof(int) * (size_t)set.B, hipMemcpyDeviceToHost));
+        for (int c = 0; c < set.B; c++) { np += cnt[(size_t)c]; nf += fbn[(size_t)c]; }
+      }
+      if (knn_points) knn_points[k] = np;
+      if (knn_handed_over) knn_handed_over[k] = nf;
+    }
   });
 }
 

@@ -928,232 +928,6 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
   }
 }
 
-// ---- the same by LDS-STAGED CELL BRICKS (round 3) ----------------------------------------------------------------------------
-// k_knn_cov_tile ranks, per lane, every candidate of its 16-lane sub-tile's list: ~190 for k = 20, through a 22-deep network, and
-// spends another quarter of its instructions filing candidates into those lists and a tenth putting the queries into kd order.
-// What a query needs is the points of a cube a little larger than its own k-th distance: ~50.  Here the candidates the wave has
-// gathered for its 64 queries are binned into a BRICK of cubic cells of edge h ~ 0.6 x the tile's expected k-NN radius, laid over
-// the gathered box and kept in LDS: a counting sort over the cells gives cstart[cell] (prefix of the per-cell counts) and perm[]
-// (candidate positions in cell order, x fastest).  The cells x0 .. x1 of one (y, z) row are then ONE contiguous piece
-// perm[cstart[row + x0] .. cstart[row + x1 + 1]) — no bit scans, no per-cell tests — and a lane visits exactly the rows and
-// pieces of its OWN cube [q - R, q + R]^3: two LDS reads per row, one 16-bit + one 16-byte LDS read and the 9 + 22 VALU of
-// distance + network per candidate.  Every lane has its own radius R: the first is the density estimate of the tile; a lane
-// whose k-th distance does not fit asks for what it needs and walks its (larger) cube again — only those lanes are active then.
-// Exactness is the tile kernel's: binning is the same monotone fp32 function for candidates and cube corners, so every gathered
-// point with coordinates inside [q - R, q + R] is in the visited pieces, the gathered box holds every point within R of any
-// query, and a lane is closed once its k-th distance (upper edge of its key bucket) lies inside 0.9999 R - eps.
-constexpr int kBrickCells = 2048;                    // cells of a brick (cstart: 4 KB)
-
-template <int K, bool STATS>
-__global__ __launch_bounds__(64) void k_knn_cov_brick(const float4* __restrict__ pts, const int* __restrict__ orig,
-                                                      const HashSlot* __restrict__ table, const GridMeta* __restrict__ meta,
-                                                      Cov6* __restrict__ cov, int* __restrict__ queue, float* __restrict__ queue_hint,
-                                                      int* __restrict__ queue_n, int* __restrict__ tile_ctr, size_t cap, size_t slots_cap, int k,
-                                                      int method, int G, int B, float r_scale, float h_scale, float gather_scale,
-                                                      unsigned long long* __restrict__ stats) {
-  __shared__ float4 cand[kTileMaxCand];                 // this wave's candidates (x, y, z, sorted index), in gather order
-  __shared__ __attribute__((aligned(16))) uint16_t cstart[kBrickCells + 8];  // first perm[] position of every cell (+ the end)
-  __shared__ uint16_t perm[kTileMaxCand + 8];           // byte offsets into cand[], in cell order (+ padding for the unrolled walk)
-  int c, bx;
-  if (!xcd_item_chunk(G, B, c, bx)) return;
-  const GridView g = grid_view(pts, orig, table, meta, c, cap, slots_cap);
-  const int n = g.m.n;
-  const int lane = lane_id();
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (int z = lane; z < kTileMaxCand + 8; z += kWave) perm[z] = 0;
-  int st_rows = 0, st_iters = 0, st_rounds = 0, st_builds = 0, st_cands = 0, st_tiles = 0;  // (STATS only: tuning aid)
-  for (;;) {
-  int tile = 0;
-  if (lane == 0) tile = atomicAdd(&tile_ctr[c], 1);
-  const int tile0 = __builtin_amdgcn_readfirstlane(tile) * kWave;
-  if (tile0 >= n) break;
-  if constexpr (STATS) st_tiles++;
-  int i = tile0 + lane;
-  float4 q = g.pts[min(i, n - 1)];
-  if (i >= n) q.x = q.y = q.z = INFINITY;
-  bool ordered = false;  // the queries are put into kd order only when the tile has to be split
-  bool valid = i < n;
-  const float rcap = 16.f * g.m.cell, rmin = 0.6f * g.m.cell;
-  bool fb = false;
-  float hint = 0.f;
-  int seg = 0, len = kWave;
-  while (seg < kWave) {
-    const bool act = valid && lane >= seg && lane < seg + len;
-    const int nact = __popcll(__ballot(act));
-    bool split = false;
-    if (nact > 0) {
-      const TileBox bb = tile_bounds(act, q.x, q.y, q.z);
-      const float eps = tile_eps(bb, rcap);
-      float r0, e_max;
-      {
-        const float ex = bb.hx - bb.lx, ey = bb.hy - bb.ly, ez = bb.hz - bb.lz;
-        const float e_min = fminf(fminf(ex, ey), ez);
-        e_max = fmaxf(fmaxf(ex, ey), ez);
-        const float e_mid = ex + ey + ez - e_min - e_max;
-        const float area = fmaxf(e_max * e_mid, 0.16f * g.m.cell * g.m.cell);
-        r0 = fminf(fmaxf(r_scale * sqrtf((float)k * area / (3.14159265f * (float)nact)), rmin), rcap);
-      }
-      float rl = r0;            // this lane's cube half edge
-      SmallestKeys<K + 2> keys;
-      keys.init();
-      int n_ord = 0;
-      TileBox ob = bb;
-      float R = -1.f;           // radius the gathered box covers around the segment's box
-      bool has_old = false, open = act, rebuild = true, exact = false;
-      Brick br{0.f, 0.f, 0.f, 1.f, 1, 1, 1};
-      for (int round = 0;; round++) {
-        // ---- candidates: the gathered box covers the largest cube an open lane asks for (a little more in the first round,
-        // so that lanes that come back for a larger cube seldom need a second gather)
-        const float want = uniform_f(wave_max_all(open ? rl : 0.f));
-        if (want > R) {
-          const float Rn = fminf(fmaxf(want, round == 0 ? gather_scale * want : want), rcap);
-          const TileBox nb = grow(bb, Rn);
-          const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
-          const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
-          if (n_new < 0) {
-            if (!has_old && want > rmin && Rn > 0.5f * e_max) {  // the density guess overshoots (clustered far-field points): start smaller
-              rl = fmaxf(0.5f * rl, rmin);
-              round = -1;
-              continue;
-            }
-            if (!has_old && len > 8) split = true;
-            else fb = fb || open;
-            break;
-          }
-          ob = nb;
-          has_old = true;
-          R = Rn;
-          n_ord = n_new;
-          rebuild = true;
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        if (rebuild) {
-          // cells of edge h over the gathered box (h grows until the brick fits)
-          br = brick_over<kBrickCells>(ob, fmaxf(h_scale * r0, 0.02f * g.m.cell));
-          brick_build<kTileMaxCand, kBrickCells>(br, cand, n_ord, cstart, perm);
-          rebuild = false;
-          if constexpr (STATS) { st_builds++; st_cands += n_ord; }
-        }
-        // ---- rank: every open lane walks the rows of its cube
-        {
-          const int x0 = brick_cell1(q.x - rl, br.ox, br.inv_h, br.nx), x1 = brick_cell1(q.x + rl, br.ox, br.inv_h, br.nx);
-          const int y0 = brick_cell1(q.y - rl, br.oy, br.inv_h, br.ny), y1 = brick_cell1(q.y + rl, br.oy, br.inv_h, br.ny);
-          const int z0 = brick_cell1(q.z - rl, br.oz, br.inv_h, br.nz), z1 = brick_cell1(q.z + rl, br.oz, br.inv_h, br.nz);
-          int iy = y0, iz = z0;
-          bool more = open;
-          // row (iy, iz): the piece perm[a, b); the next row's bounds are loaded while this one is ranked
-          int a = 0, b2 = 0;
-          if (more) {
-            const int rb = (iz * br.ny + iy) * br.nx;
-            a = cstart[rb + x0];
-            b2 = cstart[rb + x1 + 1];
-          }
-          while (__any(more)) {
-            int na = 0, nb2 = 0;
-            bool nmore = more;
-            if (more) {
-              iy++;
-              if (iy > y1) { iy = y0; iz++; }
-              nmore = iz <= z1;
-              if (nmore) {
-                const int rb = (iz * br.ny + iy) * br.nx;
-                na = cstart[rb + x0];
-                nb2 = cstart[rb + x1 + 1];
-              }
-            }
-            if constexpr (STATS) st_rows++;
-            for (int p = a; __any(p < b2); p += 2) {
-              // (a lane whose piece has ended runs on with the others: clamped into the padded end of perm[], whose zeros name cand[0])
-              const int pc = min(p, kTileMaxCand);
-              const uint32_t o0 = perm[pc], o1 = perm[pc + 1];
-              const float4 c0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + o0);
-              const float4 c1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + o1);
-              const uint32_t d0 = __float_as_uint(dist2f(q.x, q.y, q.z, c0.x, c0.y, c0.z));
-              const uint32_t d1 = __float_as_uint(dist2f(q.x, q.y, q.z, c1.x, c1.y, c1.z));
-              keys.insert((p < b2) ? ((d0 & ~kOrdMask) | (o0 >> 4)) : SmallestKeys<K + 2>::kEmpty);
-              keys.insert((p + 1 < b2) ? ((d1 & ~kOrdMask) | (o1 >> 4)) : SmallestKeys<K + 2>::kEmpty);
-              if constexpr (STATS) st_iters += 2;
-            }
-            a = na; b2 = nb2; more = nmore;
-          }
-        }
-        if constexpr (STATS) st_rounds++;
-        // ---- which lanes are done?
-        const float rsafe = rl * 0.9999f - eps;
-        const uint32_t kk = keys.at(k - 1);
-        const bool full = kk != SmallestKeys<K + 2>::kEmpty;
-        const float ub = __uint_as_float(kk | kOrdMask);
-        if (open && full) hint = sqrtf(ub) * 1.001f + 2.f * eps;
-        const bool done = full && ub <= rsafe * rsafe;
-        // a closed lane is exact unless truncation could have swapped the k-th and (k+1)-th candidates (or they tie exactly)
-        if (open && done) {
-          const uint32_t kn = keys.at(k);
-          const uint32_t tk = kk >> kOrdBits;
-          const bool clear = tk < (kn >> kOrdBits);
-          const bool pair = !clear && tk < (keys.at(k + 1) >> kOrdBits) && (k < 2 || (keys.at(k - 2) >> kOrdBits) < tk);
-          if (pair) {
-            const float4 pa = cand[kk & kOrdMask], pb = cand[kn & kOrdMask];
-            const float da = dist2f(q.x, q.y, q.z, pa.x, pa.y, pa.z), db = dist2f(q.x, q.y, q.z, pb.x, pb.y, pb.z);
-            if (db < da || (db == da && g.orig[__float_as_int(pb.w)] < g.orig[__float_as_int(pa.w)])) {
-#pragma unroll
-              for (int t = 0; t < K; t++)
-                if (t == k - 1) keys.v[t] = kn;
-            }
-          }
-          if (clear || pair) exact = true;  // its keys name cand[] positions, which stay valid: later gathers only append
-          else fb = true;
-        }
-        open = open && !done && !fb;
-        if (!__any(open)) break;
-        if (round >= 6) {
-          fb = fb || open;
-          break;
-        }
-        // ---- the open lanes come back with the cube they need
-        if (open) {
-          const float need = full ? sqrtf(ub) * 1.001f + 2.f * eps : 2.f * rl;
-          const float nr = fminf(fmaxf(need, 1.02f * rl), rcap);
-          if (!(nr > rl)) fb = true;  // at the radius cap
-          rl = nr;
-          keys.init();
-        }
-        open = open && !fb;
-        if (!__any(open)) break;
-      }
-      if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the lists
-    }
-    if (split) {
-      if (!ordered) {  // halves / quarters of 64 consecutive Morton points are compact only in kd order
-        kd_order_tile(q.x, q.y, q.z, i);
-        valid = i < n;
-        ordered = true;
-      }
-      len >>= 1;
-    } else {
-      seg += len;
-      len = seg & -seg;
-    }
-  }
-  const unsigned long long fm = __ballot(fb);
-  if (fm) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&queue_n[c], __popcll(fm));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (fb) {
-      queue[(size_t)c * cap + base + __popcll(fm & below)] = i;
-      queue_hint[(size_t)c * cap + base + __popcll(fm & below)] = hint;
-    }
-  }
-  }  // next tile
-  if constexpr (STATS) {
-    if (stats && lane == 0) {
-      atomicAdd(&stats[0], (unsigned long long)st_rows); atomicAdd(&stats[1], (unsigned long long)st_iters);
-      atomicAdd(&stats[2], (unsigned long long)st_rounds); atomicAdd(&stats[3], (unsigned long long)st_builds);
-      atomicAdd(&stats[4], (unsigned long long)st_cands); atomicAdd(&stats[5], (unsigned long long)st_tiles);
-    }
-  }
-}
 
 // Fallback for the points the tile kernel hands over (wide or sparse neighbourhoods: far-field points whose k-th neighbour
 // is metres away, boxes that outgrow the tile list, exact distance ties): ONE WAVE PER QUERY, the candidates spread over
@@ -1435,22 +1209,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
   // round 3; per 2 048-cloud launch 4 / 8 / 16 / 32 waves per cloud: 16.8 / 16.5 / 16.1 / 16.3 ms on the knn_only clouds - the waves
   // of a cloud finish together, so more of them shorten the tail each cloud leaves on its XCD).  MI355_TILE_WAVES < 0: that many per cloud.
   const int Gt = tn.tile_waves < 0 ? -tn.tile_waves : max(min(tn.tile_waves / max(set.B, 1), div_up((long)set.cap, kWave)), 16);
-  unsigned long long* d_stats = nullptr;
-  if (tn.knn_tiles >= 2 && !SOR) {  // cell bricks in LDS (MI355_KNN_TILES=2; measured slower than the sub-tile lists so far: DESIGN 4.4)
-    TimedLaunch tl(KF_KNN_COV_TILE, s);
-    if (tn.knn_stats) {
-      set.knn_stats.ensure(8);
-      MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 8 * sizeof(unsigned long long), s));
-      d_stats = set.knn_stats.p;
-      hipLaunchKernelGGL((k_knn_cov_brick<K, true>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p,
-                         set.cov.p, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
-                         tn.brick_h, tn.brick_gather, d_stats);
-    } else {
-      hipLaunchKernelGGL((k_knn_cov_brick<K, false>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p,
-                         set.cov.p, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
-                         tn.brick_h, tn.brick_gather, (unsigned long long*)nullptr);
-    }
-  } else if (tn.knn_stats && !SOR) {
+  if (tn.knn_stats && !SOR) {
     set.knn_stats.ensure(32);
     MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 32 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR, true>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
@@ -1495,13 +1254,6 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
     int worst = 0;
     for (int c = 0; c < set.B; c++) { nf += fbn[c]; np += cnt[c]; worst = std::max(worst, fbn[c]); }
     fprintf(stderr, "[mi355] k-NN tiles: %ld of %ld points handed over to k_knn_hard (%.3f %%), worst cloud %d\n", nf, np, 100.0 * nf / std::max(np, 1L), worst);
-    if (d_stats) {
-      unsigned long long st[8];
-      MI_HIP(hipMemcpy(st, d_stats, sizeof(st), hipMemcpyDeviceToHost));
-      const double tiles = (double)std::max(st[5], 1ull);
-      fprintf(stderr, "[mi355] k-NN bricks per tile: %.2f rounds, %.2f builds, %.1f candidates per build, %.1f rows and %.1f rank steps per lane\n", st[2] / tiles,
-              st[3] / tiles, (double)st[4] / std::max(st[3], 1ull), st[0] / tiles, st[1] / tiles);
-    }
   }
 }
 

@@ -79,10 +79,8 @@ struct Tuning {
   int corr_ppt = 1;           // MI355_PPT               points per thread and pass in k_gicp_correspond (1 or 4)
   int blocks_lin = 0;         // MI355_BLOCKS_LIN        blocks per pair of the streaming kernels (0 = from the batch size)
   int lin_ppt = 1;            // MI355_LIN_PPT           points per thread and tile in k_gicp_linearize (1, 2, 4)
-  int knn_tiles = 1;          // MI355_KNN_TILES         1 = sub-tile lists (k_knn_cov_tile), 2 = cell bricks in LDS (k_knn_cov_brick), 0 = per-lane
-                              //                         k-NN search for every point (k_knn_self)
-  float brick_h = 0.6f;       // MI355_BRICK_H           brick cell edge as a multiple of the tile's first radius
-  float brick_gather = 1.0f;  // MI355_BRICK_GATHER      first gather radius of a tile as a multiple of the largest first cube
+  int knn_tiles = 1;          // MI355_KNN_TILES         1 = wave-cooperative tiles with sub-tile lists (k_knn_cov_tile), 0 = per-lane k-NN search for
+                              //                         every point (k_knn_self).  (Round 3's LDS cell bricks, measured slower, live in git history only.)
   int knn_need_div = 2;       // MI355_KNN_NEED_DIV      start level heuristic of the per-lane search
   int tile_waves = 8192;      // MI355_TILE_WAVES        resident one-wave blocks of k_knn_cov_tile over the batch
   int tile_order = 1;         // MI355_TILE_ORDER        1 = batches take the tiles of k_knn_cov_tile along a Hilbert curve (one more sort per cloud), 0 = along the voxel hash's Morton order, 2 = single clouds too (tests)

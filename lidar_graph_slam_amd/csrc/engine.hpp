@@ -65,7 +65,7 @@ struct CloudSet {
   DevBuf<int> fbq, fbn;  // [B*cap] / [2B] points the tile k-NN hands over to k_knn_hard, their number per cloud (+ the tile counters)
   DevBuf<float> fbhint;  // [B*cap] radius known to hold the k nearest neighbours of a handed-over point (0: unknown)
   DevBuf<int> tile_order;  // [B*cap] sorted-array indices in the order k_knn_cov_tile takes them (64 per tile)
-  DevBuf<unsigned long long> knn_stats;  // Tuning::knn_stats only: counters of k_knn_cov_brick
+  DevBuf<unsigned long long> knn_stats;  // Tuning::knn_stats only: counters of k_knn_cov_tile<STATS>
   DevBuf<GridMeta> meta;
   DevBuf<HashSlot> table;
   bool built = false, has_cov = false, has_order = false;
@@ -162,6 +162,8 @@ void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& s
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
                   const float* T16_host_all);
 void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, mi355_result* out, double* fitness_out);
+// per pair: the iteration count at which is_converged first held (-1: never); synchronises
+void gicp_first_converged(hipStream_t s, GicpBatch& gb, int* out);
 // single linearisation at a given pose (parity tests), pair 0 only
 void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T16,
                          double* H36, double* b6, double* err, int* corr_caller_order);

@@ -27,6 +27,8 @@ struct GicpPairState {
   double last_error;
   int iter, trial, active, converged, n_inliers, lm_failed, need_error, status;
   double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
+  int first_conv;    // iterations run when is_converged first held (-1: never) - what fast_gicp runs without force_iterations
+  int pad_;
 };
 
 // One Levenberg-Marquardt trial step.  step_lm's trial sequence is fully determined by (H, b, lambda): trial t uses
@@ -142,6 +144,8 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.status = MI355_PAIR_OK;
   if (scount && (scount[p] < k_min || tcount[tgt_of_src[p]] < k_min)) { s.active = 0; s.status = MI355_PAIR_TOO_FEW_POINTS; }
   s.last_step = 1.0e9;
+  s.first_conv = -1;
+  s.pad_ = 0;
   st[p] = s;
 }
 
@@ -1100,6 +1104,7 @@ __device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParam
   }
   const bool conv = is_converged(s.delta, P.rotation_epsilon, P.transformation_epsilon);
   s.converged = conv ? 1 : 0;
+  if (conv && s.first_conv < 0) s.first_conv = s.iter;
   {
     double rmax = 0, tmax = 0;
     for (int k = 0; k < 9; k++) rmax = fmax(rmax, fabs(s.delta.R[k] - ((k % 4 == 0) ? 1.0 : 0.0)));
@@ -1658,6 +1663,13 @@ void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
     r.status = st[p].status;
     if (fitness_out) fitness_out[p] = fit[2 * p + 1] > 0 ? fit[2 * p] / fit[2 * p + 1] : 1.7976931348623157e308;
   }
+}
+
+void gicp_first_converged(hipStream_t s, GicpBatch& gb, int* out) {
+  std::vector<GicpPairState> st((size_t)gb.S);
+  MI_HIP(hipMemcpyAsync(st.data(), gb.state.p, (size_t)gb.S * sizeof(GicpPairState), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  for (int p = 0; p < gb.S; p++) out[p] = st[(size_t)p].first_conv;
 }
 
 __global__ void k_set_pose(GicpPairState* st, Pose x) {

@@ -38,6 +38,20 @@ inline std::vector<std::vector<int>> shard_by_target(const int* tgt_of_src, int 
   return out;
 }
 
+// Field-wise equality of the parameter structs (they contain padding bytes, and callers fill stack locals field by field: a
+// memcmp over the raw struct may differ where no parameter does and would rebuild a lane's batch - tens of GB - at every call).
+inline bool same_params(const mi355_gicp_params& a, const mi355_gicp_params& b) {
+  return a.k_correspondences == b.k_correspondences && a.max_iterations == b.max_iterations && a.transformation_epsilon == b.transformation_epsilon &&
+         a.rotation_epsilon == b.rotation_epsilon && a.max_correspondence_distance == b.max_correspondence_distance &&
+         a.regularization_method == b.regularization_method && a.optimizer == b.optimizer && a.lm_max_iterations == b.lm_max_iterations &&
+         a.lm_init_lambda_factor == b.lm_init_lambda_factor && a.force_iterations == b.force_iterations && a.num_threads == b.num_threads;
+}
+inline bool same_params(const mi355_ndt_params& a, const mi355_ndt_params& b) {
+  return a.transformation_epsilon == b.transformation_epsilon && a.step_size == b.step_size && a.resolution == b.resolution &&
+         a.max_iterations == b.max_iterations && a.outlier_ratio == b.outlier_ratio && a.min_points_per_voxel == b.min_points_per_voxel &&
+         a.min_covar_eigvalue_mult == b.min_covar_eigvalue_mult && a.legacy_mt_skip == b.legacy_mt_skip && a.num_threads == b.num_threads;
+}
+
 // One device's share: its context and a batch object that outlives the calls (tens of GB at 512 candidates: allocated once,
 // grown only when a call needs more sources, sub-maps or capacity).
 class Lane {
@@ -63,15 +77,19 @@ class Lane {
     size_t cap = 1;
     for (mi355_cloud* c : sources) cap = std::max(cap, mi355_cloud_size(c));
     for (mi355_cloud* c : targets) cap = std::max(cap, mi355_cloud_size(c));
-    const bool same = batch_ && method == method_ && params_.size() == params_size && std::memcmp(params_.data(), params, params_size) == 0;
+    (void)params_size;
+    const bool same = batch_ && method == method_ &&
+                      (method == MI355_METHOD_FAST_GICP ? same_params(gp_, *(const mi355_gicp_params*)params) : same_params(np_, *(const mi355_ndt_params*)params));
     if (!same || S > S_ || U > U_ || cap > cap_) {  // grow-only
       if (batch_) mi355_batch_destroy(batch_);
       batch_ = nullptr;
       if (!same) S_ = U_ = 0, cap_ = 0;
       S_ = std::max(S, S_); U_ = std::max(U, U_); cap_ = std::max(cap, cap_);
       method_ = method;
-      params_.assign((const char*)params, (const char*)params + params_size);
+      if (method == MI355_METHOD_FAST_GICP) gp_ = *(const mi355_gicp_params*)params;
+      else np_ = *(const mi355_ndt_params*)params;
       batch_ = mi355_batch_create(ctx().get(), method, params, S_, U_, cap_);
+      allocations_++;
       if (!batch_) {
         S_ = U_ = 0;
         cap_ = 0;
@@ -92,7 +110,12 @@ class Lane {
   mi355_batch* batch_ = nullptr;
   int S_ = 0, U_ = 0, method_ = -1;
   size_t cap_ = 0;
-  std::vector<char> params_;
+  mi355_gicp_params gp_{};
+  mi355_ndt_params np_{};
+  int allocations_ = 0;
+
+ public:
+  int allocations() const { return allocations_; }  // times the batch object has been (re)created: stays 1 while requests fit
 };
 
 // Run f(lane index) for every lane that has work: inline for one lane, one host thread per lane otherwise (a handle is used

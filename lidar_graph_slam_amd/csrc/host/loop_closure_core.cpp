@@ -130,13 +130,13 @@ void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows,
       f[(size_t)s] = ls.pairwise->getFitnessScore();
     }
   } else {
-    mi355_gicp_params gp;
+    mi355_gicp_params gp{};
     mi355_gicp_default_params(&gp);  // fast_gicp defaults, then the setters of :92-96
     gp.k_correspondences = params_.correspondence_randomness;
     gp.max_iterations = params_.max_iteration;
     gp.transformation_epsilon = params_.transformation_epsilon;
     gp.max_correspondence_distance = params_.max_correspondence_distance;
-    mi355_ndt_params np;
+    mi355_ndt_params np{};
     mi355_ndt_default_params(&np);   // :108-116
     np.transformation_epsilon = params_.transformation_epsilon;
     np.step_size = params_.step_size;

@@ -35,6 +35,11 @@ extern "C" mi355_ctx* mi355_multi_context(mi355_multi* m, int lane) {
   return m->lanes[(size_t)lane]->ctx().get();
 }
 
+extern "C" int mi355_multi_lane_allocations(const mi355_multi* m, int lane) {
+  if (!m || lane < 0 || (size_t)lane >= m->lanes.size()) return -1;
+  return m->lanes[(size_t)lane]->allocations();
+}
+
 extern "C" int mi355_multi_shard_by_target(const int* tgt_of_src, int n_pairs, int n_lanes, int* lane_of_pair) {
   if (n_pairs < 0 || n_lanes <= 0 || (n_pairs && (!tgt_of_src || !lane_of_pair))) return MI355_EINVAL;
   const auto shards = mi355::shard_by_target(tgt_of_src, n_pairs, n_lanes);
@@ -53,9 +58,9 @@ extern "C" int mi355_multi_batch_register(mi355_multi* m, int method, const void
     if (with_fitness && !fitness) throw mi355::Error(MI355_EINVAL, "with_fitness needs a fitness array");
     if (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP) throw mi355::Error(MI355_EINVAL, "batch mode registers with FAST_GICP or NDT_OMP");
     if (!tgt_of_src && n_sources != n_targets) throw mi355::Error(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
-    mi355_gicp_params gp;
+    mi355_gicp_params gp{};
     mi355_gicp_default_params(&gp);
-    mi355_ndt_params np;
+    mi355_ndt_params np{};
     mi355_ndt_default_params(&np);
     if (params && method == MI355_METHOD_FAST_GICP) gp = *(const mi355_gicp_params*)params;
     if (params && method == MI355_METHOD_NDT_OMP) np = *(const mi355_ndt_params*)params;

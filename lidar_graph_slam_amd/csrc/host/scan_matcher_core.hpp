@@ -120,6 +120,9 @@ class ScanMatcherCore {
   ScanMatcherCore(Context& ctx, const ScanMatcherParams& p);
   // `msg` cloud in the sensor frame; base_to_sensor = the TF the node looks up (identity when the lookup fails, cpp:259-271)
   ScanOutput callback_cloud(const PointCloud& input_cloud, const Matrix4f& base_to_sensor);
+  // NOTE: KeyFrame::device is non-null only while the key frame is inside the sliding window (the last max_scan_accumulate_num
+  // frames); when a frame leaves it its cloud is downloaded into KeyFrame::cloud and `device` is reset - read clouds through
+  // key_frame_cloud(i), which serves either.
   const std::vector<KeyFrame>& key_frames() const { return key_frame_array_; }
   // key_frame.cloud as the reference holds it (:145,196): from the host copy, or downloaded while the frame is still in the window
   PointCloud key_frame_cloud(size_t i) const {

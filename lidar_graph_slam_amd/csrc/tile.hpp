@@ -152,96 +152,6 @@ __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& c
   return n;
 }
 
-// ---- LDS-staged cell bricks ------------------------------------------------------------------------------------------
-// The candidates a wave has gathered for its 64 queries, binned into cubic cells of edge h laid over the gathered box:
-// a counting sort over the cells gives cstart[cell] (prefix of the per-cell counts) and perm[] (candidate positions, as byte
-// offsets into cand[], in cell order with x fastest).  The cells x0 .. x1 of one (y, z) row are then ONE contiguous piece
-// perm[cstart[row + x0] .. cstart[row + x1 + 1]), so a lane visits exactly the candidates of its OWN cube [q - R, q + R]^3 with
-// two LDS reads per row — instead of every candidate of the tile.  Binning is the same monotone fp32 function for candidates and
-// cube corners, so every gathered point with coordinates inside the cube is in the visited pieces.
-struct Brick {
-  float ox, oy, oz, inv_h;
-  int nx, ny, nz;
-};
-__device__ __forceinline__ int brick_cell1(float v, float o, float inv_h, int n) {
-  return min(max((int)floorf(fminf(fmaxf((v - o) * inv_h, -1.0f), 4096.0f)), 0), n - 1);
-}
-// Cells of edge >= h_want over the box [lo, hi], at most CELLS of them (h grows until the brick fits).
-template <int CELLS>
-__device__ __forceinline__ Brick brick_over(const TileBox& b, float h_want) {
-  Brick br;
-  float h = h_want;
-  const float ex = b.hx - b.lx, ey = b.hy - b.ly, ez = b.hz - b.lz;
-  for (;;) {
-    const float inv = 1.f / h;
-    br.nx = (int)floorf(ex * inv) + 1; br.ny = (int)floorf(ey * inv) + 1; br.nz = (int)floorf(ez * inv) + 1;
-    if ((long)br.nx * br.ny * br.nz <= CELLS) { br.inv_h = inv; break; }
-    h *= 1.2f;
-  }
-  br.ox = b.lx; br.oy = b.ly; br.oz = b.lz;
-  return br;
-}
-// Bin cand[0 .. n) into the brick: cstart[0 .. CELLS] (u16, 16-byte aligned) and perm[0 .. n).  Wave-level: every lane calls it with
-// the same arguments.  CAND = capacity of cand[] (a multiple of 64, at most 1024), CELLS a multiple of 512.
-template <int CAND, int CELLS>
-__device__ __forceinline__ void brick_build(const Brick& b, const float4* cand, int n, uint16_t* cstart, uint16_t* perm) {
-  constexpr int kPerLane = CAND / kWave, kCellsPerLane = CELLS / kWave;
-  const int lane = lane_id();
-  uint32_t* cw = reinterpret_cast<uint32_t*>(cstart);
-#pragma unroll
-  for (int t = 0; t < CELLS / 2 / kWave; t++) cw[t * kWave + lane] = 0u;
-  if (lane == 0) cstart[CELLS] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  uint32_t cr[kPerLane];  // (cell << 10) | rank inside the cell
-#pragma unroll
-  for (int t = 0; t < kPerLane; t++) {
-    const int i = t * kWave + lane;
-    cr[t] = 0xFFFFFFFFu;
-    if (i < n) {
-      const float4 p = cand[i];
-      const int cell = brick_cell1(p.x, b.ox, b.inv_h, b.nx) + b.nx * (brick_cell1(p.y, b.oy, b.inv_h, b.ny) + b.ny * brick_cell1(p.z, b.oz, b.inv_h, b.nz));
-      const int sh = (cell & 1) * 16;
-      const uint32_t old = atomicAdd(&cw[cell >> 1], 1u << sh);
-      cr[t] = ((uint32_t)cell << 10) | ((old >> sh) & 0xFFFFu);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  {  // exclusive prefix over the cells: lane l owns cells [kCellsPerLane l, kCellsPerLane (l + 1))
-    uint32_t w[kCellsPerLane / 2];
-#pragma unroll
-    for (int t = 0; t < kCellsPerLane / 8; t++) {
-      const uint4 v = reinterpret_cast<const uint4*>(cw)[lane * (kCellsPerLane / 8) + t];
-      w[4 * t] = v.x; w[4 * t + 1] = v.y; w[4 * t + 2] = v.z; w[4 * t + 3] = v.w;
-    }
-    uint32_t sum = 0;
-#pragma unroll
-    for (int t = 0; t < kCellsPerLane / 2; t++) sum += (w[t] & 0xFFFFu) + (w[t] >> 16);
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, kWave);
-      if (lane >= off) incl += o;
-    }
-    uint32_t run = incl - sum;
-#pragma unroll
-    for (int t = 0; t < kCellsPerLane / 2; t++) {
-      const uint32_t lo = run, hi = run + (w[t] & 0xFFFFu);
-      run = hi + (w[t] >> 16);
-      w[t] = lo | (hi << 16);
-    }
-#pragma unroll
-    for (int t = 0; t < kCellsPerLane / 8; t++)
-      reinterpret_cast<uint4*>(cw)[lane * (kCellsPerLane / 8) + t] = make_uint4(w[4 * t], w[4 * t + 1], w[4 * t + 2], w[4 * t + 3]);
-    if (lane == kWave - 1) cstart[CELLS] = (uint16_t)run;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-  for (int t = 0; t < kPerLane; t++) {
-    if (cr[t] != 0xFFFFFFFFu) perm[cstart[cr[t] >> 10] + (cr[t] & 0x3FFu)] = (uint16_t)((t * kWave + lane) << 4);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-}
-
 // The K smallest 32-bit keys seen so far, ascending, maintained by a branch-free median network (one v_med3_u32 per
 // position and candidate).  Keys are squared distances (positive floats order like unsigned integers) whose low mantissa
 // bits carry a payload, so the identity of a neighbour travels through the network with its distance.

@@ -58,6 +58,10 @@ class MultiDevice:
             raise L.Mi355Error(rc, self._lib.mi355_multi_last_error(self.handle).decode())
         return [r.to_dict() for r in res], (fit if with_fitness else None), lane
 
+    def lane_allocations(self, lane: int) -> int:
+        """Times lane `lane`'s batch object has been (re)created: stays 1 while requests fit and keep method / parameters."""
+        return int(self._lib.mi355_multi_lane_allocations(self.handle, int(lane)))
+
     def close(self):
         if getattr(self, "handle", None):
             self._lib.mi355_multi_destroy(self.handle)

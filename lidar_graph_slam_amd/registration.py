@@ -382,6 +382,15 @@ class BatchRegistration:
         self.ctx.check(self.ctx._lib.mi355_batch_verify_correspondences(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def diagnostics(self):
+        """After align() of a FAST_GICP batch (synchronises): {"first_converged": int32 [n_sources] - iterations run when fast_gicp's
+        is_converged first held, -1 = never; "knn_points" / "knn_handed_over": (targets, sources) points of the last covariance
+        launches and how many the tile search handed over to the one-wave-per-query kernel}."""
+        fc = np.empty(self.n_sources, dtype=np.int32)
+        pts, fb = np.zeros(2, dtype=np.int64), np.zeros(2, dtype=np.int64)
+        self.ctx.check(self.ctx._lib.mi355_batch_diagnostics(self.handle, fc.ctypes.data, pts.ctypes.data, fb.ctypes.data))
+        return {"first_converged": fc, "knn_points": pts, "knn_handed_over": fb}
+
     def set_side_streams(self, on: bool | None):
         """Prepare targets and sources on two overlapping side streams (True, the default), or one after the other on the batch's
         own stream (False: what a profiler wants); None = the library default."""

@@ -183,6 +183,24 @@ def make_pair(*, n_rings: int = 64, n_azimuth: int = 1024, T_gt: np.ndarray | No
     return src, tgt, T_gt
 
 
+def bench_pair_spec(i: int, rank: int = 0) -> dict:
+    """Arguments of make_pair for the i-th distinct scene / pose of the benchmark batch (bench.py): its own street scene (box
+    placement `scene_seed`), its own sensor pose on it and its own relative motion - 0.6 ... 1.2 m forward, +-0.12 m sideways,
+    +-2.4 deg of yaw (BASELINE configs[1] is the i = 0 motion: 1.0 m, 0.1 m, 2 deg) - and its own noise seeds."""
+    r = np.random.default_rng(9000 + 131 * i + 7919 * rank)
+    if i == 0 and rank == 0:
+        T_gt = default_pair_gt()
+    else:
+        T_gt = se3(r.uniform(0.6, 1.2), r.uniform(-0.12, 0.12), 0.0, 0.0, 0.0, np.deg2rad(r.uniform(-2.4, 2.4)))
+    T_tgt = se3(r.uniform(-35.0, 35.0), r.uniform(-1.2, 1.2), 0.0, 0.0, 0.0, r.uniform(-0.06, 0.06))
+    return dict(T_gt=T_gt, T_target=T_tgt, scene_seed=1234 + 17 * i + 1009 * rank, seed=11 + 17 * i + 101 * rank)
+
+
+def make_pair_job(spec: dict):
+    """make_pair(**spec) as a picklable job for a pool of spawned workers (ray casting is single-threaded NumPy)."""
+    return make_pair(**spec)
+
+
 def trajectory(n: int, *, speed: float = 8.0, hz: float = 10.0, seed: int = 3) -> np.ndarray:
     """[n,4,4] KITTI-like path: `speed` m/s at `hz` scans/s, gentle yaw-rate changes <= 10 deg/s, staying in the corridor."""
     rng = np.random.default_rng(seed)

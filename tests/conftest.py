@@ -22,6 +22,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "children_only: the test starts its GPU work in child processes; the pytest process itself stays off the GPU")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """PARITY_LOG_ONLY turns the parity assertions of tests/parity.py into log lines (a measuring run).  Such a session must
+    never read as a passing one: it ends with a non-zero exit status and says why."""
+    if os.environ.get("PARITY_LOG_ONLY"):
+        sys.stderr.write("\nPARITY_LOG_ONLY is set: parity assertions were LOGGED, NOT JUDGED - this session is a measuring run and counts as failed\n")
+        if session.exitstatus == 0:
+            session.exitstatus = 1
+
+
 @pytest.fixture(autouse=True)
 def _torch_before_the_library(request):
     """torch bundles its own ROCm runtime; once libmi355_lidar.so has pulled /opt/rocm's libamdhip64 into the process torch can

@@ -49,8 +49,10 @@ def test_sharded_registration_equals_the_single_batch(method):
     for lanes in ([0], [0, 0], [0, 0, 0]):
         md = MultiDevice(lanes)
         assert md.n_devices == len(lanes)
-        for _ in range(2):  # the second call reuses every lane's batch object
+        for call in range(2):  # the second call reuses every lane's batch object
             res, fit, lane = md.batch_register(sources, targets, tgt_of_src, method=method, **kw)
+            # ... really: allocated once per busy lane, whatever the padding bytes of the parameter structs hold
+            assert [md.lane_allocations(i) for i in range(len(lanes))] == [1 if i in set(lane.tolist()) else 0 for i in range(len(lanes))], call
             np.testing.assert_array_equal(lane, shard_by_target(tgt_of_src, len(lanes)))
             assert len(set(lane.tolist())) == min(len(lanes), U)  # every lane that can have work has some
             for p in range(S):
@@ -64,6 +66,7 @@ def test_sharded_registration_equals_the_single_batch(method):
         sub = [p for p in range(S) if tgt_of_src[p] == tgt_of_src[0]]
         res, fit, lane = md.batch_register([sources[p] for p in sub], [targets[tgt_of_src[0]]], np.zeros(len(sub), np.int32), method=method, **kw)
         assert len(set(lane.tolist())) == 1
+        assert max(md.lane_allocations(i) for i in range(len(lanes))) == 1  # a smaller request fits the grown batch
         for k, p in enumerate(sub):
             np.testing.assert_allclose(res[k]["T"], single[p]["T"], rtol=0, atol=2e-6)
         md.close()
