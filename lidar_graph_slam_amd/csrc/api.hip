@@ -37,6 +37,7 @@ const Tuning& tuning() {
     geti("MI355_TILE_ORDER", v.tile_order);
     getf("MI355_TILE_GATHER", v.tile_gather);
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
+    geti("MI355_BATCH_PARTS", v.batch_parts);
     getf("MI355_GRID_CELL", v.grid_cell);
     geti("MI355_KNN_STATS", v.knn_stats);
     return v;
@@ -149,22 +150,43 @@ struct mi355_batch {
   int n_sources = 0, n_targets = 0;          // live slots (mi355_batch_set_live; = the allocation after mi355_batch_create)
   int alloc_sources = 0, alloc_targets = 0;  // slots the buffers were sized for
   size_t cap = 0;
-  // Targets and sources are prepared (prefilter, sort, voxel hash, k-NN covariances) on two side streams forked from the
-  // context stream at call time and joined by mi355_batch_align: the two chains are independent, and most of their kernels
-  // are short or end in a thin tail (sort passes, the k-NN stragglers), so run together they fill each other's gaps.
-  struct Side {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, knn_done = nullptr;
-    bool pending = false;  // work enqueued since the last join
-    bool knn_pending = false;  // knn_done recorded since the last join
-    Workspace ws;
-    CloudSet sor_set;
-    DevBuf<int> cnt_in;
-    std::vector<int> h_counts;
+  // THE PIPELINE (round 4).  A batch of >= 512 FAST_GICP pairs is cut into 2 - 4 PARTS: contiguous shares of the sources and of the
+  // targets.  The preparation chains (prefilter -> sort -> voxel hash -> k-NN covariances) of the targets run part after part on one
+  // side stream, those of the sources on another, and every part's LM loop on a stream of its own, released by the events of the
+  // chains it needs: while part i is in its LM iterations (streaming kernels, bound by HBM) the chains of part i + 1 index the next
+  // clouds (latency-bound searches) - what a caller used to get only from several batch objects in flight.  A part is the unit of
+  // every launch; a pair's launch geometry is that of the whole batch (GicpBatch::S_geometry), so results are bit-equal whatever the
+  // number of parts.  Small batches and NDT batches have one part.
+  struct Part {
+    int s0 = 0, ns = 0, t0 = 0, nt = 0;  // live ranges of sources / targets
+    int cap_s = 0, cap_t = 0;            // slots this part was sized for
+    CloudSet src;   // this part's sources (owned; pair indices are part-local)
+    CloudSet tgt;   // this part's targets: a WINDOW into mi355_batch::tgt (one cloud-major array: a pair may register against any target)
+    GicpBatch gb;
+    Workspace ws[2];        // 0 = the targets' chain, 1 = the sources' chain
+    CloudSet sor_set[2];
+    DevBuf<int> cnt_in[2];
+    std::vector<int> h_counts[2];
+    hipStream_t lm_stream = nullptr;
+    hipEvent_t prep_done[2] = {nullptr, nullptr}, knn_done[2] = {nullptr, nullptr}, lm_done = nullptr;
+    bool prep_pending[2] = {false, false}, knn_pending[2] = {false, false};
+    int it_enqueued = 0;
+    bool lm_finished = false;
+    ~Part() {
+      if (lm_stream) { (void)hipStreamSynchronize(lm_stream); (void)hipStreamDestroy(lm_stream); }
+      for (auto& e : prep_done) if (e) (void)hipEventDestroy(e);
+      for (auto& e : knn_done) if (e) (void)hipEventDestroy(e);
+      if (lm_done) (void)hipEventDestroy(lm_done);
+    }
   };
-  Side side[2];  // 0 targets, 1 sources
-  CloudSet src, tgt;
-  GicpBatch gb;
+  std::vector<std::unique_ptr<Part>> parts;
+  struct Side {  // the stream the chains of one side (0 targets, 1 sources) run on, forked from the batch's stream at call time
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr;
+    bool pending = false;  // work enqueued since the last join
+  };
+  Side side[2];
+  CloudSet tgt;   // ALL targets
   KernelTimers timers;  // mi355_batch_set_timing / mi355_batch_kernel_times
   int side_streams = -1;  // mi355_batch_set_side_streams: -1 = the library default (Tuning::side_streams), 0 / 1 = off / on
   DevBuf<float4> host_stage_tgt, host_stage_src;  // device copies of host inputs, one per side: a side's next upload is ordered behind the align that joined its last chain
@@ -172,14 +194,26 @@ struct mi355_batch {
   hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
   bool has_own_stream = false;
   hipStream_t stream() const { return has_own_stream ? own_stream : ctx->stream; }
+  bool use_side_streams() const { return (side_streams >= 0 ? side_streams : tuning().side_streams) != 0; }
+  // where part i's LM loop runs: its own stream when the chains run beside it, else the batch's
+  hipStream_t lm_stream(size_t i) const { return (use_side_streams() && parts.size() > 1) ? parts[i]->lm_stream : stream(); }
   bool has_src = false, has_tgt = false, aligned = false, with_fitness = false;
+  // every internal stream has finished what was enqueued on it
+  void quiesce() {
+    for (auto& sd : side)
+      if (sd.stream) MI_HIP(hipStreamSynchronize(sd.stream));
+    for (auto& pt : parts)
+      if (pt->lm_stream) MI_HIP(hipStreamSynchronize(pt->lm_stream));
+    MI_HIP(hipStreamSynchronize(stream()));
+    for (auto& sd : side) sd.pending = false;
+    for (auto& pt : parts) pt->prep_pending[0] = pt->prep_pending[1] = pt->knn_pending[0] = pt->knn_pending[1] = false;
+  }
   ~mi355_batch() {
     if (ndt) ndt_batch_destroy(ndt);
+    parts.clear();
     for (auto& sd : side) {
       if (sd.stream) { (void)hipStreamSynchronize(sd.stream); (void)hipStreamDestroy(sd.stream); }
       if (sd.fork) (void)hipEventDestroy(sd.fork);
-      if (sd.join) (void)hipEventDestroy(sd.join);
-      if (sd.knn_done) (void)hipEventDestroy(sd.knn_done);
     }
   }
 };
@@ -1074,6 +1108,50 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
 }
 
 // ---- batch ---------------------------------------------------------------------------------------------------------
+using Part = mi355_batch::Part;
+
+// How many parts a batch is cut into (mi355_batch: THE PIPELINE).  One for NDT (its state machine advances all pairs together), for
+// the per-lane k-NN path and for the counter builds (tuning aids that read one set of counters per launch).
+static int batch_part_count(int method, int n_sources) {
+  if (method != MI355_METHOD_FAST_GICP) return 1;
+  const Tuning& tn = tuning();
+  if (!tn.knn_tiles || tn.knn_stats || tn.corr_stats) return 1;
+  if (tn.batch_parts > 0) return std::max(1, std::min(std::min(tn.batch_parts, n_sources), 8));
+  return n_sources >= 512 ? 2 : 1;  // (measured at 2 048 pairs: 2 parts +3 %, 3 parts +-0, 4 parts -6 %: profiles/r04_parts_ab.txt)
+}
+
+// The live sources and targets dealt to the parts: ceil(n / parts) each, the last part(s) what is left - possibly nothing.
+static void batch_layout(mi355_batch* b) {
+  const int N = (int)b->parts.size();
+  const int cs = div_up(b->n_sources, N), ct = div_up(b->n_targets, N);
+  const CloudSet& T = b->tgt;
+  for (int i = 0; i < N; i++) {
+    Part& pt = *b->parts[(size_t)i];
+    pt.s0 = std::min(i * cs, b->n_sources);
+    pt.ns = std::min(cs, b->n_sources - pt.s0);
+    pt.t0 = std::min(i * ct, b->n_targets);
+    pt.nt = std::min(ct, b->n_targets - pt.t0);
+    pt.src.B = pt.ns;
+    pt.gb.S = pt.ns;
+    CloudSet& w = pt.tgt;  // the window into the targets
+    const size_t o = (size_t)pt.t0, n = (size_t)pt.nt;
+    w.B = pt.nt;
+    w.cap = T.cap;
+    w.slots_cap = T.slots_cap;
+    w.pts.alias(T.pts.p + o * T.cap, n * T.cap);
+    w.orig.alias(T.orig.p + o * T.cap, n * T.cap);
+    w.count.alias(T.count.p + o, n);
+    w.meta.alias(T.meta.p + o, n);
+    w.table.alias(T.table.p + o * T.slots_cap, n * T.slots_cap);
+    if (T.cov.p) w.cov.alias(T.cov.p + o * T.cap, n * T.cap);
+    w.built = w.has_cov = w.has_order = w.cell_keys_in_ws = w.order_keys_in_ws = false;
+  }
+}
+static int target_part_of(const mi355_batch* b, int t) {
+  const int N = (int)b->parts.size();
+  return std::min(t / std::max(div_up(b->n_targets, N), 1), N - 1);
+}
+
 extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity) {
   if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP) || n_sources <= 0 || n_targets <= 0 || capacity == 0) {
     if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP or NDT_OMP)";
@@ -1091,28 +1169,38 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
   b->cap = capacity;
   const int rc = guarded(ctx, [&] {
     MI_HIP(hipSetDevice(ctx->device));
-    b->src.alloc(n_sources, capacity);
     b->tgt.alloc(n_targets, capacity);
-    if (method == MI355_METHOD_NDT_OMP) {
-      if (!(b->np.resolution > 0)) throw ArgError(MI355_EINVAL, "ndt resolution must be positive");
-      gicp_alloc_fitness_only(b->gb, n_sources, capacity);  // getFitnessScore is the point-to-point one for every method
-      b->ndt = ndt_batch_create(n_sources, n_targets);
-    } else {
-      gicp_alloc(b->gb, n_sources, capacity, ctx->compute_units);
+    if (method == MI355_METHOD_FAST_GICP) b->tgt.cov.ensure((size_t)n_targets * capacity);  // (the parts' windows cannot grow it later)
+    if (method == MI355_METHOD_NDT_OMP && !(b->np.resolution > 0)) throw ArgError(MI355_EINVAL, "ndt resolution must be positive");
+    const int N = batch_part_count(method, n_sources);
+    int prio_lo = 0, prio_hi = 0;
+    MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    for (int i = 0; i < N; i++) {
+      b->parts.emplace_back(new Part());
+      Part& pt = *b->parts.back();
+      pt.cap_s = div_up(n_sources, N);
+      pt.cap_t = div_up(n_targets, N);
+      pt.src.alloc(pt.cap_s, capacity);
+      if (method == MI355_METHOD_NDT_OMP) gicp_alloc_fitness_only(pt.gb, n_sources, capacity);  // getFitnessScore is the point-to-point one for every method
+      else gicp_alloc(pt.gb, pt.cap_s, capacity, ctx->compute_units, n_sources);
+      for (int k = 0; k < 2; k++) {
+        const int nb = k == 0 ? pt.cap_t : pt.cap_s;
+        ws_reserve(pt.ws[k], nb, capacity);
+        pt.cnt_in[k].ensure((size_t)nb);
+        MI_HIP(hipEventCreateWithFlags(&pt.prep_done[k], hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&pt.knn_done[k], hipEventDisableTiming));
+      }
+      MI_HIP(hipEventCreateWithFlags(&pt.lm_done, hipEventDisableTiming));
+      // the LM loops run AHEAD of the (lowest-priority) preparation chains: their short kernels get the freed wave slots first
+      if (N > 1) MI_HIP(hipStreamCreateWithPriority(&pt.lm_stream, hipStreamNonBlocking, prio_hi));
     }
+    if (method == MI355_METHOD_NDT_OMP) b->ndt = ndt_batch_create(n_sources, n_targets);
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
-      // the preparation chains run at the lowest priority: when batches overlap (mi355_batch_set_stream), the short,
-      // latency-bound kernels of another batch's LM iterations get the freed wave slots first
-      int prio_lo = 0, prio_hi = 0;
-      MI_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
       MI_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, prio_lo));
       MI_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-      MI_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
-      MI_HIP(hipEventCreateWithFlags(&sd.knn_done, hipEventDisableTiming));
-      ws_reserve(sd.ws, k == 0 ? n_targets : n_sources, capacity);
-      sd.cnt_in.ensure(k == 0 ? n_targets : n_sources);
     }
+    batch_layout(b);
   });
   if (rc != MI355_OK) {
     delete b;
@@ -1124,7 +1212,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
 extern "C" void mi355_batch_destroy(mi355_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
-  (void)hipStreamSynchronize(b->stream());
+  try { b->quiesce(); } catch (...) {}
   delete b;
 }
 
@@ -1132,68 +1220,75 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
   mi355_ctx* ctx = b->ctx;
   MI_HIP(hipSetDevice(ctx->device));
   if (!d_points || !counts) throw ArgError(MI355_EINVAL, "NULL points / counts");
-  auto& sd = b->side[targets ? 0 : 1];
-  CloudSet& set = targets ? b->tgt : b->src;
+  const int k = targets ? 0 : 1;
+  auto& sd = b->side[k];
   const int B = targets ? b->n_targets : b->n_sources;
   for (int i = 0; i < B; i++)
     if (counts[i] < 0 || (size_t)counts[i] > b->cap) throw ArgError(MI355_EINVAL, "count exceeds capacity");
-  // fork: everything already enqueued on the context stream (the producer of d_points, the previous align that still reads
-  // this cloud set) comes first
-  const bool side_streams = (b->side_streams >= 0 ? b->side_streams : tuning().side_streams) != 0;
+  // fork: everything already enqueued on the batch's stream (the producer of d_points, the previous align that still reads
+  // these cloud sets) comes first
+  const bool side_streams = b->use_side_streams();
   TimerScope timing(&b->timers);
   if (side_streams) {
     MI_HIP(hipEventRecord(sd.fork, b->stream()));
     MI_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
   }
-  if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));  // h_counts of a not-yet-joined call may still be read by its copy
-  sd.h_counts.assign(counts, counts + B);
   hipStream_t s = side_streams ? sd.stream : b->stream();
-  MI_HIP(hipMemcpyAsync(sd.cnt_in.p, sd.h_counts.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
-  const float4* pts = d_points;
-  const int* cnt = sd.cnt_in.p;
-  if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
-    run_prefilter(s, sd.ws, sd.sor_set, ctx->grid_cell, *pf, B, b->cap, d_points, sd.cnt_in.p, sd.ws.stage_a, sd.ws.stage_b, sd.ws.count_a,
-                  sd.ws.count_b, &pts, &cnt, &set);
-  build_grid(s, sd.ws, pts, cnt, set, ctx->grid_cell, b->method == MI355_METHOD_FAST_GICP);
-  if (b->method == MI355_METHOD_NDT_OMP) {
-    // NDT: the sources are just points; every target gets its voxel Gaussians (N1).  The leaf builder sizes its launches on
-    // the host, so the counts after the prefilter are read back here (one sync per set call, none per alignment).
-    std::vector<int>& hc = targets ? b->ndt_tgt_counts : b->ndt_src_counts;
-    hc.resize((size_t)B);
-    MI_HIP(hipMemcpyAsync(hc.data(), set.count.p, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
-    if (targets)
-      for (int u = 0; u < B; u++) ndt_batch_set_target(s, sd.ws, *b->ndt, u, set.pts.p + (size_t)u * b->cap, (size_t)hc[(size_t)u], b->np);
-  } else {
-    // The k-NN / covariance kernels of the two chains gain nothing from running at the same time (both are bound by the same VALU
-    // and LDS; at 1 024 clouds the second one simply queued behind the first, at 2 048 their blocks interleave and each takes
-    // twice as long): the chain that comes second starts its k-NN when the other's is done — its prefilter, sort and hash build
-    // still run beside that k-NN — and a kernel's duration is its own again (what rocprofv3 and the bench's roofline report).
-    auto& other = b->side[targets ? 1 : 0];
-    // (batches only: for ONE cloud - a registration object, the scan matcher's sub-map - the sort costs more than the search gains:
-    // measured 2.19 instead of 1.99 ms per scan on the config-4 stream)
-    build_tile_order(s, sd.ws, set);
-    if (side_streams && other.knn_pending) MI_HIP(hipStreamWaitEvent(s, other.knn_done, 0));
-    compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
-    if (side_streams) {
-      MI_HIP(hipEventRecord(sd.knn_done, s));
-      sd.knn_pending = true;
+  const bool pipelined = b->parts.size() > 1;
+  for (auto& ptp : b->parts) {
+    Part& pt = *ptp;
+    const int c0 = targets ? pt.t0 : pt.s0, n = targets ? pt.nt : pt.ns;
+    if (n <= 0) continue;
+    CloudSet& set = targets ? pt.tgt : pt.src;
+    if (pt.prep_pending[k]) MI_HIP(hipEventSynchronize(pt.prep_done[k]));  // h_counts of a not-yet-joined call may still be read by its copy
+    pt.h_counts[k].assign(counts + c0, counts + c0 + n);
+    MI_HIP(hipMemcpyAsync(pt.cnt_in[k].p, pt.h_counts[k].data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    const float4* in = d_points + (size_t)c0 * b->cap;
+    const float4* pts = in;
+    const int* cnt = pt.cnt_in[k].p;
+    Workspace& ws = pt.ws[k];
+    if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
+      run_prefilter(s, ws, pt.sor_set[k], ctx->grid_cell, *pf, n, b->cap, in, pt.cnt_in[k].p, ws.stage_a, ws.stage_b, ws.count_a, ws.count_b, &pts, &cnt, &set);
+    build_grid(s, ws, pts, cnt, set, ctx->grid_cell, b->method == MI355_METHOD_FAST_GICP);
+    if (b->method == MI355_METHOD_NDT_OMP) {
+      // NDT (one part): the sources are just points; every target gets its voxel Gaussians (N1).  The leaf builder sizes its launches
+      // on the host, so the counts after the prefilter are read back here (one sync per set call, none per alignment).
+      std::vector<int>& hc = targets ? b->ndt_tgt_counts : b->ndt_src_counts;
+      hc.resize((size_t)n);
+      MI_HIP(hipMemcpyAsync(hc.data(), set.count.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+      MI_HIP(hipStreamSynchronize(s));
+      if (targets)
+        for (int u = 0; u < n; u++) ndt_batch_set_target(s, ws, *b->ndt, u, set.pts.p + (size_t)u * b->cap, (size_t)hc[(size_t)u], b->np);
+    } else {
+      // (batches only: for ONE cloud - a registration object, the scan matcher's sub-map - the sort costs more than the search gains:
+      // measured 2.19 instead of 1.99 ms per scan on the config-4 stream)
+      build_tile_order(s, ws, set);
+      // A batch of ONE part: the k-NN / covariance kernels of the two chains gain nothing from running at the same time (both are
+      // bound by the same VALU and LDS), so the chain that comes second starts its k-NN when the other's is done - its prefilter,
+      // sort and hash build still run beside that k-NN - and a kernel's duration is its own (what rocprofv3 reports).  With
+      // several parts the chains of part i + 1 are meant to run beside the LM loop of part i anyway, and the 3 % that two
+      // interleaved k-NN launches gain are taken.
+      if (side_streams && !pipelined && pt.knn_pending[1 - k]) MI_HIP(hipStreamWaitEvent(s, pt.knn_done[1 - k], 0));
+      compute_covariances(s, set, b->gp.k_correspondences, b->gp.regularization_method);
+      if (side_streams) {
+        MI_HIP(hipEventRecord(pt.knn_done[k], s));
+        pt.knn_pending[k] = true;
+      }
     }
+    MI_HIP(hipEventRecord(pt.prep_done[k], s));
+    pt.prep_pending[k] = true;
   }
-  if (side_streams) {
-    MI_HIP(hipEventRecord(sd.join, s));
-    sd.pending = true;
+  if (side_streams) sd.pending = true;
+  if (targets) {
+    b->tgt.built = true;
+    b->tgt.has_cov = b->method == MI355_METHOD_FAST_GICP;
   }
 }
 
-// Make the context stream wait for the side streams' pending work.
-static void batch_join(mi355_batch* b) {
-  for (auto& sd : b->side)
-    if (sd.pending) {
-      MI_HIP(hipStreamWaitEvent(b->stream(), sd.join, 0));
-      sd.pending = false;
-    }
-  for (auto& sd : b->side) sd.knn_pending = false;
+// Make stream `s` wait for the pending preparation chains of side k (all parts).
+static void batch_wait_side(mi355_batch* b, hipStream_t s, int k) {
+  for (auto& pt : b->parts)
+    if (pt->prep_pending[k]) MI_HIP(hipStreamWaitEvent(s, pt->prep_done[k], 0));
 }
 
 extern "C" int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter) {
@@ -1221,10 +1316,8 @@ static int batch_set_host(mi355_batch* b, bool targets, const float* points, con
     const int B = targets ? b->n_targets : b->n_sources;
     DevBuf<float4>& stage = targets ? b->host_stage_tgt : b->host_stage_src;
     stage.ensure((size_t)B * b->cap);
-    {  // a second set call of the same side without an align in between: its last chain may still read the buffer
-      auto& sd = b->side[targets ? 0 : 1];
-      if (sd.pending) MI_HIP(hipStreamWaitEvent(b->stream(), sd.join, 0));
-    }
+    // a second set call of the same side without an align in between: its last chains may still read the buffer
+    batch_wait_side(b, b->stream(), targets ? 0 : 1);
     // only the filled part of every segment crosses PCIe (sources of 64 k points in segments sized for 300 k-point sub-maps)
     size_t widest = 0;
     if (counts)
@@ -1234,9 +1327,9 @@ static int batch_set_host(mi355_batch* b, bool targets, const float* points, con
       MI_HIP(hipMemcpy2DAsync(stage.p, b->cap * sizeof(float4), points, b->cap * sizeof(float4), widest * sizeof(float4), (size_t)B,
                               hipMemcpyHostToDevice, b->stream()));
     MI_HIP(hipStreamSynchronize(b->stream()));  // the caller's buffer is free when this call returns
-    // The chain runs on the side's own stream and this call returns: the other side's upload crosses PCIe while it runs (with ONE
+    // The chains run on the side's own stream and this call returns: the other side's upload crosses PCIe while they run (with ONE
     // staging buffer the call had to wait for the chain - 186 ms per 2 048-pair step of host inputs instead of ~160).  The buffer is
-    // written again by this side's next upload, on the batch's stream behind the align that joined this chain.
+    // written again by this side's next upload, on the batch's stream behind the align that joined these chains.
     batch_set(b, targets, stage.p, counts, pf);
     if (targets) b->has_tgt = true; else b->has_src = true;
     b->aligned = false;
@@ -1249,6 +1342,7 @@ static int batch_set_clouds(mi355_batch* b, bool targets, mi355_cloud* const* cl
     const int B = targets ? b->n_targets : b->n_sources;
     DevBuf<float4>& stage = targets ? b->cloud_stage_tgt : b->cloud_stage_src;  // stays valid until the next call: no sync needed
     stage.ensure((size_t)B * b->cap);
+    batch_wait_side(b, b->stream(), targets ? 0 : 1);  // (a second set call of this side without an align in between)
     std::vector<int> counts((size_t)B);
     for (int i = 0; i < B; i++) {
       if (!clouds[i] || clouds[i]->ctx != b->ctx) throw ArgError(MI355_EINVAL, "NULL cloud / cloud of another context");
@@ -1279,9 +1373,7 @@ extern "C" int mi355_batch_set_stream(mi355_batch* b, void* hip_stream, int use_
   if (!b) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
     MI_HIP(hipSetDevice(b->ctx->device));
-    MI_HIP(hipStreamSynchronize(b->stream()));  // nothing of this batch may still be in flight on the old stream
-    for (auto& sd : b->side)
-      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    b->quiesce();  // nothing of this batch may still be in flight on the old stream
     b->has_own_stream = !use_context_stream;
     b->own_stream = (hipStream_t)hip_stream;
   });
@@ -1292,24 +1384,100 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
   return guarded(b->ctx, [&] {
     if (!b->has_src || !b->has_tgt) throw ArgError(MI355_ESTATE, "sources / targets not set");
     if (!tgt_of_src && b->n_sources != b->n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
+    if (tgt_of_src)
+      for (int p = 0; p < b->n_sources; p++)
+        if (tgt_of_src[p] < 0 || tgt_of_src[p] >= b->n_targets) throw ArgError(MI355_EINVAL, "tgt_of_src out of range");
     MI_HIP(hipSetDevice(b->ctx->device));
-    batch_join(b);
     TimerScope timing(&b->timers);
     b->with_fitness = with_fitness != 0;
+    hipStream_t main = b->stream();
     if (b->method == MI355_METHOD_NDT_OMP) {
+      Part& pt = *b->parts[0];
+      batch_wait_side(b, main, 0);
+      batch_wait_side(b, main, 1);
       // blocks until every pair has converged (the More-Thuente states advance on the device; the host polls a counter)
-      gicp_set_map(b->stream(), b->gb, tgt_of_src, b->n_targets);
-      ndt_batch_align(b->stream(), *b->ndt, b->src.pts.p, b->cap, b->ndt_src_counts.data(), tgt_of_src, guesses16, b->np);
+      gicp_set_map(main, pt.gb, tgt_of_src, b->n_targets);
+      ndt_batch_align(main, *b->ndt, pt.src.pts.p, b->cap, b->ndt_src_counts.data(), tgt_of_src, guesses16, b->np);
       if (b->with_fitness) {
         std::vector<float> T((size_t)b->n_sources * 16);
         ndt_batch_results(*b->ndt, nullptr, T.data());
-        gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, false, T.data());
+        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
       }
     } else {
-      gicp_align(b->stream(), b->gb, b->src, b->tgt, b->gp, tgt_of_src, guesses16);
-      if (tuning().corr_stats) gicp_corr_stats_print(b->stream(), b->gb);
-      if (b->with_fitness) gicp_fitness(b->stream(), b->gb, b->src, b->tgt, 1.7976931348623157e308, true, nullptr);
+      // every part's LM loop on its stream, behind the chains it needs: its own sources' and those of the targets its pairs name
+      const bool forked = b->lm_stream(0) != main;
+      if (forked) MI_HIP(hipEventRecord(b->side[0].fork, main));  // (what the caller enqueued before this call comes first)
+      for (size_t i = 0; i < b->parts.size(); i++) {
+        Part& pt = *b->parts[i];
+        pt.it_enqueued = 0;
+        pt.lm_finished = pt.ns <= 0;
+        if (pt.ns <= 0) continue;
+        hipStream_t s = b->lm_stream(i);
+        if (forked) MI_HIP(hipStreamWaitEvent(s, b->side[0].fork, 0));
+        if (pt.prep_pending[1]) MI_HIP(hipStreamWaitEvent(s, pt.prep_done[1], 0));
+        unsigned long long need = 0;
+        for (int p = pt.s0; p < pt.s0 + pt.ns; p++) need |= 1ull << target_part_of(b, tgt_of_src ? tgt_of_src[p] : p);
+        for (size_t j = 0; j < b->parts.size(); j++)
+          if (((need >> j) & 1ull) && b->parts[j]->prep_pending[0]) MI_HIP(hipStreamWaitEvent(s, b->parts[j]->prep_done[0], 0));
+        std::vector<int> map((size_t)pt.ns);  // pair -> target, batch-wide target ids (NULL: pair p registers against target p)
+        for (int p = 0; p < pt.ns; p++) map[(size_t)p] = tgt_of_src ? tgt_of_src[pt.s0 + p] : pt.s0 + p;
+        gicp_align_begin(s, pt.gb, pt.src, b->tgt, b->gp, map.data(), guesses16 ? guesses16 + 16 * (size_t)pt.s0 : nullptr);
+      }
+      const int max_it = b->gp.max_iterations;
+      if (b->gp.force_iterations) {
+        for (size_t i = 0; i < b->parts.size(); i++) {
+          Part& pt = *b->parts[i];
+          if (pt.ns > 0) gicp_align_iterate(b->lm_stream(i), pt.gb, pt.src, b->tgt, b->gp, 0, max_it);
+        }
+      } else {
+        // Early stopping: iterations go out in groups of four, each group followed by a poll ("is any pair of this part still
+        // optimising?") whose answer the host reads without blocking; the parts take turns, so while one part's answer is on its
+        // way the others' next groups are enqueued.  At most GicpBatch::kPolls polls of a part are in flight - then the oldest is
+        // waited for - i.e. at most two groups of (empty: converged pairs leave every kernel at once) iterations run past convergence.
+        constexpr int kGroup = 4;
+        bool any = true;
+        while (any) {
+          any = false;
+          for (size_t i = 0; i < b->parts.size(); i++) {
+            Part& pt = *b->parts[i];
+            if (pt.lm_finished) continue;
+            GicpBatch& gb = pt.gb;
+            int n_active = 1;
+            while (!pt.lm_finished && gicp_poll_query(gb, false, &n_active))
+              if (n_active == 0) pt.lm_finished = true;
+            if (!pt.lm_finished && pt.it_enqueued >= max_it) pt.lm_finished = true;
+            while (!pt.lm_finished && gb.polls_issued - gb.polls_seen >= GicpBatch::kPolls)
+              if (gicp_poll_query(gb, true, &n_active) && n_active == 0) pt.lm_finished = true;
+            if (pt.lm_finished) continue;
+            const int it1 = std::min(pt.it_enqueued + kGroup, max_it);
+            gicp_align_iterate(b->lm_stream(i), gb, pt.src, b->tgt, b->gp, pt.it_enqueued, it1);
+            pt.it_enqueued = it1;
+            if (it1 < max_it) gicp_poll_active(b->lm_stream(i), gb);
+            any = true;
+          }
+        }
+        for (auto& pt : b->parts) {
+          int n_active;
+          while (gicp_poll_query(pt->gb, true, &n_active)) {}  // leave no poll in flight
+        }
+      }
+      for (size_t i = 0; i < b->parts.size(); i++) {
+        Part& pt = *b->parts[i];
+        if (pt.ns <= 0) continue;
+        hipStream_t s = b->lm_stream(i);
+        if (tuning().corr_stats) gicp_corr_stats_print(s, pt.gb);
+        if (b->with_fitness) gicp_fitness(s, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, true, nullptr);
+        if (s != main) {  // join: what the caller enqueues on the batch's stream next comes after this alignment
+          MI_HIP(hipEventRecord(pt.lm_done, s));
+          MI_HIP(hipStreamWaitEvent(main, pt.lm_done, 0));
+        }
+      }
+      // (chains no pair needed - targets nobody registers against - are joined too)
+      batch_wait_side(b, main, 0);
+      batch_wait_side(b, main, 1);
     }
+    for (auto& sd : b->side) sd.pending = false;
+    for (auto& pt : b->parts) pt->prep_pending[0] = pt->prep_pending[1] = pt->knn_pending[0] = pt->knn_pending[1] = false;
     b->aligned = true;
   });
 }
@@ -1321,14 +1489,16 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     if (fitness && !b->with_fitness) throw ArgError(MI355_ESTATE, "fitness was not requested in mi355_batch_align");
     MI_HIP(hipSetDevice(b->ctx->device));
     if (b->method == MI355_METHOD_NDT_OMP) {
+      Part& pt = *b->parts[0];
       ndt_batch_results(*b->ndt, results, nullptr);
       for (int i = 0; i < b->n_sources; i++) {
         results[i].n_source = b->ndt_src_counts[(size_t)i];
-        results[i].n_target = b->ndt_tgt_counts[(size_t)b->gb.h_map[(size_t)i]];
+        results[i].n_target = b->ndt_tgt_counts[(size_t)pt.gb.h_map[(size_t)i]];
       }
-      if (fitness) gicp_fitness_values(b->stream(), b->gb, fitness);
+      if (fitness) gicp_fitness_values(b->stream(), pt.gb, fitness);
     } else {
-      gicp_results(b->stream(), b->gb, b->src, b->tgt, results, fitness);
+      for (auto& pt : b->parts)  // (the batch's stream has joined every part's)
+        if (pt->ns > 0) gicp_results(b->stream(), pt->gb, pt->src, b->tgt, results + pt->s0, fitness ? fitness + pt->s0 : nullptr);
     }
   });
 }
@@ -1338,7 +1508,14 @@ extern "C" int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_c
   return guarded(b->ctx, [&] {
     if (!b->aligned || b->method != MI355_METHOD_FAST_GICP) throw ArgError(MI355_ESTATE, "verify_correspondences: after mi355_batch_align of a FAST_GICP batch");
     MI_HIP(hipSetDevice(b->ctx->device));
-    gicp_verify_correspondences(b->stream(), b->gb, b->src, b->tgt, b->gp, n_checked, n_mismatch);
+    *n_checked = *n_mismatch = 0;
+    for (auto& pt : b->parts) {
+      if (pt->ns <= 0) continue;
+      long long c = 0, m = 0;
+      gicp_verify_correspondences(b->stream(), pt->gb, pt->src, b->tgt, b->gp, &c, &m);
+      *n_checked += c;
+      *n_mismatch += m;
+    }
   });
 }
 
@@ -1348,21 +1525,22 @@ extern "C" int mi355_batch_diagnostics(mi355_batch* b, int* first_converged, lon
     if (b->method != MI355_METHOD_FAST_GICP) throw ArgError(MI355_ESTATE, "mi355_batch_diagnostics: a FAST_GICP batch");
     if (first_converged && !b->aligned) throw ArgError(MI355_ESTATE, "mi355_batch_diagnostics: after mi355_batch_align");
     MI_HIP(hipSetDevice(b->ctx->device));
-    MI_HIP(hipStreamSynchronize(b->stream()));
-    for (auto& sd : b->side)
-      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
-    if (first_converged) gicp_first_converged(b->stream(), b->gb, first_converged);
-    for (int k = 0; k < 2; k++) {
-      CloudSet& set = k == 0 ? b->tgt : b->src;
-      long long np = 0, nf = 0;
-      if (set.has_cov && set.fbn.p) {  // [0, B): the hand-over queue lengths of the set's last covariance launch
+    b->quiesce();
+    long long np[2] = {0, 0}, nf[2] = {0, 0};
+    for (auto& pt : b->parts) {
+      if (first_converged && pt->ns > 0) gicp_first_converged(b->stream(), pt->gb, first_converged + pt->s0);
+      for (int k = 0; k < 2; k++) {
+        CloudSet& set = k == 0 ? pt->tgt : pt->src;
+        if (set.B <= 0 || !set.has_cov || !set.fbn.p) continue;  // fbn [0, B): the hand-over queue lengths of the set's last covariance launch
         std::vector<int> fbn((size_t)set.B), cnt((size_t)set.B);
         MI_HIP(hipMemcpy(fbn.data(), set.fbn.p, sizeof(int) * (size_t)set.B, hipMemcpyDeviceToHost));
         MI_HIP(hipMemcpy(cnt.data(), set.count.p, sizeof(int) * (size_t)set.B, hipMemcpyDeviceToHost));
-        for (int c = 0; c < set.B; c++) { np += cnt[(size_t)c]; nf += fbn[(size_t)c]; }
+        for (int c = 0; c < set.B; c++) { np[k] += cnt[(size_t)c]; nf[k] += fbn[(size_t)c]; }
       }
-      if (knn_points) knn_points[k] = np;
-      if (knn_handed_over) knn_handed_over[k] = nf;
+    }
+    for (int k = 0; k < 2; k++) {
+      if (knn_points) knn_points[k] = np[k];
+      if (knn_handed_over) knn_handed_over[k] = nf[k];
     }
   });
 }
@@ -1371,9 +1549,7 @@ extern "C" int mi355_batch_set_side_streams(mi355_batch* b, int mode) {
   if (!b || mode < -1 || mode > 1) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
     MI_HIP(hipSetDevice(b->ctx->device));
-    for (auto& sd : b->side)  // nothing of an earlier call may still be running on a side stream when the mode changes
-      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
-    batch_join(b);
+    b->quiesce();  // nothing of an earlier call may still be running on an internal stream when the mode changes
     b->side_streams = mode;
   });
 }
@@ -1384,13 +1560,11 @@ extern "C" int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets
     if (n_sources <= 0 || n_sources > b->alloc_sources || n_targets <= 0 || n_targets > b->alloc_targets)
       throw ArgError(MI355_EINVAL, "mi355_batch_set_live: 1 <= live slots <= the slots given to mi355_batch_create");
     MI_HIP(hipSetDevice(b->ctx->device));
-    for (auto& sd : b->side)  // nothing of an earlier call may still be running when the slot counts change
-      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
-    batch_join(b);
-    MI_HIP(hipStreamSynchronize(b->stream()));
-    // every per-cloud / per-pair array is cloud-major, so a smaller batch is a prefix of the allocation
-    b->n_sources = b->src.B = b->gb.S = n_sources;
+    b->quiesce();  // nothing of an earlier call may still be running when the slot counts change
+    // every per-cloud / per-pair array is cloud-major, so a smaller batch is a prefix of the allocation (of every part's)
+    b->n_sources = n_sources;
     b->n_targets = b->tgt.B = n_targets;
+    batch_layout(b);
     if (b->ndt) ndt_batch_set_live(*b->ndt, n_sources, n_targets);
     b->has_src = b->has_tgt = b->aligned = false;
   });
@@ -1406,9 +1580,7 @@ extern "C" int mi355_batch_kernel_times(mi355_batch* b, mi355_kernel_time* out, 
   if (!b || !n_out || (capacity > 0 && !out)) return MI355_EINVAL;
   return guarded(b->ctx, [&] {
     MI_HIP(hipSetDevice(b->ctx->device));
-    MI_HIP(hipStreamSynchronize(b->stream()));  // the batch stream has joined the side streams: every recorded event is complete
-    for (auto& sd : b->side)
-      if (sd.pending) MI_HIP(hipStreamSynchronize(sd.stream));
+    b->quiesce();  // every recorded event is complete
     b->timers.collect();
     int n = 0;
     for (int f = 0; f < KF_COUNT; f++) {

@@ -271,6 +271,9 @@ __device__ __forceinline__ uint32_t tile_order_key(const GridMeta& m, const floa
   return hilbert2(ia, ib);
 }
 
+// (round 4: kGiGroups x 64 consecutive elements per wave, all their loads in flight together - with one element per lane a wave was
+// a chain of dependent operations: sorted index -> point gather -> CAS -> slot store, 90 % of its cycles waiting)
+constexpr int kGiGroups = 4;
 __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
                                                        const GridMeta* __restrict__ meta, float4* __restrict__ pts, int* __restrict__ orig,
                                                        HashSlot* __restrict__ table, size_t cap, size_t slots_cap, int G, int B,
@@ -278,40 +281,58 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = meta[c];
-  const int i = bx * blockDim.x + threadIdx.x;
-  if (i >= m.n) return;
-  const size_t o = (size_t)c * cap;
-  const int v = vals[o + i];
-  const float4 pv = in[o + v];
-  pts[o + i] = pv;
-  orig[o + i] = v;
-  if (order_keys) {  // the (key, index) pairs build_tile_order sorts next, while the point is in a register
-    order_keys[o + i] = tile_order_key(m, pv);
-    order_vals[o + i] = i;
-  }
-  const uint32_t key = keys[o + i];
-  const uint32_t kprev = (i > 0) ? keys[o + i - 1] : 0u, knext = (i < m.n - 1) ? keys[o + i + 1] : 0u;
-  HashSlot* tab = table + (size_t)c * slots_cap;
   const int lane = lane_id();  // (one-wave blocks: kHashBlock)
-  for (int l = 0; l <= m.top_level; l++) {  // one (start, end) entry per occupied cell of every level
-    const bool head = (i == 0) || ((kprev >> (3 * l)) != (key >> (3 * l)));
-    const bool tail = (i == m.n - 1) || ((knext >> (3 * l)) != (key >> (3 * l)));
-    // A run that lies inside the wave is entered by its head alone - one CAS and one 16-byte store instead of two of each (the
-    // scattered 4-byte stores and CAS of this kernel reach the fabric as 32-byte writes of their own: 1.5 GB per 1 024-cloud launch
-    // against 0.34 GB of points and indices); only a run that crosses a wave boundary is entered from both ends.
-    const unsigned long long heads = __ballot(head), tails = __ballot(tail);
-    const unsigned long long tails_from_here = tails & ~((1ull << lane) - 1ull), heads_up_to_here = heads & ((2ull << lane) - 1ull);
-    const bool tail_in_wave = tails_from_here != 0ull, head_in_wave = heads_up_to_here != 0ull;
-    if (head) {
-      HashSlot* sl = table_insert(tab, m, level_key(key, l));
-      if (tail_in_wave) {
-        const int t = __builtin_ctzll(tails_from_here);
-        *reinterpret_cast<int4*>(sl) = make_int4((int)level_key(key, l), i, i + (t - lane) + 1, 0);
-      } else {
-        sl->start = i;
+  const int i0 = bx * (kWave * kGiGroups) + lane;
+  if (bx * (kWave * kGiGroups) >= m.n) return;
+  const size_t o = (size_t)c * cap;
+  uint32_t key_[kGiGroups], kprev_[kGiGroups], knext_[kGiGroups];
+  int v_[kGiGroups];
+  float4 pv_[kGiGroups];
+#pragma unroll
+  for (int g = 0; g < kGiGroups; g++) {
+    const int i = i0 + g * kWave;
+    const bool valid = i < m.n;
+    v_[g] = valid ? vals[o + i] : 0;
+    key_[g] = valid ? keys[o + i] : 0u;
+    kprev_[g] = (valid && i > 0) ? keys[o + i - 1] : 0u;
+    knext_[g] = (valid && i < m.n - 1) ? keys[o + i + 1] : 0u;
+  }
+#pragma unroll
+  for (int g = 0; g < kGiGroups; g++) pv_[g] = (i0 + g * kWave < m.n) ? in[o + v_[g]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  HashSlot* tab = table + (size_t)c * slots_cap;
+#pragma unroll
+  for (int g = 0; g < kGiGroups; g++) {
+    const int i = i0 + g * kWave;
+    const bool valid = i < m.n;
+    if (valid) {
+      pts[o + i] = pv_[g];
+      orig[o + i] = v_[g];
+      if (order_keys) {  // the (key, index) pairs build_tile_order sorts next, while the point is in a register
+        order_keys[o + i] = tile_order_key(m, pv_[g]);
+        order_vals[o + i] = i;
       }
-    } else if (tail && !head_in_wave) {
-      table_insert(tab, m, level_key(key, l))->end = i + 1;
+    }
+    const uint32_t key = key_[g], kprev = kprev_[g], knext = knext_[g];
+    for (int l = 0; l <= m.top_level; l++) {  // one (start, end) entry per occupied cell of every level
+      const bool head = valid && ((i == 0) || ((kprev >> (3 * l)) != (key >> (3 * l))));
+      const bool tail = valid && ((i == m.n - 1) || ((knext >> (3 * l)) != (key >> (3 * l))));
+      // A run that lies inside the group is entered by its head alone - one CAS and one 16-byte store instead of two of each (the
+      // scattered 4-byte stores and CAS of this kernel reach the fabric as 32-byte writes of their own: 1.5 GB per 1 024-cloud launch
+      // against 0.34 GB of points and indices); only a run that crosses a group boundary is entered from both ends.
+      const unsigned long long heads = __ballot(head), tails = __ballot(tail);
+      const unsigned long long tails_from_here = tails & ~((1ull << lane) - 1ull), heads_up_to_here = heads & ((2ull << lane) - 1ull);
+      const bool tail_in_wave = tails_from_here != 0ull, head_in_wave = heads_up_to_here != 0ull;
+      if (head) {
+        HashSlot* sl = table_insert(tab, m, level_key(key, l));
+        if (tail_in_wave) {
+          const int t = __builtin_ctzll(tails_from_here);
+          *reinterpret_cast<int4*>(sl) = make_int4((int)level_key(key, l), i, i + (t - lane) + 1, 0);
+        } else {
+          sl->start = i;
+        }
+      } else if (tail && !head_in_wave) {
+        table_insert(tab, m, level_key(key, l))->end = i + 1;
+      }
     }
   }
 }
@@ -338,7 +359,7 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   TimedLaunch tl(KF_HASH_BUILD, s);
   hipLaunchKernelGGL(k_count_cells, grid, dim3(kHashBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
   hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap);
-  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = div_up((long)cap, kHashBlock);
+  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = div_up((long)cap, kHashBlock * kGiGroups);
   hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
   const bool okeys = tile_order_keys && tuning().knn_tiles == 1 && tuning().tile_order;
   hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(kHashBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
@@ -499,6 +520,9 @@ constexpr bool kTilePrefetch = KNN_TILE_PREFETCH != 0;  // fetch the next tile u
 #define KNN_SUB_CAP 764
 #define KNN_TILE_WAVES_PER_SIMD 2
 #endif
+#ifndef KNN_RANK_BATCH
+#define KNN_RANK_BATCH 1  // 0: the rank loop of round 3 (A/B builds)
+#endif
 constexpr int kTileMaxCand = KNN_TILE_CAND;  // candidates per tile segment (list positions; at most 2^kOrdBits)
 constexpr uint32_t kOrdMask = (1u << kOrdBits) - 1u;
 constexpr int kTileMaxLoad = 8192;           // points in the covering cells per round (loads only)
@@ -515,7 +539,7 @@ constexpr int kNSub = kWave / kSubQ;
 // loads in flight) — walking set bits costs ~10 more VALU instructions per candidate than reading a 16-bit list entry, and the
 // rank loop is VALU-bound, so the extra wave does not pay for it.
 constexpr int kSubCap = KNN_SUB_CAP;
-constexpr int kSubRow = kSubCap + 4;         // row pitch: the 4-way unrolled rank loop may read (and ignore) up to 3 entries past the end
+constexpr int kSubRow = kSubCap + 16;        // row pitch: the software-pipelined rank loop reads (and ignores) up to 15 entries past the end
 
 // min / max over the aligned group of kSubQ lanes a lane belongs to (same value in all lanes of the group)
 __device__ __forceinline__ float group_min(float v) {
@@ -797,19 +821,48 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           if constexpr (STATS) st_rank += trip;
           const uint16_t* mine = sub[mysub] + from;
           const int cnt = to - from;
+          // Eight candidates per step: their eight LDS reads go out together, with the list entries of the NEXT step behind them, and
+          // only then do the 8 x 31 VALU instructions of the step run - one exposed LDS latency per eight candidates.  (Left to
+          // itself the compiler issued every LDS read right in front of its use and waited: five exposed latencies per FOUR
+          // candidates, about as long as the arithmetic - round 3's phase clocks had the ranking at twice its instruction count.)  Rows are padded: reading up to 15 entries past `to` stays inside the
+          // array (of the row of a sub-tile that has entries left); what is found there is ignored.
+#if KNN_RANK_BATCH
+          auto entries8 = [&](int t, uint32_t* o) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) o[u] = (uint32_t)mine[t + u];
+          };
+          uint32_t o_nx[8];
+          entries8(0, o_nx);
+          for (int t = 0; t < trip; t += 8) {
+            uint32_t o[8];
+            float4 pp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) o[u] = o_nx[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) pp[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + o[u]);
+            entries8(t + 8, o_nx);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, pp[u].x, pp[u].y, pp[u].z));
+              const uint32_t key = (t + u < cnt) ? ((d & ~kOrdMask) | (o[u] >> 4)) : SmallestKeys<K + 2>::kEmpty;
+#ifdef KNN_ABL_NO_RANK
+              keys.v[u & 1] = min(keys.v[u & 1], key);
+#else
+              keys.insert(key);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else  // (A/B aid: the loop of round 3)
 #pragma unroll 4
           for (int t = 0; t < trip; t++) {
-            // rows are padded: reading past `to` stays inside the array; what is found there is an offset this wave stored earlier
-            // or the zero the rows start with, i.e. always inside cand[]
             const uint32_t off = (uint32_t)mine[t];
             const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cand) + off);
             const uint32_t d = __float_as_uint(dist2f(q.x, q.y, q.z, p.x, p.y, p.z));
-#ifdef KNN_ABL_NO_RANK
-            keys.v[t & 1] = min(keys.v[t & 1], (t < cnt) ? ((d & ~kOrdMask) | (off >> 4)) : SmallestKeys<K + 2>::kEmpty);
-#else
             keys.insert((t < cnt) ? ((d & ~kOrdMask) | (off >> 4)) : SmallestKeys<K + 2>::kEmpty);
-#endif
           }
+#endif
         }
         phase(4);
         // ---- which lanes are done?  every point within rsafe of a query of the sub-tile has been seen by its lanes
@@ -1185,8 +1238,7 @@ void build_tile_order(hipStream_t s, Workspace& ws, CloudSet& set, bool single_c
   MI_LAUNCH_CHECK();
   // the sorted values ARE the order: the set takes the buffer, the workspace gets the set's old one (no copy pass; everything
   // that reads either is ordered behind this call on the stream)
-  std::swap(set.tile_order.p, ws.vals_a.p);
-  std::swap(set.tile_order.n, ws.vals_a.n);
+  set.tile_order.swap(ws.vals_a);
   set.has_order = true;
 }
 
@@ -1556,6 +1608,11 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
 // tiles staged through LDS behind a block barrier 5.7 ms; head threads walking their runs from memory, four gathers in flight,
 // 2.6 ms (a run is ~4 points on average, up to ~100 next to the sensor; 3 lanes of 4 idle); now one gather per lane and the run
 // handed to its head by lane shuffles.
+// Round 4: a wave takes kVcGroups x 64 consecutive sorted elements, not 64.  With one element per lane a wave lived ~11 us - a chain of
+// four dependent memory operations (meta, keys / indices, the gather, the output position) around ~500 instructions - and 8 192
+// resident waves of that shape moved 4.3 GB in 3.9 ms (PMC: 73 % of the wave cycles waiting).  Now the loads of all groups are
+// issued together (four gathers per lane in flight), then every group is folded and written as before.
+constexpr int kVcGroups = 4;
 __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                          const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
                                                          const int* __restrict__ local,
@@ -1566,67 +1623,89 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = vmeta[c];
-  const int i = bx * blockDim.x + threadIdx.x;
-  if (i == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
-  if (bx * (int)blockDim.x >= m.n) return;  // whole block past the end of the cloud
+  const int lane = lane_id();
+  const int i0 = bx * (kWave * kVcGroups) + lane;
+  if (i0 == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
+  if (bx * (kWave * kVcGroups) >= m.n) return;  // whole block past the end of the cloud
   const size_t o = (size_t)c * cap;
-  const bool valid = i < m.n;
-  const bool head = valid && voxel_head(m, keys + o, in + o, i, i > 0 ? keys[o + i - 1] : kEmptyKey, min_distance) != 0;
   // next_meta: the voxel hash that indexes this filter's output next (voxel_grid's `index_next`) - the output point's cell key is
   // written while the point is in a register, so build_grid needs neither a bounds pass nor a key pass over the output
+  GridMeta nm;
+  if (next_meta) nm = next_meta[c];
   auto emit = [&](int pos, const float4& pt) {
     out[o + pos] = pt;
     if (next_meta) {
-      next_keys[o + pos] = cell_key(next_meta[c], pt.x, pt.y, pt.z);
+      next_keys[o + pos] = cell_key(nm, pt.x, pt.y, pt.z);
       next_vals[o + pos] = pos;
     }
   };
   if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (what the fused distance filter keeps)
-    if (head) emit(local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile], in[o + i]);
+#pragma unroll
+    for (int g = 0; g < kVcGroups; g++) {
+      const int i = i0 + g * kWave;
+      if (i < m.n && voxel_head(m, keys + o, in + o, i, kEmptyKey, min_distance)) emit(local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile], in[o + i]);
+    }
     return;
   }
-  // EVERY lane fetches the point at its sorted position (one gather per lane, all in flight together); a head then adds the
-  // points of the lanes behind it in ascending order, passed along by lane shuffles.  The loop runs as long as any head of the
-  // wave still has run left inside the wave (a run is ~4 points); a run that leaves the wave is finished from memory.
-  const int lane = lane_id();
-  const uint32_t k = valid ? keys[o + i] : 0xFFFFFFFEu;  // (no voxel index is that large: the overflow test bounds it by INT_MAX)
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) a = in[o + vals[o + i]];
-  const float4 mine = a;
-  int cnt = 1;
-  bool open = head;  // still collecting
-  for (int d = 1; d < kWave; d++) {
-    const uint32_t kk = __shfl_down(k, d, kWave);
-    const float px = __shfl_down(mine.x, d, kWave), py = __shfl_down(mine.y, d, kWave), pz = __shfl_down(mine.z, d, kWave),
-                pw = __shfl_down(mine.w, d, kWave);
-    const bool in_wave = lane + d < kWave;
-    const bool take = open && in_wave && kk == k;
-    if (take) { a.x += px; a.y += py; a.z += pz; a.w += pw; cnt++; }
-    open = take || (open && !in_wave);  // a run that reaches the end of the wave stays open for the memory walk below
-    if (!__any(open && in_wave)) break;
+  // EVERY lane fetches the points at its sorted positions (one gather per lane and group, all in flight together); a head then adds
+  // the points of the lanes behind it in ascending order, passed along by lane shuffles.  The loop runs as long as any head of the
+  // group still has run left inside the group (a run is ~4 points); a run that leaves the group is finished from memory.
+  uint32_t kk_[kVcGroups], kprev_[kVcGroups];
+  float4 a_[kVcGroups];
+  int pos_[kVcGroups];
+  bool valid_[kVcGroups];
+#pragma unroll
+  for (int g = 0; g < kVcGroups; g++) {
+    const int i = i0 + g * kWave;
+    valid_[g] = i < m.n;
+    kk_[g] = valid_[g] ? keys[o + i] : 0xFFFFFFFEu;  // (no voxel index is that large: the overflow test bounds it by INT_MAX)
+    kprev_[g] = (valid_[g] && i > 0) ? keys[o + i - 1] : kEmptyKey;
+    a_[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid_[g]) a_[g] = in[o + vals[o + i]];
+    pos_[g] = valid_[g] ? local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile] : 0;
   }
-  if (!head) return;
-  if (open) {  // the run continues past this wave's 64 points
-    for (int j = i + (kWave - lane); j < m.n; j += 4) {
-      uint32_t kk[4];
-      float4 p[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int jj = min(j + u, m.n - 1);
-        kk[u] = (j + u < m.n) ? keys[o + jj] : ~k;
-        p[u] = in[o + vals[o + jj]];
-      }
-      bool more = true;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        more = more && (kk[u] == k);
-        if (more) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; cnt++; }
-      }
-      if (!more) break;
+  for (int g = 0; g < kVcGroups; g++) {
+    const int i = i0 + g * kWave;
+    const uint32_t k = kk_[g];
+    const bool head = valid_[g] && k != kEmptyKey && (i == 0 || k != kprev_[g]);
+    float4 a = a_[g];
+    const float4 mine = a;
+    int cnt = 1;
+    bool open = head;  // still collecting
+    for (int d = 1; d < kWave; d++) {
+      const uint32_t kk = __shfl_down(k, d, kWave);
+      const float px = __shfl_down(mine.x, d, kWave), py = __shfl_down(mine.y, d, kWave), pz = __shfl_down(mine.z, d, kWave),
+                  pw = __shfl_down(mine.w, d, kWave);
+      const bool in_wave = lane + d < kWave;
+      const bool take = open && in_wave && kk == k;
+      if (take) { a.x += px; a.y += py; a.z += pz; a.w += pw; cnt++; }
+      open = take || (open && !in_wave);  // a run that reaches the end of the group stays open for the memory walk below
+      if (!__any(open && in_wave)) break;
     }
+    if (!head) continue;
+    if (open) {  // the run continues past this group's 64 points
+      for (int j = i + (kWave - lane); j < m.n; j += 4) {
+        uint32_t kq[4];
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int jj = min(j + u, m.n - 1);
+          kq[u] = (j + u < m.n) ? keys[o + jj] : ~k;
+          p[u] = in[o + vals[o + jj]];
+        }
+        bool more = true;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          more = more && (kq[u] == k);
+          if (more) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; cnt++; }
+        }
+        if (!more) break;
+      }
+    }
+    const float fc = (float)cnt;
+    emit(pos_[g], make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc));
   }
-  const float fc = (float)cnt;
-  emit(local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile], make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc));
 }
 
 void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_in, float4* out, int* cnt_out, int B, size_t cap, float leaf,
@@ -1648,7 +1727,7 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
     if (index_next->B != B || index_next->cap != cap) throw ArgError(MI355_EINVAL, "voxel_grid: index_next has another shape");
     hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, ws.totals.p, index_next->meta.p, B, index_cell, ws.sort_passes.p);
   }
-  const int Gv = div_up((long)cap, kPointBlock);
+  const int Gv = div_up((long)cap, kPointBlock * kVcGroups);
   TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
   hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kPointBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.scan_local.p,
                      ws.scan_block.p, ws.totals.p, out, cnt_out, cap, nblk, Gv, B, min_distance,

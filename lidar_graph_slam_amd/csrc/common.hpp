@@ -35,22 +35,37 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owner = true;  // false: a window into another buffer's memory (alias): never freed, never grown
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owner) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owner = true;
   }
   // grow-only; contents are NOT preserved
   void ensure(size_t need) {
     if (need <= n) return;
+    if (!owner) throw std::logic_error("DevBuf::ensure: an alias cannot grow");
     release();
     size_t cap = need + need / 8 + 64;
     MI_HIP(hipMalloc((void**)&p, cap * sizeof(T)));
     n = cap;
+  }
+  // a window [q, q + m) into memory another DevBuf owns (the parts of a batch: one cloud-major array, one window per part)
+  void alias(T* q, size_t m) {
+    release();
+    p = q;
+    n = m;
+    owner = false;
+  }
+  void swap(DevBuf& o) {
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+    std::swap(owner, o.owner);
   }
 };
 
@@ -87,6 +102,7 @@ struct Tuning {
   float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
   float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for, when the tiles follow build_tile_order (along the Morton order a wider gather was measured slower: 1.0)
   int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream
+  int batch_parts = 0;        // MI355_BATCH_PARTS       parts a FAST_GICP batch is cut into (the pipeline of api.hip); 0 = by its size: 4 from 1 024 pairs, 2 from 512, else 1
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
   int corr_tiles = 4;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)

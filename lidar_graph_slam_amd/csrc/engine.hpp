@@ -127,6 +127,9 @@ void cov_from_caller_order(hipStream_t s, CloudSet& set, size_t n, const Cov6* i
 struct GicpPairState;  // device-side LM state, one per source cloud
 struct GicpBatch {
   int S = 0;           // sources (= pairs)
+  int S_geometry = 0;  // the pair count the launch geometry (blocks per pair, search kernels) was chosen for: the WHOLE batch's when this
+                       // object serves one part of a batch, so that a pair's blocks, and with them the order of its fp64 partial sums, do
+                       // not depend on how the batch is cut into parts (results bit-equal whatever the number of parts)
   size_t cap = 0;
   int blocks_per_pair = 0;   // k_gicp_correspond geometry
   int blocks_tile = 1;  // blocks per pair of k_gicp_correspond_tile
@@ -138,8 +141,15 @@ struct GicpBatch {
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;
   DevBuf<unsigned char> trials;  // [S][16] LmTrial (gicp.hip)
+  static constexpr int kPolls = 2;  // "any pair still active?" polls in flight (gicp_poll_active / gicp_poll_query)
   DevBuf<int> n_active;
   PinnedBuf<int> h_active;
+  hipEvent_t poll_ev[kPolls] = {nullptr, nullptr};
+  int polls_issued = 0, polls_seen = 0;
+  ~GicpBatch() {
+    for (auto& e : poll_ev)
+      if (e) (void)hipEventDestroy(e);
+  }
   DevBuf<double> fit_partials;
   DevBuf<double> fitness;    // [S][2] (sum, count)
   DevBuf<float> guesses, fit_T;        // device staging that must outlive the enqueued kernels
@@ -148,13 +158,21 @@ struct GicpBatch {
   int ppt = 1;              // points per thread and pass in k_gicp_correspond (Tuning::corr_ppt)
   DevBuf<unsigned long long> corr_stats;  // Tuning::corr_stats: counters of k_gicp_correspond_tile (tuning aid), else unallocated
 };
-void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units);
+// S_geometry: see GicpBatch (0 = S)
+void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units, int S_geometry = 0);
 void gicp_alloc_fitness_only(GicpBatch& gb, int S, size_t cap);  // for gicp_fitness with host poses only
 void gicp_set_map(hipStream_t s, GicpBatch& gb, const int* tgt_of_src_host, int n_targets);
 void gicp_fitness_values(hipStream_t s, GicpBatch& gb, double* fitness_out);
-// Enqueue the full LM optimisation of every pair.  guesses_host: S x 16 floats or nullptr.
+// The full LM optimisation of every pair.  guesses_host: S x 16 floats or nullptr.  With force_iterations everything is enqueued and
+// the call returns; otherwise it returns once every pair has converged (iterations are enqueued in groups, the device is polled
+// without ever leaving the GPU idle).  gicp.hip describes the pieces a caller with several batches in flight interleaves itself.
 void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
                 const float* guesses_host);
+void gicp_align_begin(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
+                      const float* guesses_host);
+void gicp_align_iterate(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, int it0, int it1);
+void gicp_poll_active(hipStream_t s, GicpBatch& gb);
+bool gicp_poll_query(GicpBatch& gb, bool wait, int* n_active);
 void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb);  // Tuning::corr_stats only
 // parity probe: incremental correspondences at the final pose vs a from-scratch search (batches of >= 8 pairs: k_gicp_correspond)
 void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, long long* n_checked,

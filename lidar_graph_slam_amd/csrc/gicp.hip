@@ -53,11 +53,14 @@ constexpr int kTrialSlot = 32;
 constexpr int kGicpBlock = 256;
 constexpr int kMaxTrials = 16;  // lm_max_iterations is capped here (fast_gicp default 10)
 
-void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
+void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_geometry) {
   const Tuning& tn = tuning();
   gb.ppt = tn.corr_ppt == 1 ? 1 : 4;
-  gb.S = S;
+  gb.S = S_own;
+  gb.S_geometry = S_geometry > 0 ? S_geometry : S_own;
   gb.cap = cap;
+  const int Sg = gb.S_geometry;  // the launch geometry below is that of the whole batch this object is (a part of)
+  const int S = S_own;
   // One pair is worked on by 2 - 64 blocks of 256 threads that all land on one XCD (primitives.hpp).  In steady state a block's life is a chain of dependent loads (pair state, points, stored queries) around very little
   // work, so a big batch wants fewer blocks that each walk several tiles — measured at 1 024 pairs: 64 blocks per pair 74.5 ms per
   // step (k_gicp_correspond 12.9, the tile kernel 8.2), 16: 72.1 ms (12.2 / 7.4), 8: 72.4, 4: 73.5; at 128 pairs 64 is best
@@ -66,18 +69,18 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   // 59.6 ms per step, 2 048 pairs 16 / 8 / 4 / 2: 114.1 / 112.8 / 112.0 / 112.0 ms, 4 096 pairs 16 / 4 / 2: 222.4 / 215.2 / 214.8 ms
   // (benchmarks/bpp_sweep.sh).
   (void)compute_units;
-  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(2, std::min(64, 8192 / std::max(S, 1)));
+  int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(2, std::min(64, 8192 / std::max(Sg, 1)));
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
   gb.blocks_per_pair = G;
   // (the tile search likes twice as many: 2 048 pairs 4 / 8 / 16 blocks per pair 16.0 / 15.7 / 15.9 ms per step, 4 096 pairs 2 / 6: 30.8 / 30.2)
-  gb.blocks_tile = tn.blocks_per_pair > 0 ? G : std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cap, kGicpBlock)));
+  gb.blocks_tile = tn.blocks_per_pair > 0 ? G : std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(Sg, 1))), div_up((long)cap, kGicpBlock)));
   // the streaming kernels (linearize, error, fitness) want fewer, fatter blocks: 4 points per thread, fewer partials
   // few, long-lived blocks: each block streams several tiles (software-pipelined) and pays ONE 29-value fp64 reduction;
   // about 512 blocks over the batch for a few pairs; big batches 6 per pair (3 from 4 096 pairs on), never more than the tiles a cloud
   // can have.  (6 / 3 rather than the 4 of round 2: k_gicp_linearize holds 3 blocks per CU, 768 over the chip, and a launch of
   // pairs x 4 blocks ends in a part-filled last round - measured at 512 / 1 024 / 2 048 / 4 096 pairs, 4 against the value chosen:
   // 33.2 / 32.7, 59.2 / 58.8, 111.2 / 110.5, 214.6 / 212.7 ms per step, benchmarks/geometry_sweep.sh)
-  const int per_pair = std::max(S <= 2048 ? 6 : 3, std::min(32, 512 / std::max(S, 1)));
+  const int per_pair = std::max(Sg <= 2048 ? 6 : 3, std::min(32, 512 / std::max(Sg, 1)));
   gb.blocks_lin = std::max(1, std::min(per_pair, div_up((long)cap, kGicpBlock * 2)));
   if (tn.blocks_lin > 0) gb.blocks_lin = tn.blocks_lin;
   gb.tgt_of_src.ensure(S);
@@ -87,8 +90,8 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
   gb.trials.ensure((size_t)S * kMaxTrials * sizeof(LmTrial));
-  gb.n_active.ensure(1);
-  gb.h_active.ensure(1);
+  gb.n_active.ensure(GicpBatch::kPolls);
+  gb.h_active.ensure(GicpBatch::kPolls);
   gb.fit_partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * 2);
   gb.fitness.ensure((size_t)S * 2);
   if (tn.corr_stats) {
@@ -100,6 +103,7 @@ void gicp_alloc(GicpBatch& gb, int S, size_t cap, int compute_units) {
 // What gicp_fitness alone needs (a batch that registers with another method still scores its pairs with it).
 void gicp_alloc_fitness_only(GicpBatch& gb, int S, size_t cap) {
   gb.S = S;
+  gb.S_geometry = S;
   gb.cap = cap;
   gb.blocks_per_pair = 1;
   gb.blocks_lin = std::max(1, std::min(std::max(4, std::min(32, 512 / std::max(S, 1))), div_up((long)cap, kGicpBlock * 2)));
@@ -1405,8 +1409,8 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     const Tuning& tn = tuning();
     // a handful of pairs cannot fill the chip with tiles (their few hundred waves would each wait out their own gathers, and a
     // lone pair is usually a scan against a dense multi-key-frame sub-map): they get a group of lanes per query instead
-    const bool tiles = search >= 0 ? search == 1 : (iteration < tn.corr_tiles && gb.S >= 8);
-    const bool groups = search >= 0 ? search == 2 : (gb.S < 8 && tn.corr_groups != 0);
+    const bool tiles = search >= 0 ? search == 1 : (iteration < tn.corr_tiles && gb.S_geometry >= 8);
+    const bool groups = search >= 0 ? search == 2 : (gb.S_geometry < 8 && tn.corr_groups != 0);
     if (tiles) {
       TimedLaunch tl(KF_CORRESPOND_TILE, s);
       hipLaunchKernelGGL(k_gicp_correspond_tile, dim3(xcd_grid(gb.blocks_tile, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap,
@@ -1432,8 +1436,16 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
                      tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.blocks_lin, gb.S);
 }
 
-void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
-                const float* guesses_host) {
+// ---- the LM optimisation of every pair of a batch, in three pieces a caller can interleave with those of other batches --------
+// gicp_align_begin    pair -> target map, guesses, initial state (enqueue only)
+// gicp_align_iterate  iterations [it0, it1): correspond -> linearize -> solve -> error -> decide (enqueue only; a pair that has
+//                     converged leaves every kernel at once, so iterations enqueued past convergence cost launches, not work)
+// gicp_poll_active    "is any pair still optimising?": the count goes to a pinned host slot behind an event that
+//                     gicp_poll_query tests WITHOUT blocking (round 3 synchronised the stream every four iterations: the one host
+//                     round trip of the loop, and with several parts / batches in flight it stalled the thread that should have
+//                     been enqueueing the others)
+void gicp_align_begin(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
+                      const float* guesses_host) {
   if (!src.has_cov || !tgt.has_cov) throw ArgError(MI355_ESTATE, "covariances missing");
   const int S = gb.S;
   gb.h_map.resize(S);
@@ -1452,10 +1464,16 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
   // no previous correspondences yet, NaN margins: the first pass searches every point
   hipLaunchKernelGGL(k_gicp_reset_search, dim3(std::max(1, std::min(64, div_up((long)src.cap, 1024))), S), dim3(256), 0, s, (const int*)src.count.p, gb.corr.p,
                      gb.qsearch.p, src.cap);
+  (void)dev_params(p);  // (argument check before anything else is enqueued)
+  gb.polls_issued = gb.polls_seen = 0;
+  MI_LAUNCH_CHECK();
+}
+
+void gicp_align_iterate(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, int it0, int it1) {
+  const int S = gb.S;
   const GicpDevParams P = dev_params(p);
   const int G = gb.blocks_lin;
-  const int check_every = p.force_iterations ? 0 : 4;
-  for (int it = 0; it < p.max_iterations; it++) {
+  for (int it = it0; it < it1; it++) {
     launch_linearize(s, gb, src, tgt, P, it);
     {
       TimedLaunch tl(KF_SOLVE_DECIDE, s);
@@ -1479,7 +1497,7 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
       const int n_lm = P.lm_max_iterations;
       int first = tuning().err_first < 0 ? (P.force_iterations ? 0 : 1) : tuning().err_first;
       first = std::min(first, 4);
-      if (S >= 8 && first >= 1 && first < n_lm) {
+      if (gb.S_geometry >= 8 && first >= 1 && first < n_lm) {
         if (first == 1) error(k_gicp_error<1>, 0, 1, 1);
         else error(k_gicp_error<4>, 0, first, 1);
         decide(0, first);
@@ -1490,15 +1508,62 @@ void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSe
         decide(2, first);
       }
     }
-    if (check_every && ((it + 1) % check_every == 0) && it + 1 < p.max_iterations) {
-      // early stop: every few iterations ask the device whether any pair is still optimising
-      hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, gb.state.p, S, gb.n_active.p);
-      MI_HIP(hipMemcpyAsync(gb.h_active.p, gb.n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
-      if (gb.h_active.p[0] == 0) break;
-    }
   }
   MI_LAUNCH_CHECK();
+}
+
+void gicp_poll_active(hipStream_t s, GicpBatch& gb) {
+  const int slot = gb.polls_issued % GicpBatch::kPolls;
+  if (gb.polls_issued - gb.polls_seen >= GicpBatch::kPolls) throw std::logic_error("gicp_poll_active: every poll slot is in flight");
+  gb.n_active.ensure(GicpBatch::kPolls);
+  gb.h_active.ensure(GicpBatch::kPolls);
+  if (!gb.poll_ev[slot]) MI_HIP(hipEventCreateWithFlags(&gb.poll_ev[slot], hipEventDisableTiming));
+  hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, gb.state.p, gb.S, gb.n_active.p + slot);
+  MI_HIP(hipMemcpyAsync(gb.h_active.p + slot, gb.n_active.p + slot, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipEventRecord(gb.poll_ev[slot], s));
+  gb.polls_issued++;
+}
+
+// The oldest poll in flight: has its answer arrived (wait = true: block until it has)?  *n_active then holds it and the slot is free.
+bool gicp_poll_query(GicpBatch& gb, bool wait, int* n_active) {
+  if (gb.polls_seen >= gb.polls_issued) return false;
+  const int slot = gb.polls_seen % GicpBatch::kPolls;
+  if (wait) {
+    MI_HIP(hipEventSynchronize(gb.poll_ev[slot]));
+  } else {
+    const hipError_t e = hipEventQuery(gb.poll_ev[slot]);
+    if (e == hipErrorNotReady) return false;
+    MI_HIP(e);
+  }
+  *n_active = gb.h_active.p[slot];
+  gb.polls_seen++;
+  return true;
+}
+
+// One batch by itself (the registration object, a batch of one part): iterations are enqueued four at a time, each group followed
+// by a poll; the host looks at a poll's answer only after the NEXT group is in the queue, so the GPU never waits for the host - at
+// most one group of (empty) iterations runs past convergence.
+void gicp_align(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const int* tgt_of_src_host,
+                const float* guesses_host) {
+  gicp_align_begin(s, gb, src, tgt, p, tgt_of_src_host, guesses_host);
+  if (p.force_iterations) {
+    gicp_align_iterate(s, gb, src, tgt, p, 0, p.max_iterations);
+    return;
+  }
+  constexpr int kGroup = 4;
+  bool done = false;
+  for (int it = 0; it < p.max_iterations && !done; it += kGroup) {
+    const int it1 = std::min(it + kGroup, p.max_iterations);
+    gicp_align_iterate(s, gb, src, tgt, p, it, it1);
+    if (it1 >= p.max_iterations) break;
+    gicp_poll_active(s, gb);
+    int n_active = 1;
+    // the poll behind the PREVIOUS group (blocking: its group has certainly been overtaken by the one just enqueued)
+    while (gb.polls_issued - gb.polls_seen > 1)
+      if (gicp_poll_query(gb, true, &n_active) && n_active == 0) done = true;
+  }
+  int n_active;
+  while (gicp_poll_query(gb, true, &n_active)) {}  // leave no poll in flight (the slots are reused by the next alignment)
 }
 
 // ---- exactness probe of the incremental correspondence search (parity tests) -------------------------------------------------

@@ -353,6 +353,12 @@ class BatchRegistration:
         hs = (C.c_void_p * self.n_sources)(*[c.handle for c in clouds])
         self.ctx.check(self.ctx._lib.mi355_batch_set_sources_clouds(self.handle, hs, C.byref(prefilter) if prefilter else None))
 
+    def set_live(self, n_sources: int, n_targets: int):
+        """Use only the first n_sources / n_targets slots until the next call (mi355_batch_set_live): a batch object kept for
+        requests of varying size.  Invalidates the sources, targets and results set before."""
+        self.ctx.check(self.ctx._lib.mi355_batch_set_live(self.handle, int(n_sources), int(n_targets)))
+        self.n_sources, self.n_targets = int(n_sources), int(n_targets)
+
     def set_stream(self, hip_stream: int | None):
         """Run this batch on its own HIP stream (None: back to the context's); batches on different streams overlap."""
         if hip_stream is None:
