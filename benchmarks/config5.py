@@ -24,6 +24,73 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def multi_lanes(args):
+    """The whole candidate list through mi355_multi_batch_register from ONE process: the C++ back end's form."""
+    import multiprocessing as mp
+
+    from lidar_graph_slam_amd import synth
+
+    n, S, casts = args.candidates, args.submaps, args.casts_per_submap
+    length = 20.0 * S + 20.0
+    sub_pose = lambda s: synth.se3(20.0 * s, 0.0, 0.0)  # noqa: E731
+    true_off = [synth.random_perturbation(np.random.default_rng(1000 + s * 64 + c), 1.0, 2.0) for s in range(S) for c in range(casts)]
+    rng = np.random.default_rng(5)
+    wrong = [synth.random_perturbation(rng, 1.5, 4.0) for _ in range(n)]
+    tgt_of_src = np.arange(n) % S
+    cast_of = (np.arange(n) // S) % casts
+    jobs = [(length, sub_pose(s) @ true_off[s * casts + c], 9000 + s * 64 + c, args.n_azimuth, 30.0) for s in range(S) for c in range(casts)]
+    jobs += [(length, sub_pose(s) @ synth.se3(1.0 * j, 0.0, 0.0), 500 + 10 * s + j, args.n_azimuth, 30.0) for s in range(S) for j in range(-2, 3)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(max(1, min(64, (os.cpu_count() or 8) - 2))) as pool:
+        raw = pool.map(synth.cast_job, jobs, chunksize=4)
+    t_cast = time.perf_counter() - t0
+
+    import torch  # noqa: F401  (torch's ROCm runtime before the library's: INTEGRATION.md)
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    from lidar_graph_slam_amd import loop_batch
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+    from lidar_graph_slam_amd.multi import MultiDevice
+
+    def place(c, T):
+        o = c.copy()
+        o[:, :3] = (c[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        return o
+
+    pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
+    scans = [pre.callback_sensor_points(r) for r in raw]
+    submaps = [np.concatenate([place(scans[S * casts + 5 * s + (j + 2)], sub_pose(s) @ synth.se3(1.0 * j, 0.0, 0.0)) for j in range(-2, 3)], axis=0)
+               for s in range(S)]
+    true_pose = lambda p: sub_pose(int(tgt_of_src[p])) @ true_off[int(tgt_of_src[p]) * casts + int(cast_of[p])]  # noqa: E731
+    graph_pose = lambda p: true_pose(p) @ wrong[p]  # noqa: E731
+    sources = [place(scans[int(tgt_of_src[p]) * casts + int(cast_of[p])], graph_pose(p)) for p in range(n)]
+    md = MultiDevice([0] * args.multi_lanes)
+    pf = loop_batch.voxel_prefilter(0.5)
+    times = []
+    for _ in range(4):  # the first call allocates every lane's batch object
+        t0 = time.perf_counter()
+        res, fit, lane = md.batch_register(sources, submaps, tgt_of_src, target_prefilter=pf, with_fitness=True, raw=True, max_iterations=args.max_iterations)
+        times.append(time.perf_counter() - t0)
+    md.close()
+    errs = np.array([synth.pose_error(res["T"][p], true_pose(p) @ np.linalg.inv(graph_pose(p))) for p in range(n)])
+    accepted = (np.asarray(res["converged"]) != 0) & (fit < 0.3)  # graph_based_slam.cpp:321-328
+    good = (errs[:, 0] < 0.05) & (errs[:, 1] < 5e-3)
+    t_best = min(times[1:])
+    line = {
+        "config": "BASELINE configs[4] on ONE MI355X: loop-closure batch through mi355_multi_batch_register (host views in, results out; one process, lanes on device 0)",
+        "lanes": args.multi_lanes, "candidates": n, "submaps": S, "method": "FAST_GICP",
+        "pairs_per_s_including_uploads": round(n / t_best, 1), "seconds_per_call": [round(t, 4) for t in times],
+        "bytes_uploaded_per_call": int(sum(c.nbytes for c in sources) + sum(c.nbytes for c in submaps)),
+        "points_per_candidate_mean": float(np.mean([len(c) for c in sources])), "points_per_submap_mean": float(np.mean([len(c) for c in submaps])),
+        "accepted(fitness<0.3)": int(accepted.sum()), "within_5cm_of_truth": int(good.sum()), "median_pose_err_m": round(float(np.median(errs[:, 0])), 4),
+        "mean_iterations": round(float(np.asarray(res["iterations"]).mean()), 2), "seconds_ray_casting_on_host": round(t_cast, 1),
+    }
+    print(json.dumps(line))
+    if good.sum() < args.min_good * n:
+        raise SystemExit("config5: results wrong")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,7 +102,11 @@ def main():
     ap.add_argument("--max-iterations", type=int, default=64)
     ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "NDT_OMP"], help="registration engine of the batch (graph_based_slam.cpp:80-119)")
     ap.add_argument("--min-good", type=float, default=0.9, help="fail unless this fraction of the pairs lands within 5 cm / 5 mrad of the truth")
+    ap.add_argument("--multi-lanes", type=int, default=0, help="ONE process, this many lanes on device 0 through mi355_multi_batch_register (host views in, "
+                    "results out: uploads included in the rate) instead of one rank per GPU")
     args = ap.parse_args()
+    if args.multi_lanes > 0:
+        return multi_lanes(args)
 
     import torch
     import torch.distributed as dist

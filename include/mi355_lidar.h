@@ -279,6 +279,11 @@ int mi355_batch_set_sources_dev(mi355_batch* b, const void* d_points, const int*
 /* Host-pointer variants (PCIe copy included). */
 int mi355_batch_set_targets(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* prefilter);
 int mi355_batch_set_sources(mi355_batch* b, const float* points, const int* counts, const mi355_prefilter_params* prefilter);
+/* Host clouds as views, one per slot (any stride / intensity offset; at most `capacity` points each): packed through pinned
+ * staging and sent a run of slots per copy, the packing of the next run overlapping the transfer of the last.  The caller's buffers
+ * are free when the call returns. */
+int mi355_batch_set_targets_views(mi355_batch* b, const mi355_cloud_view* views, const mi355_prefilter_params* prefilter);
+int mi355_batch_set_sources_views(mi355_batch* b, const mi355_cloud_view* views, const mi355_prefilter_params* prefilter);
 /* The same from device clouds (one per slot, at most `capacity` points each): copied slot by slot on the device. */
 int mi355_batch_set_targets_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* prefilter);
 int mi355_batch_set_sources_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* prefilter);
@@ -358,6 +363,13 @@ int mi355_multi_batch_register(mi355_multi* m, int method, const void* params, c
                                const mi355_cloud_view* targets, int n_targets, const int* tgt_of_src, const float* guesses16,
                                const mi355_prefilter_params* source_prefilter, const mi355_prefilter_params* target_prefilter, int with_fitness,
                                mi355_result* results, double* fitness, int* lane_of_pair);
+/* The same for clouds that already live on the devices (mi355_cloud_* on mi355_multi_context(m, lane)): source p and the sub-map it
+ * registers against must belong to the lane mi355_multi_shard_by_target deals pair p to (MI355_EINVAL otherwise) - a caller that
+ * keeps its key frames device-resident per lane, as LoopClosureCore does, uploads nothing here. */
+int mi355_multi_batch_register_clouds(mi355_multi* m, int method, const void* params, mi355_cloud* const* sources, int n_sources,
+                                      mi355_cloud* const* targets, int n_targets, const int* tgt_of_src, const float* guesses16,
+                                      const mi355_prefilter_params* source_prefilter, const mi355_prefilter_params* target_prefilter,
+                                      int with_fitness, mi355_result* results, double* fitness, int* lane_of_pair);
 
 #ifdef __cplusplus
 }

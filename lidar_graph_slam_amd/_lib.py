@@ -128,12 +128,12 @@ EXPORTS = [
     "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
     "mi355_cloud_upload", "mi355_cloud_destroy", "mi355_cloud_size", "mi355_cloud_has_covariances", "mi355_cloud_download", "mi355_cloud_transform",
     "mi355_cloud_concat", "mi355_cloud_compute_covariances", "mi355_cloud_prefilter", "mi355_reg_set_source_cloud", "mi355_reg_set_target_cloud",
-    "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds",
+    "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds", "mi355_batch_set_targets_views", "mi355_batch_set_sources_views",
     "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
     "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams", "mi355_batch_set_live", "mi355_batch_verify_correspondences", "mi355_batch_diagnostics",
     "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_last_error", "mi355_multi_device_count", "mi355_multi_context",
-    "mi355_multi_shard_by_target", "mi355_multi_batch_register", "mi355_multi_lane_allocations",
+    "mi355_multi_shard_by_target", "mi355_multi_batch_register", "mi355_multi_batch_register_clouds", "mi355_multi_lane_allocations",
 ]
 # include/mi355_scan_matcher.h
 EXPORTS_SCAN_MATCHER = [
@@ -279,6 +279,8 @@ def lib():
         L.mi355_reg_set_target_cloud.argtypes = [C.c_void_p, C.c_void_p]
         L.mi355_batch_set_targets_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
         L.mi355_batch_set_sources_clouds.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
+        L.mi355_batch_set_targets_views.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
+        L.mi355_batch_set_sources_views.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PrefilterParams)]
         L.mi355_cloud_from_pointcloud2.restype = C.c_void_p
         L.mi355_cloud_from_pointcloud2.argtypes = [C.c_void_p, C.POINTER(PointCloud2)]
         L.mi355_cloud_to_pointcloud2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -318,6 +320,8 @@ def lib():
         L.mi355_multi_shard_by_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mi355_multi_batch_register.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.POINTER(PrefilterParams), C.POINTER(PrefilterParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_multi_batch_register_clouds.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                        C.POINTER(PrefilterParams), C.POINTER(PrefilterParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mi355_loop_closure_destroy.argtypes = [C.c_void_p]
         L.mi355_loop_closure_destroy.restype = None
         L.mi355_loop_closure_last_error.restype = C.c_char_p

@@ -44,7 +44,8 @@ class Context:
 
     def close(self):
         if self.handle:
-            self._lib.mi355_destroy(self.handle)
+            if not getattr(self, "_borrowed", False):  # (a lane's context belongs to its mi355_multi: multi.MultiDevice.lane_context)
+                self._lib.mi355_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

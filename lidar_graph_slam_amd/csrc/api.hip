@@ -24,6 +24,7 @@ const Tuning& tuning() {
     geti("MI355_PPT", v.corr_ppt);
     geti("MI355_CORR_TILES", v.corr_tiles);
     geti("MI355_CORR_STATS", v.corr_stats);
+    geti("MI355_CORR_MASK", v.corr_mask);
     geti("MI355_CORR_GROUPS", v.corr_groups);
     geti("MI355_ERR_FIRST", v.err_first);
     getf("MI355_CORR_R1", v.corr_r1);
@@ -38,6 +39,8 @@ const Tuning& tuning() {
     getf("MI355_TILE_GATHER", v.tile_gather);
     geti("MI355_BATCH_SIDE_STREAMS", v.side_streams);
     geti("MI355_BATCH_PARTS", v.batch_parts);
+    getf("MI355_PREP_CUS", v.prep_cus);
+    getf("MI355_LM_CUS", v.lm_cus);
     getf("MI355_GRID_CELL", v.grid_cell);
     geti("MI355_KNN_STATS", v.knn_stats);
     return v;
@@ -191,6 +194,11 @@ struct mi355_batch {
   int side_streams = -1;  // mi355_batch_set_side_streams: -1 = the library default (Tuning::side_streams), 0 / 1 = off / on
   DevBuf<float4> host_stage_tgt, host_stage_src;  // device copies of host inputs, one per side: a side's next upload is ordered behind the align that joined its last chain
   DevBuf<float4> cloud_stage_src, cloud_stage_tgt;  // mi355_batch_set_*_clouds: the slots assembled on the device
+  // mi355_batch_set_*_views: host clouds of any stride are packed into two pinned buffers that take turns - while one crosses PCIe
+  // (one 2-D copy for a run of slots) the host packs the next run into the other
+  PinnedBuf<float4> pin[2];
+  hipEvent_t pin_free[2] = {nullptr, nullptr};
+  bool pin_used[2] = {false, false};
   hipStream_t own_stream = nullptr;  // mi355_batch_set_stream: this batch's stream instead of the context's
   bool has_own_stream = false;
   hipStream_t stream() const { return has_own_stream ? own_stream : ctx->stream; }
@@ -211,6 +219,8 @@ struct mi355_batch {
   ~mi355_batch() {
     if (ndt) ndt_batch_destroy(ndt);
     parts.clear();
+    for (auto& e : pin_free)
+      if (e) (void)hipEventDestroy(e);
     for (auto& sd : side) {
       if (sd.stream) { (void)hipStreamSynchronize(sd.stream); (void)hipStreamDestroy(sd.stream); }
       if (sd.fork) (void)hipEventDestroy(sd.fork);
@@ -1110,6 +1120,23 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
 // ---- batch ---------------------------------------------------------------------------------------------------------
 using Part = mi355_batch::Part;
 
+// A stream restricted to a share of the compute units (experiment: the latency-bound preparation chains and the bandwidth-bound LM
+// loops of a pipelined batch on disjoint CUs).  The CU mask's bits interleave over the XCDs, so a contiguous run of bits is the same
+// share of every XCD's CUs.  first: the share starts at bit 0, else it ends at the last bit.
+static void create_stream(hipStream_t* s, int priority, float cu_share, bool first, int compute_units) {
+  if (cu_share >= 1.f || cu_share <= 0.f || compute_units <= 0) {
+    MI_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority));
+    return;
+  }
+  const int n = std::max(8, std::min(compute_units, (int)(cu_share * (float)compute_units + 0.5f) / 8 * 8));
+  std::vector<uint32_t> mask((size_t)(compute_units + 31) / 32, 0u);
+  for (int i = 0; i < n; i++) {
+    const int bit = first ? i : compute_units - 1 - i;
+    mask[(size_t)bit / 32] |= 1u << (bit % 32);
+  }
+  MI_HIP(hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()));
+}
+
 // How many parts a batch is cut into (mi355_batch: THE PIPELINE).  One for NDT (its state machine advances all pairs together), for
 // the per-lane k-NN path and for the counter builds (tuning aids that read one set of counters per launch).
 static int batch_part_count(int method, int n_sources) {
@@ -1192,12 +1219,12 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
       }
       MI_HIP(hipEventCreateWithFlags(&pt.lm_done, hipEventDisableTiming));
       // the LM loops run AHEAD of the (lowest-priority) preparation chains: their short kernels get the freed wave slots first
-      if (N > 1) MI_HIP(hipStreamCreateWithPriority(&pt.lm_stream, hipStreamNonBlocking, prio_hi));
+      if (N > 1) create_stream(&pt.lm_stream, prio_hi, tuning().lm_cus, true, ctx->compute_units);
     }
     if (method == MI355_METHOD_NDT_OMP) b->ndt = ndt_batch_create(n_sources, n_targets);
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
-      MI_HIP(hipStreamCreateWithPriority(&sd.stream, hipStreamNonBlocking, prio_lo));
+      create_stream(&sd.stream, prio_lo, N > 1 ? tuning().prep_cus : 1.f, false, ctx->compute_units);
       MI_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
     }
     batch_layout(b);
@@ -1355,6 +1382,73 @@ static int batch_set_clouds(mi355_batch* b, bool targets, mi355_cloud* const* cl
     if (targets) b->has_tgt = true; else b->has_src = true;
     b->aligned = false;
   });
+}
+// Host clouds given as VIEWS (any stride, one per slot): packed into pinned memory a run of slots at a time - as many slots as fit
+// kPinBytes at the run's widest cloud - and sent with one 2-D copy per run, the two pinned buffers taking turns, so the host packs
+// run r + 1 while run r crosses PCIe.  (mi355_multi_batch_register used to upload every cloud through its own mi355_cloud: one
+// pageable-to-pinned repack, one copy and one stream synchronisation per cloud.)
+static int batch_set_views(mi355_batch* b, bool targets, const mi355_cloud_view* views, const mi355_prefilter_params* pf) {
+  if (!b || !views) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    MI_HIP(hipSetDevice(b->ctx->device));
+    constexpr size_t kPinBytes = 16u << 20;
+    const int B = targets ? b->n_targets : b->n_sources;
+    DevBuf<float4>& stage = targets ? b->host_stage_tgt : b->host_stage_src;
+    stage.ensure((size_t)B * b->cap);
+    std::vector<int> counts((size_t)B);
+    for (int i = 0; i < B; i++) {
+      check_view(&views[i]);
+      if (views[i].n > b->cap) throw ArgError(MI355_EINVAL, "cloud exceeds the batch capacity");
+      counts[(size_t)i] = (int)views[i].n;
+    }
+    batch_wait_side(b, b->stream(), targets ? 0 : 1);  // (a second set call of this side without an align in between)
+    for (int k = 0; k < 2; k++)
+      if (!b->pin_free[k]) MI_HIP(hipEventCreateWithFlags(&b->pin_free[k], hipEventDisableTiming));
+    int run = 0;
+    for (int i0 = 0; i0 < B;) {
+      // the run [i0, i1): its widest cloud sets the pitch
+      size_t width = std::max<size_t>(views[i0].n, 1);
+      int i1 = i0 + 1;
+      while (i1 < B) {
+        const size_t w = std::max(width, std::max<size_t>(views[i1].n, 1));
+        if (w * (size_t)(i1 + 1 - i0) * sizeof(float4) > kPinBytes) break;
+        width = w;
+        i1++;
+      }
+      const int k = run++ & 1;
+      PinnedBuf<float4>& pin = b->pin[k];
+      if (b->pin_used[k]) MI_HIP(hipEventSynchronize(b->pin_free[k]));  // its previous run (of this call or an earlier one) has left the buffer
+      pin.ensure(std::max(width * (size_t)(i1 - i0), kPinBytes / sizeof(float4)));
+      for (int i = i0; i < i1; i++) {
+        const mi355_cloud_view& v = views[i];
+        float4* dst = pin.p + (size_t)(i - i0) * width;
+        const char* base = (const char*)v.data;
+        if (v.stride == sizeof(float4) && v.intensity_offset == 12) {
+          if (v.n) memcpy(dst, base, v.n * sizeof(float4));
+        } else {
+          for (size_t j = 0; j < v.n; j++) {
+            const float* q = (const float*)(base + j * v.stride);
+            dst[j] = make_float4(q[0], q[1], q[2], *(const float*)(base + j * v.stride + v.intensity_offset));
+          }
+        }
+      }
+      MI_HIP(hipMemcpy2DAsync(stage.p + (size_t)i0 * b->cap, b->cap * sizeof(float4), pin.p, width * sizeof(float4), width * sizeof(float4), (size_t)(i1 - i0),
+                              hipMemcpyHostToDevice, b->stream()));
+      MI_HIP(hipEventRecord(b->pin_free[k], b->stream()));
+      b->pin_used[k] = true;
+      i0 = i1;
+    }
+    // (the caller's buffers were read synchronously: they are free when this call returns; the pinned buffers are guarded by their events)
+    batch_set(b, targets, stage.p, counts.data(), pf);
+    if (targets) b->has_tgt = true; else b->has_src = true;
+    b->aligned = false;
+  });
+}
+extern "C" int mi355_batch_set_targets_views(mi355_batch* b, const mi355_cloud_view* views, const mi355_prefilter_params* pf) {
+  return batch_set_views(b, true, views, pf);
+}
+extern "C" int mi355_batch_set_sources_views(mi355_batch* b, const mi355_cloud_view* views, const mi355_prefilter_params* pf) {
+  return batch_set_views(b, false, views, pf);
 }
 extern "C" int mi355_batch_set_targets_clouds(mi355_batch* b, mi355_cloud* const* clouds, const mi355_prefilter_params* pf) {
   return batch_set_clouds(b, true, clouds, pf);

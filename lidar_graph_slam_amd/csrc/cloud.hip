@@ -520,6 +520,12 @@ constexpr bool kTilePrefetch = KNN_TILE_PREFETCH != 0;  // fetch the next tile u
 #define KNN_SUB_CAP 764
 #define KNN_TILE_WAVES_PER_SIMD 2
 #endif
+#ifndef KNN_GATHER_DEPTH
+#define KNN_GATHER_DEPTH 8  // 64-point chunk loads of the candidate gather in flight per wave
+#endif
+#ifndef KNN_COV_REGS
+#define KNN_COV_REGS 1  // 0: the covariance epilogue reads its neighbours from LDS point by point (A/B builds)
+#endif
 #ifndef KNN_RANK_BATCH
 #define KNN_RANK_BATCH 1  // 0: the rank loop of round 3 (A/B builds)
 #endif
@@ -542,6 +548,15 @@ constexpr int kSubCap = KNN_SUB_CAP;
 constexpr int kSubRow = kSubCap + 16;        // row pitch: the software-pipelined rank loop reads (and ignores) up to 15 entries past the end
 
 // min / max over the aligned group of kSubQ lanes a lane belongs to (same value in all lanes of the group)
+#if WAVE_REDUCE_DPP
+__device__ __forceinline__ float group_min(float v) {
+  static_assert(kSubQ == 16, "a sub-tile is one DPP row");
+  return row_reduce16(v, [](float a, float b) { return fminf(a, b); });
+}
+__device__ __forceinline__ float group_max(float v) {
+  return row_reduce16(v, [](float a, float b) { return fmaxf(a, b); });
+}
+#else
 __device__ __forceinline__ float group_min(float v) {
 #pragma unroll
   for (int off = 1; off < kSubQ; off <<= 1) v = fminf(v, __shfl_xor(v, off, kWave));
@@ -552,6 +567,7 @@ __device__ __forceinline__ float group_max(float v) {
   for (int off = 1; off < kSubQ; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
   return v;
 }
+#endif
 
 // Bitonic sort of the wave's lanes by a float key, ascending inside every aligned segment of S lanes.  Only (key, src) travel
 // — src = the lane that held the point originally — so a compare-exchange stage costs two lane exchanges, not four.
@@ -734,7 +750,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           if constexpr (STATS) st_gathers++;
           const TileBox nb = grow(bb, Rn);
           const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
-          const int n_new = cells.ok ? tile_gather(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
+          const int n_new = cells.ok ? tile_gather<KNN_GATHER_DEPTH>(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
           if constexpr (STATS) { if (!cells.ok) t_fail_cells++; else if (n_new < 0) t_fail_list++; }
           if (n_new < 0) {  // over a budget: split the segment if nothing has been gathered yet, else hand the open lanes over
             if (!has_old && Rw > rmin && Rn > 0.5f * e_max) {
@@ -934,7 +950,19 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
 #ifdef KNN_ABL_NO_COV
           if (exact) cov[(size_t)c * cap + i] = cov6_pack(__uint_as_float(keys.v[0]), __uint_as_float(keys.v[1]), __uint_as_float(keys.v[K - 1]), 1.f, 0.f, 1.f);
 #else
-          if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
+          if constexpr (K > 32 || !KNN_COV_REGS) {
+            if (exact) covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return cand[keys.v[t] & kOrdMask]; });
+          } else if (exact) {
+            // the k neighbours into registers first, ALL their LDS reads in flight together (the two passes of the covariance then run
+            // on registers: 2 k reads, each waited for in front of its use, were ~4 k cycles of a tile's ~130 k)
+            float nx[K], ny[K], nz[K];
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+              const float4 pp = cand[keys.v[t < k ? t : 0] & kOrdMask];
+              nx[t] = pp.x; ny[t] = pp.y; nz[t] = pp.z;
+            }
+            covariance_of<K>(k, method, cov + ((size_t)c * cap + i), [&](int t) { return make_float4(nx[t], ny[t], nz[t], 0.f); });
+          }
 #endif
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next segment overwrites the lists
@@ -1090,10 +1118,7 @@ __global__ __launch_bounds__(64, (K <= 32 ? 4 : 1)) void k_knn_hard(const float4
       uint32_t tau = SmallestKeys<K + 1>::kEmpty;
       while (n_lt + n_eq < k) {
         const uint32_t hd = (head <= K) ? col[min(head, K)][lane] : SmallestKeys<K + 1>::kEmpty;
-        uint32_t best = hd;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, kWave));
-        best = (uint32_t)__builtin_amdgcn_readfirstlane((int)best);
+        uint32_t best = wave_reduce64(hd, [](uint32_t a, uint32_t b) { return min(a, b); });
         if (best == SmallestKeys<K + 1>::kEmpty) break;  // fewer than k candidates
         // a lane may hold the value several times (distinct points at the same distance): pop them all
         int pops = 0;
@@ -1102,11 +1127,8 @@ __global__ __launch_bounds__(64, (K <= 32 ? 4 : 1)) void k_knn_hard(const float4
           while (head + pops <= K && col[head + pops][lane] == best) pops++;
           head += pops;
         }
-        int total = pops;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, kWave);
         n_lt += n_eq;
-        n_eq = __builtin_amdgcn_readfirstlane(total);
+        n_eq = wave_sum_all_i(pops);
         tau = best;
       }
       const bool enough = n_lt + n_eq >= k;
@@ -1156,11 +1178,7 @@ __global__ __launch_bounds__(64, (K <= 32 ? 4 : 1)) void k_knn_hard(const float4
     {
       const bool has = lane < k;
       const float4 p = (has && mine >= 0) ? g.pts[mine] : make_float4(0.f, 0.f, 0.f, 0.f);
-      auto wsum = [&](double v) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-        return v;
-      };
+      auto wsum = [&](double v) { return wave_reduce64(v, [](double a, double b) { return a + b; }); };  // (the same bits in every lane)
       if constexpr (SOR) {  // the statistic of StatisticalOutlierRemoval instead (see sor_mean_distance)
         const double ds = wsum((has && mine >= 0) ? sqrt((double)dist2f(q.x, q.y, q.z, p.x, p.y, p.z)) : 0.0);
         if (lane == 0) mean_dist[(size_t)c * cap + g.orig[i]] = (float)(ds / (double)(k - 1));

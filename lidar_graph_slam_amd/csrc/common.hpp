@@ -102,6 +102,9 @@ struct Tuning {
   float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
   float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for, when the tiles follow build_tile_order (along the Morton order a wider gather was measured slower: 1.0)
   int side_streams = 1;       // MI355_BATCH_SIDE_STREAMS 0 = prepare targets and sources on the batch's own stream
+  float prep_cus = 1.0f;      // MI355_PREP_CUS          fraction of the compute units the preparation chains of a pipelined batch may use (a CU mask on
+                              //                         their streams: the LAST such share of the mask bits, i.e. of every XCD's CUs); 1 = all
+  float lm_cus = 1.0f;        // MI355_LM_CUS            the same for the LM loops' streams (the FIRST such share of the bits); 1 = all
   int batch_parts = 0;        // MI355_BATCH_PARTS       parts a FAST_GICP batch is cut into (the pipeline of api.hip); 0 = by its size: 4 from 1 024 pairs, 2 from 512, else 1
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
   int corr_tiles = 4;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
@@ -109,6 +112,8 @@ struct Tuning {
   int corr_groups = 1;        // MI355_CORR_GROUPS       0 = per-lane correspondence search also for batches of < 8 pairs (no lane groups)
   float margin_step = 0.03f;  // MI355_MARGIN_STEP       a pair tracks search margins once its last accepted step moved it by less than this (m at a 50 m lever arm)
   int err_first = -1;         // MI355_ERR_FIRST         LM trials a batch evaluates before the rest (1..4); 0 = all in one pass; -1 = 1, or 0 with forced iterations
+  int corr_mask = 1;          // MI355_CORR_MASK         1 = the cost pass marks the points whose search margin survives every LM trial pose and the next
+                              //                         k_gicp_correspond reads those bits instead of the points (gicp.hip); 0 = the margin check of round 3
   int corr_stats = 0;         // MI355_CORR_STATS        1 = count what the correspondence tiles scan, print after every align
   int knn_stats = 0;          // MI355_KNN_STATS         1 = after every covariance launch, synchronise and print to stderr how many
                               //                         points the tile kernel handed over to k_knn_hard (tuning aid, host side only)

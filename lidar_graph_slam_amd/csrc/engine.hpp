@@ -138,6 +138,8 @@ struct GicpBatch {
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
   DevBuf<Cov6> mahal;        // [S*cap] Mahalanobis matrices of the current linearisation
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
+  DevBuf<unsigned long long> safe_mask;  // [S][cap / 64] bit i of a pair: point i provably keeps its correspondence under EVERY trial pose of the
+                                         // current LM iteration (written by the cost pass, read by the next k_gicp_correspond: gicp.hip)
   DevBuf<double> partials;   // [S][blocks][32]
   DevBuf<GicpPairState> state;
   DevBuf<unsigned char> trials;  // [S][16] LmTrial (gicp.hip)

@@ -28,7 +28,9 @@ struct GicpPairState {
   int iter, trial, active, converged, n_inliers, lm_failed, need_error, status;
   double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
   int first_conv;    // iterations run when is_converged first held (-1: never) - what fast_gicp runs without force_iterations
-  int pad_;
+  int mask_valid;    // the "safe" bits of this pair (GicpBatch::safe_mask) hold for the pose the next k_gicp_correspond will see
+  float slack_rot, slack_trans;  // a point at distance r from the origin moves by at most slack_rot * r + slack_trans between x0 and ANY
+                                 // trial pose of the current iteration (k_gicp_solve)
 };
 
 // One Levenberg-Marquardt trial step.  step_lm's trial sequence is fully determined by (H, b, lambda): trial t uses
@@ -87,6 +89,7 @@ void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_g
   gb.corr.ensure((size_t)S * cap);
   gb.mahal.ensure((size_t)S * cap);
   gb.qsearch.ensure((size_t)S * cap);
+  gb.safe_mask.ensure((size_t)S * (size_t)div_up((long)cap, 64));
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
   gb.trials.ensure((size_t)S * kMaxTrials * sizeof(LmTrial));
@@ -149,7 +152,8 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   if (scount && (scount[p] < k_min || tcount[tgt_of_src[p]] < k_min)) { s.active = 0; s.status = MI355_PAIR_TOO_FEW_POINTS; }
   s.last_step = 1.0e9;
   s.first_conv = -1;
-  s.pad_ = 0;
+  s.mask_valid = 0;
+  s.slack_rot = s.slack_trans = 0.f;
   st[p] = s;
 }
 
@@ -629,10 +633,15 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
                                                                const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                 float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
                                                                 int tiles_took_the_moving_pairs, double margin_step,
-                                                                unsigned long long* __restrict__ stats = nullptr, int iteration = 0) {
+                                                                unsigned long long* __restrict__ stats = nullptr, int iteration = 0,
+                                                                const unsigned long long* __restrict__ safe_mask = nullptr, size_t mask_words = 0) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
+  constexpr int kMaskTiles = 64;  // tiles of a block whose "safe" words are fetched in one go
   __shared__ int queue[kLinTile + kGicpBlock];  // what is left of the earlier tiles (< one block's worth) + this tile's
   __shared__ int qcount;
+  constexpr int kUnsafeCap = 2048;  // points of a block that are not marked safe: listed when they are at most this many
+  __shared__ int ulist[kUnsafeCap];
+  __shared__ int ucount;
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
@@ -655,9 +664,49 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     Tf[4 * r + 3] = (float)x0.t[r];
   }
   const size_t so = (size_t)pair * scap;
-  if (threadIdx.x == 0) qcount = 0;
+  // The cost pass of the previous iteration has marked the points whose margin survives every trial pose it evaluated (safe_mask): a
+  // pair that tracks margins looks at the OTHER points only - a few per cent of them once the pose has settled (the margins of a
+  // voxelised cloud are spread over centimetres; the poses of the last iterations move by fractions of a millimetre).  The words of
+  // all this block's tiles come in with one load per thread, their zero bits become a list in LDS, and the margin check runs over
+  // that list: a block is then three memory latencies - words, listed points, the odd search - where the tile loop below is a chain
+  // of dependent loads and three barriers per 256 points (0.5 ms per iteration at 2 048 pairs, whatever the bytes).
+  constexpr int kWordsPerTile = kLinTile / kWave;
+  const bool masked = safe_mask != nullptr && st->mask_valid && (st->last_step < margin_step) && (n <= kMaskTiles * G * kLinTile);
+  bool use_list = false;
+  int n_list = 0;
+  if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
   __syncthreads();
-  for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
+  if (masked) {
+    const unsigned long long* mw = safe_mask + (size_t)pair * mask_words;
+    for (int w = threadIdx.x; w < kMaskTiles * kWordsPerTile; w += kGicpBlock) {
+      const int tile_no = w / kWordsPerTile;  // this block's tile_no-th tile: points (bx + tile_no G) kLinTile ..., and the word of them this thread reads
+      const long first = (long)(bx + (long)tile_no * G) * kLinTile + (long)(w % kWordsPerTile) * kWave;
+      if (first >= n) continue;
+      unsigned long long bits = ~mw[first / kWave];  // (the cost pass sets the bits past the end of the cloud)
+      if (!bits) continue;
+      int pos = atomicAdd(&ucount, __popcll(bits));
+      while (bits) {
+        const int bit = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (pos < kUnsafeCap) ulist[pos] = (int)first + bit;
+        pos++;
+      }
+    }
+    __syncthreads();
+    n_list = ucount;
+    use_list = n_list <= kUnsafeCap;  // (more than that - a pair that has just started to track margins: the tile loop)
+  }
+  for (int step = 0;; step++) {
+    int base = 0;
+    bool last_tile;
+    if (use_list) {
+      if (step * kLinTile >= n_list) break;
+      last_tile = (step + 1) * kLinTile >= n_list;
+    } else {
+      base = (bx + step * G) * kLinTile;
+      if (base >= n) break;
+      last_tile = base + G * kLinTile >= n;
+    }
     // ---- phase 1: which points of this tile need a new nearest-neighbour search?  
     // The last full search of a point left, at query position qs.xyz, a margin qs.w: while the query has moved less
     // than that, its nearest neighbour provably cannot change (triangle inequality on the nearest / runner-up
@@ -665,11 +714,17 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     // search runs on dense waves instead of stalling every wave of the block behind a few lanes: the queue is searched a
     // whole block's worth at a time, what is left waits for the next tile's (when 1 - 10 % of the points have left their
     // margins - the first iterations of margin tracking - a tile alone fills one or two of the block's four waves, partly).
-    const bool last_tile = base + G * kLinTile >= n;
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
-      const int i = base + u * kGicpBlock + threadIdx.x;
-      if (i >= n) continue;
+      int i;
+      if (use_list) {
+        const int at = step * kLinTile + u * kGicpBlock + (int)threadIdx.x;
+        if (at >= n_list) continue;
+        i = ulist[at];
+      } else {
+        i = base + u * kGicpBlock + threadIdx.x;
+        if (i >= n) continue;
+      }
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
       const float4 qs = qsearch[so + i];
@@ -687,7 +742,7 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     __syncthreads();
     // ---- phase 2: dense search of the queued points
     int nq = qcount;
-    if (stats && threadIdx.x == 0 && bx == 0 && base == 0 && track_margin && !tile_pair) atomicAdd(&stats[8 + 4 * min(iteration, 63) + 3], 1ull);
+    if (stats && threadIdx.x == 0 && bx == 0 && step == 0 && track_margin && !tile_pair) atomicAdd(&stats[8 + 4 * min(iteration, 63) + 3], 1ull);
     const float reach_coop2 = search_reach2(g, max_corr_d2, true);
     while (nq >= kGicpBlock || (last_tile && nq > 0)) {  // whole waves go round together: the cooperative part needs all 64 lanes
       const int take = min(nq, kGicpBlock);
@@ -743,6 +798,10 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
 // same or adjacent buckets (a tie or a near-tie: lattice clouds) repeats its search per lane, with exact distances and the
 // lowest-caller-index tie rule.  The nearest's exact distance is recomputed with dist2f, the runner-up enters the margin as
 // the lower edge of its bucket, so every margin is at most what the per-lane search would have granted.
+#ifndef CORR_SCAN_BATCH
+#define CORR_SCAN_BATCH 0  // 1: four candidates per step with the next step's LDS reads in flight - measured SLOWER (3.97 against 3.64 ms per
+                           // 2 048-pair launch: a fifth more instructions, and four waves per SIMD hide the LDS latency already); kept for A/B builds
+#endif
 constexpr int kCorrOrdBits = 9;
 constexpr int kCorrCand = 1 << kCorrOrdBits;
 constexpr uint32_t kCorrOrdMask = (uint32_t)kCorrCand - 1u;
@@ -756,15 +815,34 @@ struct CorrBest {
 __device__ __forceinline__ void corr_scan(const float4* __restrict__ cand, int n, float qx, float qy, float qz, CorrBest& b) {
   const uint32_t before = b.k1;
   uint32_t k1 = b.k1, k2 = b.k2;
-#pragma unroll 8
-  for (int c = 0; c < n; c++) {
-    const float4 p = cand[c];  // the same address in every lane: an LDS broadcast
+  auto one = [&](const float4& p, int c) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     const uint32_t key = (__float_as_uint(dd) & ~kCorrOrdMask) | (uint32_t)c;
     k2 = max(min(k1, k2), min(max(k1, k2), key));  // median(k1, k2, key) -> v_med3_u32: the new runner-up
     k1 = min(k1, key);
+  };
+  // Four candidates per step, the four LDS reads of the NEXT step requested before this step's 40 VALU instructions run (the same
+  // address in every lane: broadcasts).  Left to itself the compiler - at the 128 registers of four waves per SIMD - re-used one
+  // register triple for the second half of an 8-way unrolled body: four exposed LDS latencies per eight candidates, about as long
+  // as their arithmetic (PMC: 28 % VALU issue, 41 % waiting).  Reading up to 4 entries past n stays inside the ring's slack.
+#if CORR_SCAN_BATCH
+  int c = 0;
+  float4 p0 = cand[0], p1 = cand[1], p2 = cand[2], p3 = cand[3];
+  for (; c + 4 <= n; c += 4) {
+    const float4 q0 = cand[c + 4], q1 = cand[c + 5], q2 = cand[c + 6], q3 = cand[c + 7];
+    __builtin_amdgcn_sched_barrier(0);
+    one(p0, c); one(p1, c + 1); one(p2, c + 2); one(p3, c + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    p0 = q0; p1 = q1; p2 = q2; p3 = q3;
   }
+  if (c < n) one(p0, c);
+  if (c + 1 < n) one(p1, c + 1);
+  if (c + 2 < n) one(p2, c + 2);
+#else  // (A/B aid: the loop of round 3)
+#pragma unroll 8
+  for (int c = 0; c < n; c++) one(cand[c], c);
+#endif
   if (k1 != before) b.j1 = __float_as_int(cand[k1 & kCorrOrdMask].w);
   b.k1 = k1;
   b.k2 = k2;
@@ -874,7 +952,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
                                                                      float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S,
                                                                      unsigned long long* __restrict__ stats, double margin_step,
                                                                      const int* __restrict__ tile_order) {
-  __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand];
+  __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand + 8];  // (+ 8: corr_scan reads ahead of the entries it uses)
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
@@ -1118,6 +1196,22 @@ __device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParam
   if ((conv && !P.force_iterations) || s.iter >= P.max_iterations) s.active = 0;
 }
 
+// Sum of one value over the G block partials of a pair, in block order (bitwise reproducible whatever the machine does).  ALL the
+// loads go out before the first add - up to 32 at a time: a pair's 6 (a big batch) or 32 (a few pairs) partials are one memory
+// latency, where round 3's 8-at-a-time loop with a one-by-one tail took four (a lone pair) or six (the bench's G = 6: all tail).
+__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int G) {
+  double s = 0;
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++) v[u] = (g0 + u < G) ? p[(size_t)(g0 + u) * kPartStride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; u++)
+      if (g0 + u < G) s += v[u];
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, LmTrial* __restrict__ trials, const double* __restrict__ partials,
                                                    int G, GicpDevParams P) {
   __shared__ double sums[kPartStride];
@@ -1128,25 +1222,11 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
   GicpPairState* st = state + pair;
   if (!st->active) return;
   const int l = threadIdx.x;
-  if (l < kNAcc) {
-    // (block order: bitwise reproducible.  Unrolled so that the loads of 8 partials are in flight together — one pair alone spent
-    // most of this kernel's 15 us waiting for 32 loads one after the other)
-    double s = 0;
-    const double* p = partials + (size_t)pair * G * kPartStride + l;
-    int g = 0;
-    for (; g + 8 <= G; g += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(g + u) * kPartStride];
-#pragma unroll
-      for (int u = 0; u < 8; u++) s += v[u];
-    }
-    for (; g < G; g++) s += p[(size_t)g * kPartStride];
-    sums[l] = s;
-  }
+  if (l < kNAcc) sums[l] = sum_partials(partials + (size_t)pair * G * kPartStride + l, G);
   __syncthreads();
   if (P.optimizer == MI355_OPT_GN) {
     if (l == 0) {
+      st->mask_valid = 0;
       GicpPairState s = *st;
       unpack_normal_equations(sums, s.H, s.b);
       s.y0 = sums[27];
@@ -1184,6 +1264,7 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
   __syncthreads();
   if (l < 36) st->H[l] = sH[l];
   if (l < 6) st->b[l] = sb[l];
+  float slack_r = 0.f, slack_t = 0.f;
   if (do_trials && l < P.lm_max_iterations) {
     // lambda of trial l: step_lm multiplies by nu = 2, 4, 8, ... after each rejection
     double lam = slambda, nu = 2.0;
@@ -1191,6 +1272,26 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
     LmTrial tr;
     lm_make_trial(sH, sb, sx0, lam, tr);
     trials[(size_t)pair * kMaxTrials + l] = tr;
+    // how far a point can move between x0 and this trial pose: x_t p - x0 p = (dR - I)(x0 p) + dt, so at most
+    // ||dR - I||_F |x0 p| + |dt|.  The largest of both over the trials goes to the pair's state: the cost pass marks the points whose
+    // search margin survives ANY of these poses, and the next k_gicp_correspond does not look at them again.
+    double fr = 0, ft = 0;
+    for (int k = 0; k < 9; k++) { const double v = tr.delta.R[k] - ((k % 4 == 0) ? 1.0 : 0.0); fr += v * v; }
+    for (int k = 0; k < 3; k++) ft += tr.delta.t[k] * tr.delta.t[k];
+    slack_r = (float)(sqrt(fr) * (1.0 + 1e-6)) + 1e-12f;
+    slack_t = (float)(sqrt(ft) * (1.0 + 1e-6)) + 1e-12f;
+  }
+  if (do_trials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      slack_r = fmaxf(slack_r, __shfl_xor(slack_r, off, kWave));
+      slack_t = fmaxf(slack_t, __shfl_xor(slack_t, off, kWave));
+    }
+    if (l == 0) {
+      st->slack_rot = slack_r;
+      st->slack_trans = slack_t;
+      st->mask_valid = 1;
+    }
   }
 }
 
@@ -1218,7 +1319,8 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
                                                            const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
                                                            const GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
                                                            const int* __restrict__ corr, const Cov6* __restrict__ mahal,
-                                                           double* __restrict__ partials, int t0, int n_trials, int want) {
+                                                           double* __restrict__ partials, int t0, int n_trials, int want,
+                                                           const float4* __restrict__ qsearch, unsigned long long* __restrict__ safe_mask, size_t mask_words) {
   __shared__ double smem[4 * NT];
   __shared__ double accL[NT > 1 ? NT : 1][NT > 1 ? kGicpBlock : 1];  // per-thread sums of the trials (NT > 1)
   const int pair = blockIdx.y;
@@ -1233,6 +1335,19 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
   const int n = scount[pair];
   const size_t so = (size_t)pair * scap;
   const int nt = min(n_trials - t0, NT);
+  const bool mark_safe = safe_mask != nullptr && t0 == 0 && st->mask_valid;
+  float Tf0[12], slack_rot = 0.f, slack_trans = 0.f;
+  if (mark_safe) {
+    const Pose x0 = st->x0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) Tf0[4 * r + c] = (float)x0.R[3 * r + c];
+      Tf0[4 * r + 3] = (float)x0.t[r];
+    }
+    slack_rot = st->slack_rot;
+    slack_trans = st->slack_trans;
+  }
   double acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) acc[t] = 0.0;
@@ -1250,6 +1365,27 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
       p[u] = spts[ii];
       q[u] = tp[max(j, 0)];
       m[u] = mahal[ii];
+    }
+    if (mark_safe) {
+      // Which points can keep their correspondence WHATEVER trial the decision takes?  The last search of a point left a margin
+      // (k_gicp_correspond); a point at x0 p moves by at most slack_rot |x0 p| + slack_trans under any trial pose (k_gicp_solve), so
+      // "moved so far + that < margin" settles it for the pose the next iteration linearises at - one bit per point, and the next
+      // k_gicp_correspond reads the bits (1/128 of the bytes of its margin check) instead of the points and their stored queries.
+#pragma unroll
+      for (int u = 0; u < kErrPoints; u++) {
+        const int i = base + u * kGicpBlock + threadIdx.x;
+        bool safe = i >= n;  // (past the end: nothing to look at)
+        if (i < n) {
+          const float4 qs = qsearch[so + i];
+          const float qx = transform_row(Tf0, p[u].x, p[u].y, p[u].z), qy = transform_row(Tf0 + 4, p[u].x, p[u].y, p[u].z),
+                      qz = transform_row(Tf0 + 8, p[u].x, p[u].y, p[u].z);
+          const float moved = sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z));
+          const float reach = sqrtf(qx * qx + qy * qy + qz * qz) * (1.f + 1e-5f);
+          safe = isfinite(qx) && isfinite(qy) && isfinite(qz) && (moved + (slack_rot * reach + slack_trans) * (1.f + 1e-5f) + 2.0e-5f < qs.w);
+        }
+        const unsigned long long bits = __ballot(safe);
+        if (lane_id() == 0) safe_mask[(size_t)pair * mask_words + (size_t)((base + u * kGicpBlock) / kWave + wave_id())] = bits;
+      }
     }
     if constexpr (NT == 1) {
       const Pose xi = tr[0].xi;  // wave-uniform: scalar loads
@@ -1314,20 +1450,7 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
   if (!state[pair].active || state[pair].need_error != (phase == 1 ? 2 : 1)) return;
   const int walk = (phase == 0) ? min(first, P.lm_max_iterations) : P.lm_max_iterations;
   const int l = threadIdx.x;
-  if (l < P.lm_max_iterations) {
-    double s = 0;
-    const double* p = partials + (size_t)pair * G * kPartStride + kTrialSlot + l;
-    int g = 0;
-    for (; g + 8 <= G; g += 8) {  // (as in k_gicp_solve: 8 loads in flight, summed in block order)
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(g + u) * kPartStride];
-#pragma unroll
-      for (int u = 0; u < 8; u++) s += v[u];
-    }
-    for (; g < G; g++) s += p[(size_t)g * kPartStride];
-    yi[l] = s;
-  }
+  if (l < P.lm_max_iterations) yi[l] = sum_partials(partials + (size_t)pair * G * kPartStride + kTrialSlot + l, G);
   __syncthreads();
   if (l != 0) return;
   GicpPairState& s = state[pair];  // in place: only the fields of the taken branch move (the state is 1 KB)
@@ -1428,7 +1551,9 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     } else {
       hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                          tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step, gb.corr_stats.p, iteration);
+                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step, gb.corr_stats.p, iteration,
+                         (tn.corr_mask && search < 0) ? (const unsigned long long*)gb.safe_mask.p : (const unsigned long long*)nullptr,
+                         (size_t)div_up((long)gb.cap, 64));
     }
   }
   TimedLaunch tl(KF_LINEARIZE, s);
@@ -1484,7 +1609,8 @@ void gicp_align_iterate(hipStream_t s, GicpBatch& gb, const CloudSet& src, const
       auto error = [&](auto kernel, int t0, int t1, int want) {
         TimedLaunch tl(KF_ERROR, s);
         hipLaunchKernelGGL(kernel, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, t0, t1, want);
+                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, t0, t1, want, (const float4*)gb.qsearch.p,
+                           tuning().corr_mask ? gb.safe_mask.p : (unsigned long long*)nullptr, (size_t)div_up((long)gb.cap, 64));
       };
       auto decide = [&](int phase, int first) {
         TimedLaunch tl(KF_SOLVE_DECIDE, s);
@@ -1600,17 +1726,19 @@ void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& s
   out.ensure(2);
   MI_HIP(hipMemsetAsync(out.p, 0, 2 * sizeof(unsigned long long), s));
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
-  auto correspond = [&] {
+  auto correspond = [&](bool with_mask) {
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p, tgt.table.p,
                        tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2, gb.blocks_per_pair, S, 0,
-                       (double)tuning().margin_step, (unsigned long long*)nullptr, 0);
+                       (double)tuning().margin_step, (unsigned long long*)nullptr, 0,
+                       (with_mask && tuning().corr_mask) ? (const unsigned long long*)gb.safe_mask.p : (const unsigned long long*)nullptr,
+                       (size_t)div_up((long)gb.cap, 64));
   };
   hipLaunchKernelGGL(k_gicp_set_active, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, S, 1, saved.p);
-  correspond();  // incremental: margins as the last iteration left them, at the final pose
+  correspond(true);  // incremental: margins - and the "safe" bits - as the last iteration left them, at the final pose
   MI_HIP(hipMemcpyAsync(inc.p, gb.corr.p, (size_t)S * src.cap * sizeof(int), hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_gicp_reset_search, dim3(std::max(1, std::min(64, div_up((long)src.cap, 1024))), S), dim3(256), 0, s, (const int*)src.count.p, gb.corr.p,
                      gb.qsearch.p, src.cap);
-  correspond();  // from scratch: NaN margins, every point searched
+  correspond(false);  // from scratch: NaN margins, every point searched
   hipLaunchKernelGGL(k_gicp_compare_corr, dim3(16, S), dim3(256), 0, s, (const int*)src.count.p, gb.state.p, (const int*)inc.p, (const int*)gb.corr.p, src.cap, out.p);
   hipLaunchKernelGGL(k_gicp_set_active, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, S, 0, saved.p);
   unsigned long long h[2];

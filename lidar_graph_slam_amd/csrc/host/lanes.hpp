@@ -67,17 +67,41 @@ class Lane {
     if (!ctx_) ctx_.reset(new Context(device_));
     return *ctx_;
   }
-  // Register source s against target tgt_of_src[s] (device clouds of THIS lane's context), all in one batch launch sequence.
+  // Register source s against target tgt_of_src[s], all in one batch launch sequence.  The clouds are either device clouds of THIS
+  // lane's context (sources / targets) or host views (src_views / tgt_views: uploaded through the batch's pinned staging).
   // method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params) or MI355_METHOD_NDT_OMP (mi355_ndt_params).
   void register_batch(int method, const void* params, size_t params_size, const std::vector<mi355_cloud*>& sources, const std::vector<mi355_cloud*>& targets,
                       const std::vector<int>& tgt_of_src, const float* guesses16, const mi355_prefilter_params* source_prefilter,
                       const mi355_prefilter_params* target_prefilter, bool with_fitness, mi355_result* results, double* fitness) {
-    const int S = (int)sources.size(), U = (int)targets.size();
-    if (S == 0) return;
+    (void)params_size;
     size_t cap = 1;
     for (mi355_cloud* c : sources) cap = std::max(cap, mi355_cloud_size(c));
     for (mi355_cloud* c : targets) cap = std::max(cap, mi355_cloud_size(c));
-    (void)params_size;
+    if (!prepare(method, params, (int)sources.size(), (int)targets.size(), cap)) return;
+    ctx().check(mi355_batch_set_targets_clouds(batch_, targets.data(), target_prefilter));
+    ctx().check(mi355_batch_set_sources_clouds(batch_, sources.data(), source_prefilter));
+    ctx().check(mi355_batch_align(batch_, tgt_of_src.data(), guesses16, with_fitness ? 1 : 0));
+    ctx().check(mi355_batch_results(batch_, results, with_fitness ? fitness : nullptr));
+  }
+  void register_batch_views(int method, const void* params, const std::vector<mi355_cloud_view>& src_views, const std::vector<mi355_cloud_view>& tgt_views,
+                            const std::vector<int>& tgt_of_src, const float* guesses16, const mi355_prefilter_params* source_prefilter,
+                            const mi355_prefilter_params* target_prefilter, bool with_fitness, mi355_result* results, double* fitness) {
+    size_t cap = 1;
+    for (const auto& v : src_views) cap = std::max(cap, v.n);
+    for (const auto& v : tgt_views) cap = std::max(cap, v.n);
+    if (!prepare(method, params, (int)src_views.size(), (int)tgt_views.size(), cap)) return;
+    // the sub-maps first: their chains (voxel filter, index, covariances) run while the candidates cross PCIe
+    ctx().check(mi355_batch_set_targets_views(batch_, tgt_views.data(), target_prefilter));
+    ctx().check(mi355_batch_set_sources_views(batch_, src_views.data(), source_prefilter));
+    ctx().check(mi355_batch_align(batch_, tgt_of_src.data(), guesses16, with_fitness ? 1 : 0));
+    ctx().check(mi355_batch_results(batch_, results, with_fitness ? fitness : nullptr));
+  }
+
+ private:
+  // The lane's batch object, sized for (S, U, cap): created by the first call, re-created only when a call needs more sources,
+  // sub-maps or capacity, or another method / other parameters (grow-only); then narrowed to the live slots.  false: nothing to do.
+  bool prepare(int method, const void* params, int S, int U, size_t cap) {
+    if (S == 0) return false;
     const bool same = batch_ && method == method_ &&
                       (method == MI355_METHOD_FAST_GICP ? same_params(gp_, *(const mi355_gicp_params*)params) : same_params(np_, *(const mi355_ndt_params*)params));
     if (!same || S > S_ || U > U_ || cap > cap_) {  // grow-only
@@ -98,13 +122,9 @@ class Lane {
     }
     // the batch runs its first `live` slots only: a slot beyond them costs nothing (no empty cloud, no NDT leaf build)
     ctx().check(mi355_batch_set_live(batch_, S, U));
-    ctx().check(mi355_batch_set_targets_clouds(batch_, targets.data(), target_prefilter));
-    ctx().check(mi355_batch_set_sources_clouds(batch_, sources.data(), source_prefilter));
-    ctx().check(mi355_batch_align(batch_, tgt_of_src.data(), guesses16, with_fitness ? 1 : 0));
-    ctx().check(mi355_batch_results(batch_, results, with_fitness ? fitness : nullptr));
+    return true;
   }
 
- private:
   int device_;
   std::unique_ptr<Context> ctx_;
   mi355_batch* batch_ = nullptr;

@@ -48,13 +48,16 @@ extern "C" int mi355_multi_shard_by_target(const int* tgt_of_src, int n_pairs, i
   return MI355_OK;
 }
 
-extern "C" int mi355_multi_batch_register(mi355_multi* m, int method, const void* params, const mi355_cloud_view* sources, int n_sources,
-                                          const mi355_cloud_view* targets, int n_targets, const int* tgt_of_src, const float* guesses16,
-                                          const mi355_prefilter_params* source_prefilter, const mi355_prefilter_params* target_prefilter,
-                                          int with_fitness, mi355_result* results, double* fitness, int* lane_of_pair) {
+namespace {
+// What both forms of mi355_multi_batch_register share: argument checks, the partition, one host thread per busy lane, the gather.
+// per_lane(lane, pairs of the lane sorted by (target, pair), local target index of every one of them, distinct targets in that
+// order, results, fitness) registers the lane's share.
+template <typename PerLane>
+int multi_register(mi355_multi* m, int method, const void* params, int n_sources, int n_targets, const int* tgt_of_src, int with_fitness,
+                   mi355_result* results, double* fitness, int* lane_of_pair, PerLane&& per_lane) {
   if (!m) return MI355_EINVAL;
   try {
-    if (n_sources <= 0 || n_targets <= 0 || !sources || !targets || !results) throw mi355::Error(MI355_EINVAL, "mi355_multi_batch_register: NULL / empty argument");
+    if (n_sources <= 0 || n_targets <= 0 || !results) throw mi355::Error(MI355_EINVAL, "mi355_multi_batch_register: NULL / empty argument");
     if (with_fitness && !fitness) throw mi355::Error(MI355_EINVAL, "with_fitness needs a fitness array");
     if (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP) throw mi355::Error(MI355_EINVAL, "batch mode registers with FAST_GICP or NDT_OMP");
     if (!tgt_of_src && n_sources != n_targets) throw mi355::Error(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
@@ -65,7 +68,6 @@ extern "C" int mi355_multi_batch_register(mi355_multi* m, int method, const void
     if (params && method == MI355_METHOD_FAST_GICP) gp = *(const mi355_gicp_params*)params;
     if (params && method == MI355_METHOD_NDT_OMP) np = *(const mi355_ndt_params*)params;
     const void* pp = method == MI355_METHOD_FAST_GICP ? (const void*)&gp : (const void*)&np;
-    const size_t pp_size = method == MI355_METHOD_FAST_GICP ? sizeof(gp) : sizeof(np);
     std::vector<int> map((size_t)n_sources);
     for (int p = 0; p < n_sources; p++) {
       map[(size_t)p] = tgt_of_src ? tgt_of_src[p] : p;
@@ -80,30 +82,19 @@ extern "C" int mi355_multi_batch_register(mi355_multi* m, int method, const void
         for (int p : shards[(size_t)l]) lane_of_pair[p] = l;
     }
     mi355::for_each_lane(busy, [&](int l) {
-      mi355::Lane& lane = *m->lanes[(size_t)l];
       const std::vector<int>& mine = shards[(size_t)l];  // sorted by (target, pair)
-      // this lane's sub-maps cross PCIe once each, its candidates once each
-      std::vector<int> local_of((size_t)n_targets, -1);
-      std::vector<mi355::DeviceCloud::Ptr> tgt_clouds, src_clouds;
-      std::vector<mi355_cloud*> th, sh;
-      std::vector<int> local_map;
-      std::vector<float> local_guess;
+      std::vector<int> local_of((size_t)n_targets, -1), local_map, my_targets;
       for (int p : mine) {
         const int t = map[(size_t)p];
         if (local_of[(size_t)t] < 0) {
-          local_of[(size_t)t] = (int)tgt_clouds.size();
-          tgt_clouds.push_back(mi355::DeviceCloud::upload_view(lane.ctx(), targets[t]));
-          th.push_back(tgt_clouds.back()->get());
+          local_of[(size_t)t] = (int)my_targets.size();
+          my_targets.push_back(t);
         }
-        src_clouds.push_back(mi355::DeviceCloud::upload_view(lane.ctx(), sources[p]));
-        sh.push_back(src_clouds.back()->get());
         local_map.push_back(local_of[(size_t)t]);
-        if (guesses16) local_guess.insert(local_guess.end(), guesses16 + 16 * (size_t)p, guesses16 + 16 * (size_t)p + 16);
       }
       std::vector<mi355_result> res(mine.size());
       std::vector<double> fit(mine.size());
-      lane.register_batch(method, pp, pp_size, sh, th, local_map, guesses16 ? local_guess.data() : nullptr, source_prefilter, target_prefilter,
-                          with_fitness != 0, res.data(), fit.data());
+      per_lane(*m->lanes[(size_t)l], pp, mine, local_map, my_targets, res.data(), fit.data());
       for (size_t k = 0; k < mine.size(); k++) {  // the gather: fixed-size records back to the caller's pair order
         results[mine[k]] = res[k];
         if (with_fitness) fitness[mine[k]] = fit[k];
@@ -117,4 +108,55 @@ extern "C" int mi355_multi_batch_register(mi355_multi* m, int method, const void
     m->err = e.what();
     return MI355_EINVAL;
   }
+}
+std::vector<float> lane_guesses(const float* guesses16, const std::vector<int>& mine) {
+  std::vector<float> g;
+  if (guesses16)
+    for (int p : mine) g.insert(g.end(), guesses16 + 16 * (size_t)p, guesses16 + 16 * (size_t)p + 16);
+  return g;
+}
+}  // namespace
+
+// Host views: every lane sends its sub-maps and candidates through its batch object's pinned staging (mi355_batch_set_*_views: one
+// 2-D copy per run of slots, packing overlapped with the transfers) - each cloud crosses PCIe once, to the lane that registers it.
+extern "C" int mi355_multi_batch_register(mi355_multi* m, int method, const void* params, const mi355_cloud_view* sources, int n_sources,
+                                          const mi355_cloud_view* targets, int n_targets, const int* tgt_of_src, const float* guesses16,
+                                          const mi355_prefilter_params* source_prefilter, const mi355_prefilter_params* target_prefilter,
+                                          int with_fitness, mi355_result* results, double* fitness, int* lane_of_pair) {
+  if (m && (!sources || !targets)) {
+    m->err = "mi355_multi_batch_register: NULL sources / targets";
+    return MI355_EINVAL;
+  }
+  return multi_register(m, method, params, n_sources, n_targets, tgt_of_src, with_fitness, results, fitness, lane_of_pair,
+                        [&](mi355::Lane& lane, const void* pp, const std::vector<int>& mine, const std::vector<int>& local_map,
+                            const std::vector<int>& my_targets, mi355_result* res, double* fit) {
+                          std::vector<mi355_cloud_view> sv, tv;
+                          for (int p : mine) sv.push_back(sources[p]);
+                          for (int t : my_targets) tv.push_back(targets[t]);
+                          const std::vector<float> g = lane_guesses(guesses16, mine);
+                          lane.register_batch_views(method, pp, sv, tv, local_map, guesses16 ? g.data() : nullptr, source_prefilter, target_prefilter,
+                                                    with_fitness != 0, res, fit);
+                        });
+}
+
+// Device clouds: nothing is uploaded; every cloud must live on the lane that registers it (mi355_batch_set_*_clouds refuses a cloud
+// of another context).
+extern "C" int mi355_multi_batch_register_clouds(mi355_multi* m, int method, const void* params, mi355_cloud* const* sources, int n_sources,
+                                                 mi355_cloud* const* targets, int n_targets, const int* tgt_of_src, const float* guesses16,
+                                                 const mi355_prefilter_params* source_prefilter, const mi355_prefilter_params* target_prefilter,
+                                                 int with_fitness, mi355_result* results, double* fitness, int* lane_of_pair) {
+  if (m && (!sources || !targets)) {
+    m->err = "mi355_multi_batch_register_clouds: NULL sources / targets";
+    return MI355_EINVAL;
+  }
+  return multi_register(m, method, params, n_sources, n_targets, tgt_of_src, with_fitness, results, fitness, lane_of_pair,
+                        [&](mi355::Lane& lane, const void* pp, const std::vector<int>& mine, const std::vector<int>& local_map,
+                            const std::vector<int>& my_targets, mi355_result* res, double* fit) {
+                          std::vector<mi355_cloud*> sh, th;
+                          for (int p : mine) sh.push_back(sources[p]);
+                          for (int t : my_targets) th.push_back(targets[t]);
+                          const std::vector<float> g = lane_guesses(guesses16, mine);
+                          lane.register_batch(method, pp, 0, sh, th, local_map, guesses16 ? g.data() : nullptr, source_prefilter, target_prefilter,
+                                              with_fitness != 0, res, fit);
+                        });
 }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mi355 {
 
 constexpr int kWave = 64;
@@ -37,6 +39,47 @@ __device__ __forceinline__ void block_sum(double* acc, double* smem) {
     }
   }
   __syncthreads();
+}
+
+// ---- wave / row all-reductions without LDS ------------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 on gfx950: an LDS-crossbar round trip (~100 cycles) per step, and the six steps of a
+// wave reduction depend on each other.  The tile kernels reduce a bounding box (6 values), group boxes, radii and counts per tile and
+// per round - ~100 such steps per 64-point tile of k_knn_cov_tile, more per tile of k_gicp_correspond_tile.  DPP does the steps
+// inside a row of 16 lanes in the VALU itself (quad permutes, then the two mirrors: every lane ends with its row's result), and the
+// four rows are combined through v_readlane - the result is wave-uniform and sits in an SGPR.  Exact for min / max / integer sums
+// whatever the order.  Callers are in wave-uniform control flow (all 64 lanes active).
+template <typename T, typename Op>
+__device__ __forceinline__ T row_reduce16(T v, Op op) {  // every lane of an aligned group of 16 gets the group's result
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+  auto dpp = [](T x, auto ctrl) {
+    constexpr int c = decltype(ctrl)::value;
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &x, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; k++) w[k] = __builtin_amdgcn_update_dpp(w[k], w[k], c, 0xF, 0xF, false);
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+  };
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));  // row_mirror
+  return v;
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce64(T v, Op op) {  // wave-uniform result
+  v = row_reduce16(v, op);
+  auto lane_of = [&](int l) {
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; k++) w[k] = __builtin_amdgcn_readlane(w[k], l);
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+  };
+  return op(op(lane_of(0), lane_of(16)), op(lane_of(32), lane_of(48)));
 }
 
 // XCD-aware work mapping (perf only, never correctness).  MI355X deals workgroups round-robin over its 8 XCDs, each with

@@ -266,8 +266,6 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
   __shared__ int split[4];
   const int c = blockIdx.y;
   const int n = counts[c];
-  const int o0 = blockIdx.x * kMergeChunk;
-  if (o0 >= n) return;
   int nt, tl;
   tile_geometry(n, nt, tl);
   if (nt == 1) return;  // already in its final place (k_sort_tile)
@@ -275,6 +273,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
   const uint32_t* K = keys_in + o;
   const int* V = vals_in + o;
   const long L = (long)tl * run;  // elements per input run
+  // (a block takes every gridDim.x-th chunk of its cloud: the launch is sized for the CAPACITY of a segment, and for a batch of
+  // voxelised clouds - one tile each - every block leaves at once: 4 x B blocks to retire instead of 16 x B)
+  for (int o0 = blockIdx.x * kMergeChunk; o0 < n; o0 += gridDim.x * kMergeChunk) {
   // a chunk may straddle the boundary between two output runs (2 L elements each): handle the (at most two) pieces in turn
   int pos = o0;
   const int end = min(o0 + kMergeChunk, n);
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
     __syncthreads();
     pos = a0 + d1;
   }
+  }
 }
 
 // Sorts B segments of (key, index-in-segment) pairs by the low 8 * passes key bits, stably; the result ends up in
@@ -343,7 +345,10 @@ void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_co
     uint32_t* ki = ws.keys_b.p; uint32_t* ko = ws.keys_a.p;
     int* vi = ws.vals_b.p; int* vo = ws.vals_a.p;
     for (int run = 1; run < max_tiles; run *= 2) {
-      hipLaunchKernelGGL(k_sort_merge, dim3(div_up((long)cap, kMergeChunk), B), dim3(kMergeThreads), 0, s, ki, vi, ko, vo, d_counts, cap, run);
+      // (enough blocks per segment to fill the chip when every segment merges: >= 8 k blocks over the batch, at most one per chunk)
+      const int chunks = div_up((long)cap, kMergeChunk);
+      const int gx = std::max(1, std::min(chunks, std::max(4, div_up(8192, B))));
+      hipLaunchKernelGGL(k_sort_merge, dim3(gx, B), dim3(kMergeThreads), 0, s, ki, vi, ko, vo, d_counts, cap, run);
       std::swap(ki, ko);
       std::swap(vi, vo);
       hops++;

@@ -31,6 +31,15 @@ __device__ __forceinline__ bool in_box(const TileBox& b, float x, float y, float
 }
 __device__ __forceinline__ TileBox grow(const TileBox& b, float r) { return TileBox{b.lx - r, b.ly - r, b.lz - r, b.hx + r, b.hy + r, b.hz + r}; }
 
+#ifndef WAVE_REDUCE_DPP
+#define WAVE_REDUCE_DPP 1  // 0: the ds_bpermute butterflies of round 3 (A/B builds)
+#endif
+#if WAVE_REDUCE_DPP
+__device__ __forceinline__ float wave_min_all(float v) { return wave_reduce64(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max_all(float v) { return wave_reduce64(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ int wave_sum_all_i(int v) { return wave_reduce64(v, [](int a, int b) { return a + b; }); }
+__device__ __forceinline__ int wave_max_all_i(int v) { return wave_reduce64(v, [](int a, int b) { return max(a, b); }); }
+#else
 __device__ __forceinline__ float wave_min_all(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
@@ -51,6 +60,7 @@ __device__ __forceinline__ int wave_max_all_i(int v) {
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, kWave));
   return __builtin_amdgcn_readfirstlane(v);
 }
+#endif
 __device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
@@ -107,6 +117,7 @@ __device__ __forceinline__ TileCells tile_cells(const GridView& g, const TileBox
 // cand[n0 ...] as (x, y, z, sorted index).  Returns the new list length, or -1 if it would exceed `cap` (the list is then
 // undefined past n0).  The chunk loads do not depend on each other, so kGatherDepth of them are in flight per wave.
 constexpr int kGatherDepth = 8;
+template <int DEPTH = kGatherDepth>
 __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& cells_in, const TileBox& nb, const TileBox& ob, bool has_old,
                                            float4* cand, int n0, int cap) {
   const int lane = lane_id();
@@ -125,11 +136,11 @@ __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& c
   };
   int n = n0;
   for (;;) {
-    int jb[kGatherDepth];
-    bool have[kGatherDepth];
-    float4 p[kGatherDepth];
+    int jb[DEPTH];
+    bool have[DEPTH];
+    float4 p[DEPTH];
 #pragma unroll
-    for (int u = 0; u < kGatherDepth; u++) {
+    for (int u = 0; u < DEPTH; u++) {
       have[u] = advance();
       jb[u] = j;
       p[u] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
@@ -137,7 +148,7 @@ __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& c
     }
     if (!have[0]) break;
 #pragma unroll
-    for (int u = 0; u < kGatherDepth; u++) {
+    for (int u = 0; u < DEPTH; u++) {
       if (!have[u]) break;
       // a lane past the end of its range holds +inf coordinates and fails the box test
       const bool in = in_box(nb, p[u].x, p[u].y, p[u].z) && !(has_old && in_box(ob, p[u].x, p[u].y, p[u].z));
@@ -147,7 +158,7 @@ __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& c
       if (in) cand[n + __popcll(mask & below)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(jb[u] + lane));
       n += cnt;
     }
-    if (!have[kGatherDepth - 1]) break;
+    if (!have[DEPTH - 1]) break;
   }
   return n;
 }

@@ -32,9 +32,9 @@ class MultiDevice:
         self.n_devices = self._lib.mi355_multi_device_count(self.handle)
 
     def batch_register(self, sources, targets, tgt_of_src=None, guesses=None, *, method="FAST_GICP", source_prefilter=None,
-                       target_prefilter=None, with_fitness=True, **params):
-        """sources / targets: lists of float32 [n,4] (or [n,8] PointXYZI-shaped) clouds.  Returns (list of result dicts,
-        fitness array or None, lane_of_pair)."""
+                       target_prefilter=None, with_fitness=True, raw=False, **params):
+        """sources / targets: lists of float32 [n,4] (or [n,8] PointXYZI-shaped) clouds.  Returns (list of result dicts - or, raw=True,
+        ONE record array over the C structs -, fitness array or None, lane_of_pair)."""
         m = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP}[method]
         p = L.gicp_params(**params) if m == L.METHOD_FAST_GICP else L.ndt_params(**params)
         sv = (L.CloudView * len(sources))()
@@ -56,7 +56,42 @@ class MultiDevice:
             1 if with_fitness else 0, res, fit.ctypes.data if with_fitness else None, lane.ctypes.data)
         if rc != L.OK:
             raise L.Mi355Error(rc, self._lib.mi355_multi_last_error(self.handle).decode())
-        return [r.to_dict() for r in res], (fit if with_fitness else None), lane
+        out = np.frombuffer(res, dtype=L.RESULT_DTYPE, count=len(sources)) if raw else [r.to_dict() for r in res]
+        return out, (fit if with_fitness else None), lane
+
+    def lane_context(self, lane: int):
+        """A Context object over lane `lane`'s mi355_ctx (owned by the multi object): for device clouds that live on that lane
+        (DeviceCloud.upload(cloud, ctx=md.lane_context(i)))."""
+        from .context import Context
+
+        h = self._lib.mi355_multi_context(self.handle, int(lane))
+        if not h:
+            raise L.Mi355Error(L.EINVAL, f"no lane {lane}")
+        c = Context.__new__(Context)
+        c._lib, c.handle, c.device_id, c._borrowed = self._lib, h, None, True
+        return c
+
+    def batch_register_clouds(self, sources, targets, tgt_of_src=None, guesses=None, *, method="FAST_GICP", source_prefilter=None,
+                              target_prefilter=None, with_fitness=True, raw=False, **params):
+        """The same for DeviceCloud objects that already live on the lanes: source p and its sub-map on the lane
+        shard_by_target deals pair p to (nothing crosses PCIe but the results)."""
+        m = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP}[method]
+        p = L.gicp_params(**params) if m == L.METHOD_FAST_GICP else L.ndt_params(**params)
+        sh = (C.c_void_p * len(sources))(*[c.handle for c in sources])
+        th = (C.c_void_p * len(targets))(*[c.handle for c in targets])
+        t = None if tgt_of_src is None else np.ascontiguousarray(tgt_of_src, dtype=np.int32)
+        g = None if guesses is None else np.ascontiguousarray(guesses, dtype=np.float32).reshape(len(sources), 16)
+        res = (L.Result * len(sources))()
+        fit = np.zeros(len(sources), dtype=np.float64)
+        lane = np.full(len(sources), -1, dtype=np.int32)
+        rc = self._lib.mi355_multi_batch_register_clouds(
+            self.handle, m, C.byref(p), sh, len(sources), th, len(targets), None if t is None else t.ctypes.data, None if g is None else g.ctypes.data,
+            None if source_prefilter is None else C.byref(source_prefilter), None if target_prefilter is None else C.byref(target_prefilter),
+            1 if with_fitness else 0, res, fit.ctypes.data if with_fitness else None, lane.ctypes.data)
+        if rc != L.OK:
+            raise L.Mi355Error(rc, self._lib.mi355_multi_last_error(self.handle).decode())
+        out = np.frombuffer(res, dtype=L.RESULT_DTYPE, count=len(sources)) if raw else [r.to_dict() for r in res]
+        return out, (fit if with_fitness else None), lane
 
     def lane_allocations(self, lane: int) -> int:
         """Times lane `lane`'s batch object has been (re)created: stays 1 while requests fit and keep method / parameters."""

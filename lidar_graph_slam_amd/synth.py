@@ -201,6 +201,18 @@ def make_pair_job(spec: dict):
     return make_pair(**spec)
 
 
+_STREETS = {}
+
+
+def cast_job(spec):
+    """One scan of a street scene as a picklable job for a pool of spawned workers: spec = (street length, 4x4 sensor pose, noise
+    seed, n_azimuth, ground_max_range).  The scene is built once per worker process."""
+    length, pose, seed, n_azimuth, ground_max_range = spec
+    if length not in _STREETS:
+        _STREETS[length] = street(length)
+    return cast_scan(_STREETS[length], np.asarray(pose, dtype=np.float64), n_azimuth=n_azimuth, seed=seed, ground_max_range=ground_max_range)
+
+
 def trajectory(n: int, *, speed: float = 8.0, hz: float = 10.0, seed: int = 3) -> np.ndarray:
     """[n,4,4] KITTI-like path: `speed` m/s at `hz` scans/s, gentle yaw-rate changes <= 10 deg/s, staying in the corridor."""
     rng = np.random.default_rng(seed)
