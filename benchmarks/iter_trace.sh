@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: duration of every launch of the LM-loop kernels of ONE bench step, in launch order (rocprofv3 kernel trace).
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-rm -rf /tmp/itr; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/itr -- python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 1 --warmup 1 > /dev/null 2>&1
+rm -rf /tmp/itr; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/itr -- python3 bench.py --no-cpu-baseline --no-h2d --bases 8 --no-kernel-timing --steps 1 --warmup 1 > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
 f=sorted(glob.glob('/tmp/itr/*/*_kernel_trace.csv'))[-1]

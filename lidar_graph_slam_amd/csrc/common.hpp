@@ -105,7 +105,7 @@ struct Tuning {
   float prep_cus = 1.0f;      // MI355_PREP_CUS          fraction of the compute units the preparation chains of a pipelined batch may use (a CU mask on
                               //                         their streams: the LAST such share of the mask bits, i.e. of every XCD's CUs); 1 = all
   float lm_cus = 1.0f;        // MI355_LM_CUS            the same for the LM loops' streams (the FIRST such share of the bits); 1 = all
-  int batch_parts = 0;        // MI355_BATCH_PARTS       parts a FAST_GICP batch is cut into (the pipeline of api.hip); 0 = by its size: 4 from 1 024 pairs, 2 from 512, else 1
+  int batch_parts = 0;        // MI355_BATCH_PARTS       parts a FAST_GICP batch is cut into (the pipeline of api.hip); 0 = by its size: 2 from 512 pairs, else 1
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
   int corr_tiles = 4;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)

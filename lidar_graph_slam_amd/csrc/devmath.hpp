@@ -328,44 +328,76 @@ MI_HD bool is_converged(const Pose& delta, double rot_eps, double trans_eps) {
 
 // 6x6 symmetric LDL^T with largest-diagonal pivoting; solves A x = rhs.
 MI_HD bool ldlt6_solve(const double* A_in, const double* rhs, double* x) {
+  // Every index below is a compile-time constant once the loops are unrolled: the pivot row is CHOSEN at run time, but the swap is
+  // written as "for every candidate row c: if (piv == c) swap" - so the matrices live in registers on the device.  (Indexed by the
+  // run-time pivot they lived in scratch memory: 1.7 KB per lane of k_gicp_solve, every access a trip to memory, ~10 of the 15 us
+  // that kernel took for a lone pair.)  Same operations in the same order as the plain loops: same bits.
   constexpr int N = 6;
-  double A[N * N], L[N * N], D[N], y[N], z[N];
+  double A[N * N], L[N * N], D[N], y[N], z[N], r[N];
   int perm[N];
+#pragma unroll
   for (int i = 0; i < N * N; i++) { A[i] = A_in[i]; L[i] = 0.0; }
-  for (int i = 0; i < N; i++) perm[i] = i;
+#pragma unroll
+  for (int i = 0; i < N; i++) { perm[i] = i; r[i] = rhs[i]; }
+  bool singular = false;
+#pragma unroll
   for (int k = 0; k < N; k++) {
     int piv = k;
     double best = fabs(A[k * N + k]);
+#pragma unroll
     for (int i = k + 1; i < N; i++)
       if (fabs(A[i * N + i]) > best) { best = fabs(A[i * N + i]); piv = i; }
-    if (piv != k) {
-      for (int j = 0; j < N; j++) { const double t = A[k * N + j]; A[k * N + j] = A[piv * N + j]; A[piv * N + j] = t; }
-      for (int j = 0; j < N; j++) { const double t = A[j * N + k]; A[j * N + k] = A[j * N + piv]; A[j * N + piv] = t; }
-      for (int j = 0; j < k; j++) { const double t = L[k * N + j]; L[k * N + j] = L[piv * N + j]; L[piv * N + j] = t; }
-      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+#pragma unroll
+    for (int c = k + 1; c < N; c++) {
+      if (piv == c) {
+#pragma unroll
+        for (int j = 0; j < N; j++) { const double t = A[k * N + j]; A[k * N + j] = A[c * N + j]; A[c * N + j] = t; }
+#pragma unroll
+        for (int j = 0; j < N; j++) { const double t = A[j * N + k]; A[j * N + k] = A[j * N + c]; A[j * N + c] = t; }
+#pragma unroll
+        for (int j = 0; j < k; j++) { const double t = L[k * N + j]; L[k * N + j] = L[c * N + j]; L[c * N + j] = t; }
+        { const int t = perm[k]; perm[k] = perm[c]; perm[c] = t; }
+        { const double t = r[k]; r[k] = r[c]; r[c] = t; }  // r[i] = rhs[perm[i]]
+      }
     }
     D[k] = A[k * N + k];
     L[k * N + k] = 1.0;
-    if (D[k] == 0.0) {  // singular (e.g. no correspondences): Eigen's LDLT::solve returns the zero vector here
-      for (int i = 0; i < N; i++) x[i] = 0.0;
-      return false;
+    if (D[k] == 0.0) singular = true;  // (e.g. no correspondences): Eigen's LDLT::solve returns the zero vector here
+    if (!singular) {
+#pragma unroll
+      for (int i = k + 1; i < N; i++) L[i * N + k] = A[i * N + k] / D[k];
+#pragma unroll
+      for (int i = k + 1; i < N; i++)
+#pragma unroll
+        for (int j = k + 1; j < N; j++) A[i * N + j] -= L[i * N + k] * D[k] * L[j * N + k];
     }
-    for (int i = k + 1; i < N; i++) L[i * N + k] = A[i * N + k] / D[k];
-    for (int i = k + 1; i < N; i++)
-      for (int j = k + 1; j < N; j++) A[i * N + j] -= L[i * N + k] * D[k] * L[j * N + k];
   }
+  if (singular) {
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = 0.0;
+    return false;
+  }
+#pragma unroll
   for (int i = 0; i < N; i++) {
-    double s = rhs[perm[i]];
+    double s = r[i];
+#pragma unroll
     for (int j = 0; j < i; j++) s -= L[i * N + j] * y[j];
     y[i] = s;
   }
+#pragma unroll
   for (int i = 0; i < N; i++) y[i] /= D[i];
+#pragma unroll
   for (int i = N - 1; i >= 0; i--) {
     double s = y[i];
+#pragma unroll
     for (int j = i + 1; j < N; j++) s -= L[j * N + i] * z[j];
     z[i] = s;
   }
-  for (int i = 0; i < N; i++) x[perm[i]] = z[i];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (perm[i] == j) x[j] = z[i];
   return true;
 }
 

@@ -1213,7 +1213,7 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ p, int
 }
 
 __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, LmTrial* __restrict__ trials, const double* __restrict__ partials,
-                                                   int G, GicpDevParams P) {
+                                                   int G, GicpDevParams P, double margin_step = -1.0) {
   __shared__ double sums[kPartStride];
   __shared__ double sH[36], sb[6], slambda;
   __shared__ Pose sx0;
@@ -1290,7 +1290,9 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
     if (l == 0) {
       st->slack_rot = slack_r;
       st->slack_trans = slack_t;
-      st->mask_valid = 1;
+      // (only a pair that tracks margins has use for the bits: while it still moves by centimetres every point is searched anyway,
+      // and the cost pass is spared the 16 B per point of the stored queries)
+      st->mask_valid = (st->last_step < margin_step) ? 1 : 0;
     }
   }
 }
@@ -1379,9 +1381,10 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
           const float4 qs = qsearch[so + i];
           const float qx = transform_row(Tf0, p[u].x, p[u].y, p[u].z), qy = transform_row(Tf0 + 4, p[u].x, p[u].y, p[u].z),
                       qz = transform_row(Tf0 + 8, p[u].x, p[u].y, p[u].z);
-          const float moved = sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z));
-          const float reach = sqrtf(qx * qx + qy * qy + qz * qz) * (1.f + 1e-5f);
-          safe = isfinite(qx) && isfinite(qy) && isfinite(qz) && (moved + (slack_rot * reach + slack_trans) * (1.f + 1e-5f) + 2.0e-5f < qs.w);
+          // (no square roots in this VALU-bound kernel: |x0 p| <= its 1-norm, and "moved < budget" is compared squared)
+          const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
+          const float budget = qs.w - ((slack_rot * reach + slack_trans) * (1.f + 1e-5f) + 2.0e-5f);
+          safe = isfinite(reach) && budget > 0.f && dist2f(qx, qy, qz, qs.x, qs.y, qs.z) < budget * budget * (1.f - 1e-6f);
         }
         const unsigned long long bits = __ballot(safe);
         if (lane_id() == 0) safe_mask[(size_t)pair * mask_words + (size_t)((base + u * kGicpBlock) / kWave + wave_id())] = bits;
@@ -1445,54 +1448,70 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restr
 // phase 2: the full walk for pairs with need_error == 1 (all trials evaluated in one launch: batches of a few pairs).
 __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
                                                     const double* __restrict__ partials, int G, GicpDevParams P, int phase, int first) {
+  static_assert(sizeof(LmTrial) == 31 * sizeof(double), "LmTrial is 31 doubles");
   __shared__ double yi[kMaxTrials];
+  __shared__ LmTrial s_tr[kMaxTrials];  // the trials, fetched by all lanes at once (lane 0 used to walk them through dependent global loads)
+  __shared__ double s_b[6], s_y0, s_lam;
+  __shared__ int s_accepted;
   const int pair = blockIdx.x;
   if (!state[pair].active || state[pair].need_error != (phase == 1 ? 2 : 1)) return;
   const int walk = (phase == 0) ? min(first, P.lm_max_iterations) : P.lm_max_iterations;
   const int l = threadIdx.x;
+  {
+    const double* tg = reinterpret_cast<const double*>(trials + (size_t)pair * kMaxTrials);
+    double* tl = reinterpret_cast<double*>(s_tr);
+    for (int w = l; w < walk * 31; w += kWave) tl[w] = tg[w];
+    if (l < 6) s_b[l] = state[pair].b[l];
+    if (l == 6) s_y0 = state[pair].y0;
+    if (l == 7) s_lam = state[pair].lambda;
+    if (l == 8) s_accepted = 0;
+  }
   if (l < P.lm_max_iterations) yi[l] = sum_partials(partials + (size_t)pair * G * kPartStride + kTrialSlot + l, G);
   __syncthreads();
-  if (l != 0) return;
-  GicpPairState& s = state[pair];  // in place: only the fields of the taken branch move (the state is 1 KB)
-  bool finished = false;
-  double lam_next = s.lambda, nu = 2.0;
-  for (int t = 0; t < walk && !finished; t++) {
-    const LmTrial& tr = trials[(size_t)pair * kMaxTrials + t];
-    double denom = 0;
-    for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - s.b[i]);
-    const double rho = (s.y0 - yi[t]) / denom;
-    s.trial = t;
-    if (rho < 0) {
-      if (!P.force_iterations && is_converged(tr.delta, P.rotation_epsilon, P.transformation_epsilon)) {
-        s.delta = tr.delta;  // step_lm returns true without moving x0 (and without touching lambda)
-        s.lambda = tr.lambda;
+  if (l == 0) {
+    GicpPairState& s = state[pair];  // in place: only the fields of the taken branch move (the state is 1 KB)
+    bool finished = false, marked = false;
+    double lam_next = s_lam, nu = 2.0;
+    for (int t = 0; t < walk && !finished; t++) {
+      const LmTrial& tr = s_tr[t];
+      double denom = 0;
+      for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - s_b[i]);
+      const double rho = (s_y0 - yi[t]) / denom;
+      s.trial = t;
+      if (rho < 0) {
+        if (!P.force_iterations && is_converged(tr.delta, P.rotation_epsilon, P.transformation_epsilon)) {
+          s.delta = tr.delta;  // step_lm returns true without moving x0 (and without touching lambda)
+          s.lambda = tr.lambda;
+          finish_step(s, P, true);
+          finished = true;
+        } else {
+          lam_next = nu * tr.lambda;
+          nu = 2 * nu;
+        }
+      } else {
+        s.x0 = tr.xi;
+        s.delta = tr.delta;
+        for (int i = 0; i < 6; i++) s.d[i] = tr.d[i];
+        const double c = 2 * rho - 1;
+        s.lambda = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
+        s_accepted = 1;  // final_H = H: by 36 lanes, below
+        s.last_error = yi[t];
+        s.yi = yi[t];
         finish_step(s, P, true);
         finished = true;
-      } else {
-        lam_next = nu * tr.lambda;
-        nu = 2 * nu;
       }
-    } else {
-      s.x0 = tr.xi;
-      s.delta = tr.delta;
-      for (int i = 0; i < 6; i++) s.d[i] = tr.d[i];
-      const double c = 2 * rho - 1;
-      s.lambda = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
-      for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
-      s.last_error = yi[t];
-      s.yi = yi[t];
-      finish_step(s, P, true);
-      finished = true;
+    }
+    if (!finished && phase == 0 && P.lm_max_iterations > walk) {  // the first trials rejected: the other trials are evaluated next
+      s.need_error = 2;
+      marked = true;
+    }
+    if (!finished && !marked) {  // every trial rejected: "lm not converged!!"
+      s.lambda = lam_next;
+      finish_step(s, P, false);
     }
   }
-  if (!finished && phase == 0 && P.lm_max_iterations > walk) {  // the first trials rejected: the other trials are evaluated next
-    s.need_error = 2;
-    return;
-  }
-  if (!finished) {  // every trial rejected: "lm not converged!!"
-    s.lambda = lam_next;
-    finish_step(s, P, false);
-  }
+  __syncthreads();
+  if (s_accepted && l < 36) state[pair].final_H[l] = state[pair].H[l];
 }
 
 __global__ void k_count_active(const GicpPairState* __restrict__ st, int S, int* __restrict__ n_active) {
@@ -1602,7 +1621,8 @@ void gicp_align_iterate(hipStream_t s, GicpBatch& gb, const CloudSet& src, const
     launch_linearize(s, gb, src, tgt, P, it);
     {
       TimedLaunch tl(KF_SOLVE_DECIDE, s);
-      hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P);
+      hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P,
+                         tuning().corr_mask ? (double)tuning().margin_step : -1.0);
     }
     if (p.optimizer == MI355_OPT_LM) {
       auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
