@@ -197,6 +197,10 @@ int mi355_reg_fitness(mi355_reg* reg, double max_range, double* score);
 /* One linearisation at pose T (row-major 4x4 double): the 6x6 normal equations of FastGICP::linearize, for parity tests.
  * corr (optional, n_source ints): target index per source point in the CALLER's point order, -1 = none. */
 int mi355_reg_gicp_linearize(mi355_reg* reg, const double T16[16], double* H36, double* b6, double* error, int* corr);
+/* FastGICP::compute_error(T_trial) with the correspondences and Mahalanobis matrices of a linearisation at T_lin (fast_gicp_impl.hpp,
+ * LsqRegistration::step_lm's trial cost), for parity tests: model_cost = as the optimisation prices its trials (from the sums of the
+ * linearisation pass, no pass over the points); direct_cost = the reference's loop over the points. */
+int mi355_reg_gicp_trial_cost(mi355_reg* reg, const double T_lin16[16], const double T_trial16[16], double* model_cost, double* direct_cost);
 /* NDT computeDerivatives at p6 = (tx,ty,tz,roll,pitch,yaw); hessian_fp64 selects computeHessian's fp64 path. */
 int mi355_reg_ndt_derivatives(mi355_reg* reg, const double p6[6], double* score, double* grad6, double* hess36, int hessian_fp64);
 /* NDT leaves (VoxelGridCovariance) for parity: arrays sized by mi355_reg_ndt_num_cells(); sorted by linear voxel index. */

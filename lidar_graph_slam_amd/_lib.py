@@ -125,7 +125,7 @@ EXPORTS = [
     "mi355_distance_filter", "mi355_voxel_grid", "mi355_sor", "mi355_prefilter", "mi355_transform",
     "mi355_knn", "mi355_covariances",
     "mi355_reg_create", "mi355_reg_destroy", "mi355_reg_set_params", "mi355_reg_set_target", "mi355_reg_set_source", "mi355_reg_align",
-    "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
+    "mi355_reg_fitness", "mi355_reg_gicp_linearize", "mi355_reg_gicp_trial_cost", "mi355_reg_ndt_derivatives", "mi355_reg_ndt_num_cells", "mi355_reg_ndt_cells",
     "mi355_cloud_upload", "mi355_cloud_destroy", "mi355_cloud_size", "mi355_cloud_has_covariances", "mi355_cloud_download", "mi355_cloud_transform",
     "mi355_cloud_concat", "mi355_cloud_compute_covariances", "mi355_cloud_prefilter", "mi355_reg_set_source_cloud", "mi355_reg_set_target_cloud",
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds", "mi355_batch_set_targets_views", "mi355_batch_set_sources_views",
@@ -257,6 +257,7 @@ def lib():
         L.mi355_reg_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Result), C.c_void_p]
         L.mi355_reg_fitness.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double)]
         L.mi355_reg_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        L.mi355_reg_gicp_trial_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mi355_reg_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int]
         L.mi355_reg_ndt_num_cells.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
         L.mi355_reg_ndt_cells.argtypes = [C.c_void_p] + [C.c_void_p] * 7

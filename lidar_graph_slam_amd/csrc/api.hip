@@ -13,7 +13,7 @@ thread_local KernelTimers* g_timers = nullptr;
 thread_local int g_family_override = -1;
 const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
                                                  "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
-                                                 "k_gicp_error", "k_gicp_solve+k_gicp_decide", "k_fitness",
+                                                 "k_gicp_step", "k_fitness",
                                                  "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)"};
 const Tuning& tuning() {
   static const Tuning t = [] {
@@ -26,7 +26,7 @@ const Tuning& tuning() {
     geti("MI355_CORR_STATS", v.corr_stats);
     geti("MI355_CORR_MASK", v.corr_mask);
     geti("MI355_CORR_GROUPS", v.corr_groups);
-    geti("MI355_ERR_FIRST", v.err_first);
+    getf("MI355_MASK_SLACK", v.mask_slack);
     getf("MI355_CORR_R1", v.corr_r1);
     getf("MI355_MARGIN_STEP", v.margin_step);
     geti("MI355_BLOCKS_LIN", v.blocks_lin);
@@ -788,6 +788,16 @@ extern "C" int mi355_reg_gicp_linearize(mi355_reg* reg, const double T16[16], do
   return guarded(ctx, [&] {
     reg_require(reg);
     gicp_linearize_once(ctx->stream, reg->gb, reg->src, reg->tgt, reg->gp, T16, H36, b6, error, corr);
+  });
+}
+
+extern "C" int mi355_reg_gicp_trial_cost(mi355_reg* reg, const double T_lin16[16], const double T_trial16[16], double* model_cost, double* direct_cost) {
+  if (!reg || !T_lin16 || !T_trial16 || !model_cost || !direct_cost) return MI355_EINVAL;
+  if (reg->method != MI355_METHOD_FAST_GICP) return MI355_EINVAL;
+  mi355_ctx* ctx = reg->ctx;
+  return guarded(ctx, [&] {
+    reg_require(reg);
+    gicp_trial_cost_probe(ctx->stream, reg->gb, reg->src, reg->tgt, reg->gp, T_lin16, T_trial16, model_cost, direct_cost);
   });
 }
 

@@ -140,9 +140,8 @@ struct GicpBatch {
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
   DevBuf<unsigned long long> safe_mask;  // [S][cap / 64] bit i of a pair: point i provably keeps its correspondence under EVERY trial pose of the
                                          // current LM iteration (written by the cost pass, read by the next k_gicp_correspond: gicp.hip)
-  DevBuf<double> partials;   // [S][blocks][32]
+  DevBuf<double> partials;   // [S][blocks][128]: normal equations + trial-cost model (gicp.hip kPartStride)
   DevBuf<GicpPairState> state;
-  DevBuf<unsigned char> trials;  // [S][16] LmTrial (gicp.hip)
   static constexpr int kPolls = 2;  // "any pair still active?" polls in flight (gicp_poll_active / gicp_poll_query)
   DevBuf<int> n_active;
   PinnedBuf<int> h_active;
@@ -187,6 +186,9 @@ void gicp_first_converged(hipStream_t s, GicpBatch& gb, int* out);
 // single linearisation at a given pose (parity tests), pair 0 only
 void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T16,
                          double* H36, double* b6, double* err, int* corr_caller_order);
+// linearise at T_lin, then the cost at T_trial through the trial-cost model and through a pass over the points (parity probe: gicp.hip)
+void gicp_trial_cost_probe(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T_lin16,
+                           const double* T_trial16, double* model_cost, double* direct_cost);
 
 // ---- icp.hip -------------------------------------------------------------------------------------------------
 struct IcpScratch {

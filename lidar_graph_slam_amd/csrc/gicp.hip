@@ -2,14 +2,14 @@
 // batched Levenberg-Marquardt.  One launch covers every scan pair of the batch (blockIdx.y = pair).
 //
 // Per outer iteration (LsqRegistration::step_lm):
-//   k_gicp_linearize  F3+F4 fused: fp32 transform -> exact 1-NN in the target voxel-hash -> RCR = C_B + R C_A R^T ->
-//                     Mahalanobis = RCR^-1 -> residual (fp64 transform) -> 21+6+1 normal-equation terms, accumulated
-//                     in fp64 registers, reduced by wave shuffles + LDS to ONE partial per block (fixed order =>
-//                     bitwise reproducible).  Writes the correspondence and the Mahalanobis matrix (28 B/pt) for F5.
-//   k_gicp_solve      per pair: sums the partials, lambda init, LDL^T solve of (H + lambda I) d = -b, se3_exp, trial pose.
-//   k_gicp_error      F5 compute_error at the trial pose with frozen correspondences / Mahalanobis.
-//   k_gicp_decide     rho test, accept / reject (rejected trials are re-evaluated inside this block: rare path),
-//                     lambda update, convergence test, iteration bookkeeping — no host round trip.
+//   k_gicp_correspond(_tile)  F3: fp32 transform -> exact 1-NN in the target voxel-hash, incrementally (search margins).
+//   k_gicp_linearize  F4: RCR = C_B + R C_A R^T -> Mahalanobis = RCR^-1 -> residual (fp64 transform) -> 21+6+1 normal-equation terms,
+//                     accumulated in fp64 registers, reduced by wave shuffles + LDS to ONE partial per block (fixed order =>
+//                     bitwise reproducible) + the 72 sums of the trial-cost model on the matrix cores (F5, see kModelSlot) + the
+//                     search-margin bits of the next k_gicp_correspond.  Writes the Mahalanobis matrix (24 B/pt).
+//   k_gicp_step       per pair: sums the partials, lambda init, LDL^T solve of (H + lambda I) d = -b for every lambda of step_lm's
+//                     sequence, se3_exp, trial poses, their costs (F5 compute_error, through the model), rho test, accept / reject,
+//                     lambda update, convergence test, iteration bookkeeping — no host round trip, no pass over the points.
 // Algorithmic HBM bytes of k_gicp_linearize per source point: src pt 16 + src cov 24 + tgt pt 16 + tgt cov 24 = 80 B.
 #include "engine.hpp"
 #include "grid.hpp"
@@ -25,18 +25,18 @@ struct GicpPairState {
   double y0, yi, lambda, nu;
   double final_H[36];
   double last_error;
-  int iter, trial, active, converged, n_inliers, lm_failed, need_error, status;
+  int iter, trial, active, converged, n_inliers, lm_failed, status;
   double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
   int first_conv;    // iterations run when is_converged first held (-1: never) - what fast_gicp runs without force_iterations
   int mask_valid;    // the "safe" bits of this pair (GicpBatch::safe_mask) hold for the pose the next k_gicp_correspond will see
-  float slack_rot, slack_trans;  // a point at distance r from the origin moves by at most slack_rot * r + slack_trans between x0 and ANY
-                                 // trial pose of the current iteration (k_gicp_solve)
+  float slack_rot, slack_trans;  // the budget of the current iteration: its search-margin bits hold while no trial pose moves a point at distance r
+                                 // from the origin by more than slack_rot * r + slack_trans (k_gicp_step sets and checks it; < 0: none yet)
 };
 
 // One Levenberg-Marquardt trial step.  step_lm's trial sequence is fully determined by (H, b, lambda): trial t uses
-// lambda_t = lambda * 2 * 4 * ... * 2^t, so ALL trial poses are computed up front, ONE pass over the points evaluates all
-// their costs (10x the flops — the chip has them — but 1x the memory traffic), and the decision walks the trials in order.
-// Same result as the sequential loop, but no data-dependent number of passes over the points.
+// lambda_t = lambda * 2 * 4 * ... * 2^t, so ALL trial poses are computed up front (one lane each), their costs come from the sums
+// of the linearize pass (kModelSlot), and the decision walks the trials in order.
+// Same result as the sequential loop, but no data-dependent number of passes over the points - none at all.
 struct LmTrial {
   Pose xi, delta;
   double d[6];
@@ -49,9 +49,29 @@ struct GicpDevParams {
   float max_corr_d2;
 };
 
-constexpr int kNAcc = 29;      // 6 Hrr + 9 Hrt + 6 Htt + 6 b + 1 cost + 1 inlier count
-constexpr int kPartStride = 64;  // doubles per (pair, block): 0..28 linearize, 32..47 one cost per LM trial
-constexpr int kTrialSlot = 32;
+constexpr int kNLin = 29;       // 6 Hrr + 9 Hrt + 6 Htt + 6 b + 1 cost + 1 inlier count
+constexpr int kNAcc = kNLin + 12;  // + the 12 sums of the trial-cost model that are kept in registers (below)
+constexpr int kPartStride = 128;  // doubles per (pair, block): 0..40 the register sums, 48..111 the 8 x 8 tile of the matrix cores
+constexpr int kModelSlot = 48;
+// The cost of an LM trial without a pass over the points.  With the correspondences and Mahalanobis matrices of the iteration frozen
+// (FastGICP::compute_error), the cost at the trial pose x_t = delta_t x0 is a quadratic form of W = [dR - I | dt] (3 x 4):
+//   d_t = q - x_t p = d0 - W a~        a~ = (x0 p, 1), d0 = q - x0 p (the residual linearize already has)
+//   e_t = sum d_t^T M d_t = y0 - 2 <W, L> + sum_{r,s,c,e} W_rc W_se Q[rs][ce]
+//   L[r][c] = sum (M d0)_r a~_c   (12 sums)        Q[rs][ce] = sum M_rs a~_c a~_e   (6 x 10 sums)
+// - 72 sums over the points that do not depend on the trial.  k_gicp_linearize accumulates them in the pass it makes anyway, and
+// k_gicp_step prices all the trials of step_lm from them: the cost pass (56 B per point and iteration, fp64-issue-bound on ten
+// trials) is gone.  It is the same function of the pose as the reference's loop, evaluated as (decrease from y0), which is better
+// conditioned than the difference of two sums the reference forms for its rho test.
+// Where the 72 sums live: as the 9 x 10 matrix "model" (rows M_xx M_xy M_xz M_yy M_yz M_zz (M d0)_x (M d0)_y (M d0)_z, columns ax ax,
+// ax ay, ax az, ay ay, ay az, az az, ax, ay, az, 1; a = x0 p) they are
+//   - an 8 x 8 outer product per point on the matrix cores: rows M (6), (M d0)_x, (M d0)_y; columns ax ax, ax ay, ax az, ay ay, ay az,
+//     ax, ay, az (one v_mfma_f64_16x16x4_f64 takes EIGHT points: four in its rows / columns 0-7, four in 8-15; the off-diagonal
+//     blocks mix points and are ignored),
+//   - 12 more fp64 accumulators per lane: M x az az (6), sum M d0 (3), (M d0)_z x (ax, ay, az) (3),
+//   - and sum M itself, which the normal equations already hold (H_tt).
+constexpr int kMfmaDim = 8, kNMfma = kMfmaDim * kMfmaDim;
+constexpr int kModelRows = 9, kModelCols = 10, kNModel = kModelRows * kModelCols;
+constexpr int kFeatStride = 9;  // LDS row stride of a point's 8 factors (doubles; odd: the lanes of a wave write whole rows)
 constexpr int kGicpBlock = 256;
 constexpr int kMaxTrials = 16;  // lm_max_iterations is capped here (fast_gicp default 10)
 
@@ -92,7 +112,6 @@ void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_g
   gb.safe_mask.ensure((size_t)S * (size_t)div_up((long)cap, 64));
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
-  gb.trials.ensure((size_t)S * kMaxTrials * sizeof(LmTrial));
   gb.n_active.ensure(GicpBatch::kPolls);
   gb.h_active.ensure(GicpBatch::kPolls);
   gb.fit_partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * 2);
@@ -148,12 +167,12 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   s.lambda = -1.0;
   s.nu = 2.0;
   s.last_error = 0;
-  s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.need_error = 0; s.status = MI355_PAIR_OK;
+  s.iter = 0; s.trial = 0; s.active = 1; s.converged = 0; s.n_inliers = 0; s.lm_failed = 0; s.status = MI355_PAIR_OK;
   if (scount && (scount[p] < k_min || tcount[tgt_of_src[p]] < k_min)) { s.active = 0; s.status = MI355_PAIR_TOO_FEW_POINTS; }
   s.last_step = 1.0e9;
   s.first_conv = -1;
   s.mask_valid = 0;
-  s.slack_rot = s.slack_trans = 0.f;
+  s.slack_rot = s.slack_trans = -1.f;
   st[p] = s;
 }
 
@@ -186,17 +205,22 @@ __device__ __forceinline__ double cost64(double ex, double ey, double ez, float 
   return ex * a + ey * b + ez * c;
 }
 
-__device__ __forceinline__ void residual(const Pose& x, const float4& p, const float4& q, float& ax, float& ay, float& az, float& ex, float& ey,
-                                         float& ez, double& dex, double& dey, double& dez) {
+__device__ __forceinline__ void residual64(const Pose& x, const float4& p, const float4& q, double& dax, double& day, double& daz, float& ax, float& ay,
+                                           float& az, float& ex, float& ey, float& ez, double& dex, double& dey, double& dez) {
 #pragma clang fp contract(fast)
   // transed_mean_A = trans * mean_A in fp64 (as upstream); the small residual is then handed to fp32
   const double px = (double)p.x, py = (double)p.y, pz = (double)p.z;
-  const double dax = x.R[0] * px + x.R[1] * py + x.R[2] * pz + x.t[0];
-  const double day = x.R[3] * px + x.R[4] * py + x.R[5] * pz + x.t[1];
-  const double daz = x.R[6] * px + x.R[7] * py + x.R[8] * pz + x.t[2];
+  dax = x.R[0] * px + x.R[1] * py + x.R[2] * pz + x.t[0];
+  day = x.R[3] * px + x.R[4] * py + x.R[5] * pz + x.t[1];
+  daz = x.R[6] * px + x.R[7] * py + x.R[8] * pz + x.t[2];
   ax = (float)dax; ay = (float)day; az = (float)daz;
   dex = (double)q.x - dax; dey = (double)q.y - day; dez = (double)q.z - daz;
   ex = (float)dex; ey = (float)dey; ez = (float)dez;
+}
+__device__ __forceinline__ void residual(const Pose& x, const float4& p, const float4& q, float& ax, float& ay, float& az, float& ex, float& ey,
+                                         float& ez, double& dex, double& dey, double& dez) {
+  double dax, day, daz;
+  residual64(x, p, q, dax, day, daz, ax, ay, az, ex, ey, ez, dex, dey, dez);
 }
 
 // ---- correspondence search of one source point -----------------------------------------------------------------------
@@ -1035,14 +1059,33 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 // F4 linearize given the correspondences: Mahalanobis + normal equations, a pure streaming pass — per source point it
 // reads src pt 16 + src cov 24(32) + tgt pt 16 + tgt cov 24(32) B (the 80 algorithmic bytes of SURVEY.md §8d) and the
 // 4-byte correspondence, writes the 24(32)-byte Mahalanobis matrix, and accumulates 21+6+1 terms in fp64 registers.
+// `model` (LM): the pass also accumulates the 72 sums of the trial-cost model (see kModelSlot) - 63 more fp64 accumulators per lane
+// would halve the kernel's occupancy, so most of them are an outer product per point on the matrix cores: the lanes of a wave leave the
+// 8 + 8 factors of their points in LDS, and 8 v_mfma_f64_16x16x4_f64 (8 points each: A = factors of the Mahalanobis side, B = of the
+// transformed point) add the 8 x 8 products of all 64 points to an accumulator tile of 4 doubles per lane; 12 sums stay in registers.
+// `safe_mask` (LM, pairs that track search margins): the pass marks the points whose margin survives a move of the pose by the slack
+// k_gicp_step has budgeted for this iteration's trials (slack_rot / slack_trans of the pair's state; k_gicp_step validates the
+// budget against the trials it then makes) - the next k_gicp_correspond reads those bits instead of the points.
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+#ifndef LIN_ABLATE
+#define LIN_ABLATE 0  // timing experiments only (wrong results): 1 no MFMA, 2 no LDS reads either, 3 no model at all, 4 no margin bits
+#endif
+#ifndef LIN_OCC
+#define LIN_OCC 2  // resident blocks per CU (= waves per SIMD) the register allocation aims at
+#endif
 template <int kLinPointsPerThread>
-__global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __restrict__ spts, const Cov6* __restrict__ scov,
+__global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const float4* __restrict__ spts, const Cov6* __restrict__ scov,
                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
                                                                const Cov6* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S) {
+                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S, int model,
+                                                               const float4* __restrict__ qsearch, unsigned long long* __restrict__ safe_mask,
+                                                               size_t mask_words, double margin_step) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
-  __shared__ double smem[4 * kNAcc];
+  constexpr int kWaves = kGicpBlock / kWave;
+  constexpr int kFeat = 2 * kWave * kFeatStride;
+  __shared__ double smem[kWaves * kNAcc];
+  __shared__ double feat[kWaves][kFeat];  // per wave: the factors of its 64 points; at the end: its accumulator tile
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
@@ -1056,15 +1099,29 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
 #pragma unroll
   for (int k = 0; k < 9; k++) Rf[k] = (float)x0.R[k];
   const size_t so = (size_t)pair * scap;
+  const float slack_rot = st->slack_rot, slack_trans = st->slack_trans;
+  const bool mark = LIN_ABLATE != 4 && model && safe_mask != nullptr && st->last_step < margin_step && slack_rot >= 0.f;
+  if (LIN_ABLATE == 3) model = 0;
+  float Tf0[12];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) Tf0[4 * r + c] = Rf[3 * r + c];
+    Tf0[4 * r + 3] = (float)x0.t[r];
+  }
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
+  mfma_acc_t macc = {0.0, 0.0, 0.0, 0.0};
+  const int lane = lane_id(), wv = wave_id();
+  double* featA = feat[wv] + lane * kFeatStride;
+  double* featB = feat[wv] + kWave * kFeatStride + lane * kFeatStride;
   // Software pipeline over the block's tiles: the correspondence index, the source point and its covariance of the NEXT
   // tile are loaded while the current tile is computed, so the dependent gathers (target point / covariance at corr[i])
   // of a tile are issued as soon as its loop iteration starts — one exposed memory latency per tile instead of two.
   struct Pre {
     int j;
-    float4 p;
+    float4 p, qs;
     Cov6 c;
   };
   auto preload = [&](int base, int u) -> Pre {
@@ -1075,6 +1132,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
       r.j = corr[so + i];
       r.p = spts[so + i];
       r.c = scov[so + i];
+      if (mark) r.qs = qsearch[so + i];
     }
     return r;
   };
@@ -1098,52 +1156,105 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
       const int j = cur[u].j;
-      if (j < 0) continue;  // past the end, or no correspondence
       const float4 p = cur[u].p;
-      const Sym3<float> CA = cov6_unpack(cur[u].c);
-      const Sym3<float> CB = cov6_unpack(tcv[u]);
-      Sym3<float> RCR = sym3_rotate(Rf, CA);
-      RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
-      const Sym3<float> M = sym3_inverse(RCR);
-      mahal[so + i] = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
-      float ax, ay, az, ex, ey, ez;
-      double dex, dey, dez;
-      residual(x0, p, tq[u], ax, ay, az, ex, ey, ez, dex, dey, dez);
-      const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
-      const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
-      const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
-      // MS = M * skew(a)
-      const float m0[3] = {M.xx, M.xy, M.xz}, m1[3] = {M.xy, M.yy, M.yz}, m2[3] = {M.xz, M.yz, M.zz};
-      float MS[3][3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const float* mr = (r == 0) ? m0 : ((r == 1) ? m1 : m2);
-        MS[r][0] = mr[1] * az - mr[2] * ay;
-        MS[r][1] = mr[2] * ax - mr[0] * az;
-        MS[r][2] = mr[0] * ay - mr[1] * ax;
+      if (mark) {
+        // Which points keep their correspondence wherever this iteration's step ends?  The last search of a point left a margin
+        // (k_gicp_correspond); a point at x0 p moves by at most slack_rot |x0 p| + slack_trans under any pose within the budget, so
+        // "moved so far + that < margin" settles it for the pose the next iteration linearises at - one bit per point, and the next
+        // k_gicp_correspond reads the bits (1/128 of the bytes of its margin check) instead of the points and their stored queries.
+        bool safe = i >= n;  // (past the end: nothing to look at)
+        if (i < n) {
+          const float4 qs = cur[u].qs;
+          const float qx = transform_row(Tf0, p.x, p.y, p.z), qy = transform_row(Tf0 + 4, p.x, p.y, p.z), qz = transform_row(Tf0 + 8, p.x, p.y, p.z);
+          // (no square roots: |x0 p| <= its 1-norm, and "moved < budget" is compared squared)
+          const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
+          const float budget = qs.w - ((slack_rot * reach + slack_trans) * (1.f + 1e-5f) + 2.0e-5f);
+          safe = isfinite(reach) && budget > 0.f && dist2f(qx, qy, qz, qs.x, qs.y, qs.z) < budget * budget * (1.f - 1e-6f);
+        }
+        const unsigned long long bits = __ballot(safe);
+        if (lane == 0) safe_mask[(size_t)pair * mask_words + (size_t)((base + u * kGicpBlock) / kWave + wv)] = bits;
       }
-      // Hrr = skew(a)^T * MS  (symmetric)
-      acc[0] += (double)(az * MS[1][0] - ay * MS[2][0]);
-      acc[1] += (double)(az * MS[1][1] - ay * MS[2][1]);
-      acc[2] += (double)(az * MS[1][2] - ay * MS[2][2]);
-      acc[3] += (double)(ax * MS[2][1] - az * MS[0][1]);
-      acc[4] += (double)(ax * MS[2][2] - az * MS[0][2]);
-      acc[5] += (double)(ay * MS[0][2] - ax * MS[1][2]);
-      // Hrt[i][c] = -(MS)[c][i]
+      const bool has = j >= 0;  // (not past the end, and a correspondence)
+      if (has) {
+        const Sym3<float> CA = cov6_unpack(cur[u].c);
+        const Sym3<float> CB = cov6_unpack(tcv[u]);
+        Sym3<float> RCR = sym3_rotate(Rf, CA);
+        RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
+        const Sym3<float> M = sym3_inverse(RCR);
+        mahal[so + i] = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
+        float ax, ay, az, ex, ey, ez;
+        double dax, day, daz, dex, dey, dez;
+        residual64(x0, p, tq[u], dax, day, daz, ax, ay, az, ex, ey, ez, dex, dey, dez);
+        const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
+        const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
+        const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
+        // MS = M * skew(a)
+        const float m0[3] = {M.xx, M.xy, M.xz}, m1[3] = {M.xy, M.yy, M.yz}, m2[3] = {M.xz, M.yz, M.zz};
+        float MS[3][3];
 #pragma unroll
-      for (int i2 = 0; i2 < 3; i2++)
+        for (int r = 0; r < 3; r++) {
+          const float* mr = (r == 0) ? m0 : ((r == 1) ? m1 : m2);
+          MS[r][0] = mr[1] * az - mr[2] * ay;
+          MS[r][1] = mr[2] * ax - mr[0] * az;
+          MS[r][2] = mr[0] * ay - mr[1] * ax;
+        }
+        // Hrr = skew(a)^T * MS  (symmetric)
+        acc[0] += (double)(az * MS[1][0] - ay * MS[2][0]);
+        acc[1] += (double)(az * MS[1][1] - ay * MS[2][1]);
+        acc[2] += (double)(az * MS[1][2] - ay * MS[2][2]);
+        acc[3] += (double)(ax * MS[2][1] - az * MS[0][1]);
+        acc[4] += (double)(ax * MS[2][2] - az * MS[0][2]);
+        acc[5] += (double)(ay * MS[0][2] - ax * MS[1][2]);
+        // Hrt[i][c] = -(MS)[c][i]
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc[6 + 3 * i2 + c] -= (double)MS[c][i2];
-      // Htt = M
-      acc[15] += (double)M.xx; acc[16] += (double)M.xy; acc[17] += (double)M.xz;
-      acc[18] += (double)M.yy; acc[19] += (double)M.yz; acc[20] += (double)M.zz;
-      // b = J^T M e
-      acc[21] += (double)(az * Me1 - ay * Me2);
-      acc[22] += (double)(ax * Me2 - az * Me0);
-      acc[23] += (double)(ay * Me0 - ax * Me1);
-      acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
-      acc[27] += cost64(dex, dey, dez, M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
-      acc[28] += 1.0;
+        for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc[6 + 3 * i2 + c] -= (double)MS[c][i2];
+        // Htt = M
+        acc[15] += (double)M.xx; acc[16] += (double)M.xy; acc[17] += (double)M.xz;
+        acc[18] += (double)M.yy; acc[19] += (double)M.yz; acc[20] += (double)M.zz;
+        // b = J^T M e
+        acc[21] += (double)(az * Me1 - ay * Me2);
+        acc[22] += (double)(ax * Me2 - az * Me0);
+        acc[23] += (double)(ay * Me0 - ax * Me1);
+        acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
+        acc[27] += cost64(dex, dey, dez, M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
+        acc[28] += 1.0;
+        if (model) {
+#pragma clang fp contract(fast)
+          const double mxx = (double)M.xx, mxy = (double)M.xy, mxz = (double)M.xz, myy = (double)M.yy, myz = (double)M.yz, mzz = (double)M.zz;
+          const double md0x = mxx * dex + mxy * dey + mxz * dez;  // M d0 (the same products as cost64)
+          const double md0y = mxy * dex + myy * dey + myz * dez;
+          const double md0z = mxz * dex + myz * dey + mzz * dez;
+          // (straight to LDS: the factors kept in registers until the whole wave is here cost the kernel a wave per SIMD)
+          featA[0] = mxx; featA[1] = mxy; featA[2] = mxz; featA[3] = myy; featA[4] = myz; featA[5] = mzz; featA[6] = md0x; featA[7] = md0y;
+          featB[0] = dax * dax; featB[1] = dax * day; featB[2] = dax * daz; featB[3] = day * day; featB[4] = day * daz;
+          featB[5] = dax; featB[6] = day; featB[7] = daz;
+          const double azaz = daz * daz;
+          acc[kNLin + 0] += mxx * azaz; acc[kNLin + 1] += mxy * azaz; acc[kNLin + 2] += mxz * azaz;
+          acc[kNLin + 3] += myy * azaz; acc[kNLin + 4] += myz * azaz; acc[kNLin + 5] += mzz * azaz;
+          acc[kNLin + 6] += md0x; acc[kNLin + 7] += md0y; acc[kNLin + 8] += md0z;
+          acc[kNLin + 9] += md0z * dax; acc[kNLin + 10] += md0z * day; acc[kNLin + 11] += md0z * daz;
+        }
+      } else if (model) {
+#pragma unroll
+        for (int k = 0; k < kMfmaDim; k++) { featA[k] = 0.0; featB[k] = 0.0; }
+      }
+      if (model && LIN_ABLATE != 2 && __ballot(has)) {  // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rows are read by other lanes
+        // product step s takes points 8 s .. 8 s + 7: lane (r = lane & 15, k = lane >> 4) holds factor r & 7 of point 8 s + k (r < 8:
+        // rows / columns 0-7 of the tile) or of point 8 s + 4 + k (rows / columns 8-15)
+        const int r = lane & 15, kq = lane >> 4;
+        const double* rowA = feat[wv] + (kq + 4 * (r >> 3)) * kFeatStride + (r & 7);
+        const double* rowB = rowA + kWave * kFeatStride;
+#pragma unroll 4
+        for (int step = 0; step < kWave / 8; step++) {
+          const double a = rowA[step * 8 * kFeatStride], b = rowB[step * 8 * kFeatStride];
+          if (LIN_ABLATE == 1) macc[0] += a * b;
+          else macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile overwrites the rows
+      }
     }
   }
   block_sum<kNAcc, 4>(acc, smem);
@@ -1151,6 +1262,20 @@ __global__ __launch_bounds__(kGicpBlock) void k_gicp_linearize(const float4* __r
     double* out = partials + ((size_t)pair * G + bx) * kPartStride;
 #pragma unroll
     for (int k = 0; k < kNAcc; k++) out[k] = acc[k];
+  }
+  if (model) {
+    // the four waves' accumulator tiles -> one 8 x 8: element v of lane l is row (l >> 4) + 4 v, column l & 15 (the f64 MFMA's own map);
+    // the two diagonal blocks hold the two halves of the points
+#pragma unroll
+    for (int v = 0; v < 4; v++) feat[wv][((lane >> 4) + 4 * v) * 16 + (lane & 15)] = macc[v];
+    __syncthreads();
+    if (threadIdx.x < kNMfma) {
+      const int i = threadIdx.x / kMfmaDim, j = threadIdx.x % kMfmaDim;
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) sum += feat[w][i * 16 + j] + feat[w][(i + 8) * 16 + j + 8];
+      partials[((size_t)pair * G + bx) * kPartStride + kModelSlot + threadIdx.x] = sum;
+    }
   }
 }
 
@@ -1178,7 +1303,6 @@ __device__ __forceinline__ void lm_make_trial(const double* H, const double* b, 
 // After a step_optimize completed: iteration bookkeeping + convergence (F6).
 __device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParams& P, bool ok) {
   s.iter += 1;
-  s.need_error = 0;
   if (!ok) {  // "lm not converged!!" -> break (benchmark mode keeps iterating: fixed work per pair)
     s.lm_failed = 1;
     if (!P.force_iterations || s.iter >= P.max_iterations) s.active = 0;
@@ -1212,18 +1336,79 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ p, int
   return s;
 }
 
-__global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ state, LmTrial* __restrict__ trials, const double* __restrict__ partials,
-                                                   int G, GicpDevParams P, double margin_step = -1.0) {
-  __shared__ double sums[kPartStride];
+// Entry idx = row * 10 + column of the 9 x 10 model matrix (see kModelSlot) from the summed partials of a pair.
+MI_HD double model_entry(const double* sums, int idx) {
+  const int r = idx / kModelCols, c = idx % kModelCols;
+  const double* mf = sums + kModelSlot;  // the 8 x 8 tile
+  if (r < 6) {
+    if (c < 5) return mf[r * kMfmaDim + c];
+    if (c == 5) return sums[kNLin + r];
+    if (c < 9) return mf[r * kMfmaDim + c - 1];
+    return sums[15 + r];  // sum M = H_tt
+  }
+  if (c < 6) return 0.0;  // (never read)
+  if (r < 8) return c < 9 ? mf[r * kMfmaDim + c - 1] : sums[kNLin + 6 + (r - 6)];
+  return c < 9 ? sums[kNLin + 9 + (c - 6)] : sums[kNLin + 8];
+}
+
+// The decrease y0 - e_t of the cost at the trial pose delta x0, from the sums of k_gicp_linearize (see kModelSlot): m = the 9 x 10
+// tile, rows M_xx M_xy M_xz M_yy M_yz M_zz (M d0)_xyz, columns ax ax, ax ay, ax az, ay ay, ay az, az az, ax, ay, az, 1.
+MI_HD double model_decrease(const Pose& delta, const double* m) {
+  double W[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) W[r][c] = delta.R[3 * r + c] - ((r == c) ? 1.0 : 0.0);
+    W[r][3] = delta.t[r];
+  }
+  const int kSym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  const int kSym4[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+  double lin = 0.0, quad = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) lin += W[r][c] * m[(6 + r) * kModelCols + kSym4[c][3]];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; s2++) {
+      double q = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) q += W[r][c] * W[s2][e] * m[kSym3[r][s2] * kModelCols + kSym4[c][e]];
+      quad += q;
+    }
+  return 2.0 * lin - quad;
+}
+
+// One LsqRegistration::step_lm per pair, from the sums of k_gicp_linearize: the normal equations, every trial of the lambda sequence
+// (lane t: LDL^T solve, se3_exp, trial pose, its cost through the model), then lane 0 walks the trials as step_lm does - accept /
+// reject by rho, lambda update, convergence test, iteration bookkeeping - no host round trip and no pass over the points.
+// sums_only: the normal equations and y0 go to the state and nothing else happens (gicp_linearize_once).
+// margin_step >= 0: the search-margin bits k_gicp_linearize wrote for this pair hold if the trials stayed inside the slack it had
+// budgeted; the budget of the next iteration is slack_factor x what these trials took.
+__global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ state, const double* __restrict__ partials, int G, GicpDevParams P,
+                                                  int sums_only, double margin_step, float slack_factor) {
+  __shared__ double sums[kPartStride], mdl[kNModel];
   __shared__ double sH[36], sb[6], slambda;
   __shared__ Pose sx0;
-  __shared__ int do_trials;
+  __shared__ LmTrial s_tr[kMaxTrials];
+  __shared__ double dec[kMaxTrials];  // cost decrease y0 - e_t of every trial
+  __shared__ int s_accepted;
   const int pair = blockIdx.x;
   GicpPairState* st = state + pair;
   if (!st->active) return;
   const int l = threadIdx.x;
-  if (l < kNAcc) sums[l] = sum_partials(partials + (size_t)pair * G * kPartStride + l, G);
+  const double* mine = partials + (size_t)pair * G * kPartStride;
+  const bool lm = P.optimizer != MI355_OPT_GN && !sums_only;
+  sums[l] = (l < (lm ? kNAcc : kNLin) || (lm && l >= kModelSlot)) ? sum_partials(mine + l, G) : 0.0;
+  sums[kWave + l] = (lm && kWave + l < kModelSlot + kNMfma) ? sum_partials(mine + kWave + l, G) : 0.0;
   __syncthreads();
+  if (lm) {
+    mdl[l] = model_entry(sums, l);
+    if (kWave + l < kNModel) mdl[kWave + l] = model_entry(sums, kWave + l);
+  }
   if (P.optimizer == MI355_OPT_GN) {
     if (l == 0) {
       st->mask_valid = 0;
@@ -1231,14 +1416,16 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
       unpack_normal_equations(sums, s.H, s.b);
       s.y0 = sums[27];
       s.n_inliers = (int)(sums[28] + 0.5);
-      double nb[6];
-      for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
-      ldlt6_solve(s.H, nb, s.d);
-      s.delta = se3_exp(s.d);
-      s.x0 = pose_compose(s.delta, s.x0);
-      for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
-      s.last_error = s.y0;
-      finish_step(s, P, true);
+      if (!sums_only) {
+        double nb[6];
+        for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
+        ldlt6_solve(s.H, nb, s.d);
+        s.delta = se3_exp(s.d);
+        s.x0 = pose_compose(s.delta, s.x0);
+        for (int i = 0; i < 36; i++) s.final_H[i] = s.H[i];
+        s.last_error = s.y0;
+        finish_step(s, P, true);
+      }
       *st = s;
     }
     return;
@@ -1251,232 +1438,56 @@ __global__ __launch_bounds__(64) void k_gicp_solve(GicpPairState* __restrict__ s
       double mx = 0;
       for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(sH[7 * i]));
       lam = P.lm_init_lambda_factor * mx;
-      st->lambda = lam;
+      if (!sums_only) st->lambda = lam;
     }
     slambda = lam;
     st->y0 = sums[27];
     st->n_inliers = (int)(sums[28] + 0.5);
-    st->need_error = 1;
-    do_trials = 1;
+    s_accepted = 0;
   }
   if (l < 9) sx0.R[l] = st->x0.R[l];
   else if (l < 12) sx0.t[l - 9] = st->x0.t[l - 9];
   __syncthreads();
   if (l < 36) st->H[l] = sH[l];
   if (l < 6) st->b[l] = sb[l];
+  if (sums_only) return;
   float slack_r = 0.f, slack_t = 0.f;
-  if (do_trials && l < P.lm_max_iterations) {
+  if (l < P.lm_max_iterations) {
     // lambda of trial l: step_lm multiplies by nu = 2, 4, 8, ... after each rejection
     double lam = slambda, nu = 2.0;
     for (int i = 0; i < l; i++) { lam = nu * lam; nu = 2 * nu; }
     LmTrial tr;
     lm_make_trial(sH, sb, sx0, lam, tr);
-    trials[(size_t)pair * kMaxTrials + l] = tr;
+    s_tr[l] = tr;
+    dec[l] = model_decrease(tr.delta, mdl);
     // how far a point can move between x0 and this trial pose: x_t p - x0 p = (dR - I)(x0 p) + dt, so at most
-    // ||dR - I||_F |x0 p| + |dt|.  The largest of both over the trials goes to the pair's state: the cost pass marks the points whose
-    // search margin survives ANY of these poses, and the next k_gicp_correspond does not look at them again.
+    // ||dR - I||_F |x0 p| + |dt|
     double fr = 0, ft = 0;
     for (int k = 0; k < 9; k++) { const double v = tr.delta.R[k] - ((k % 4 == 0) ? 1.0 : 0.0); fr += v * v; }
     for (int k = 0; k < 3; k++) ft += tr.delta.t[k] * tr.delta.t[k];
     slack_r = (float)(sqrt(fr) * (1.0 + 1e-6)) + 1e-12f;
     slack_t = (float)(sqrt(ft) * (1.0 + 1e-6)) + 1e-12f;
   }
-  if (do_trials) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      slack_r = fmaxf(slack_r, __shfl_xor(slack_r, off, kWave));
-      slack_t = fmaxf(slack_t, __shfl_xor(slack_t, off, kWave));
-    }
-    if (l == 0) {
-      st->slack_rot = slack_r;
-      st->slack_trans = slack_t;
-      // (only a pair that tracks margins has use for the bits: while it still moves by centimetres every point is searched anyway,
-      // and the cost pass is spared the 16 B per point of the stored queries)
-      st->mask_valid = (st->last_step < margin_step) ? 1 : 0;
-    }
+  for (int off = 32; off > 0; off >>= 1) {
+    slack_r = fmaxf(slack_r, __shfl_xor(slack_r, off, kWave));
+    slack_t = fmaxf(slack_t, __shfl_xor(slack_t, off, kWave));
   }
-}
-
-__device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const Cov6& m) {
-  float ax, ay, az, ex, ey, ez;
-  double dex, dey, dez;
-  residual(x, p, q, ax, ay, az, ex, ey, ez, dex, dey, dez);
-  return cost64(dex, dey, dez, m.v[0], m.v[1], m.v[2], m.v[3], m.v[4], m.v[5]);
-}
-
-// F5 compute_error for every LM trial pose in one pass (frozen correspondences and Mahalanobis matrices).
-// All LM trial costs in one pass.  Per tile every thread keeps kErrPoints points (source, correspondent, Mahalanobis) in
-// registers and walks the trials in a rolled loop; a trial pose is wave-uniform and comes through scalar loads into SGPRs,
-// so the register budget is the points plus NT accumulators (the first version kept all NT poses in VGPRs: 256 VGPRs +
-// AGPRs, one wave per SIMD, and spent its time waiting on the point loads with nothing to overlap them).
-constexpr int kErrPoints = 2;
-// The kernel is VALU-bound, not memory-bound: the residual and the quadratic form are fp64 without contraction (the oracle's
-// arithmetic) — 83 v_add_f64 / v_mul_f64 per trial and pair of points, 10 trials: most of its 0.30 ms per 1 024-pair launch is
-// issue time (0.38 ms before the conversions were hoisted out of the trial loop and the sums moved to LDS).  LM accepts its FIRST trial far more often than not, so a batch evaluates trial 0 alone
-// (`want` = 1, NT = 1: a streaming pass), k_gicp_decide(phase 0) takes it or marks the pair (need_error = 2), and only the marked
-// pairs pay for trials 1 .. in a second launch (`want` = 2).  Trials [t0, min(t0 + NT, n_trials)) of every pair whose
-// need_error == want.
-template <int NT>
-__global__ __launch_bounds__(kGicpBlock) void k_gicp_error(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
-                                                           const float4* __restrict__ tpts, size_t tcap, const int* __restrict__ tgt_of_src,
-                                                           const GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
-                                                           const int* __restrict__ corr, const Cov6* __restrict__ mahal,
-                                                           double* __restrict__ partials, int t0, int n_trials, int want,
-                                                           const float4* __restrict__ qsearch, unsigned long long* __restrict__ safe_mask, size_t mask_words) {
-  __shared__ double smem[4 * NT];
-  __shared__ double accL[NT > 1 ? NT : 1][NT > 1 ? kGicpBlock : 1];  // per-thread sums of the trials (NT > 1)
-  const int pair = blockIdx.y;
-  const GicpPairState* st = state + pair;
-  if (!st->active || st->need_error != want) return;
-  if constexpr (NT > 1) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) accL[t][threadIdx.x] = 0.0;
-  }
-  const float4* tp = tpts + (size_t)tgt_of_src[pair] * tcap;
-  const LmTrial* tr = trials + (size_t)pair * kMaxTrials + t0;
-  const int n = scount[pair];
-  const size_t so = (size_t)pair * scap;
-  const int nt = min(n_trials - t0, NT);
-  const bool mark_safe = safe_mask != nullptr && t0 == 0 && st->mask_valid;
-  float Tf0[12], slack_rot = 0.f, slack_trans = 0.f;
-  if (mark_safe) {
-    const Pose x0 = st->x0;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) Tf0[4 * r + c] = (float)x0.R[3 * r + c];
-      Tf0[4 * r + 3] = (float)x0.t[r];
-    }
-    slack_rot = st->slack_rot;
-    slack_trans = st->slack_trans;
-  }
-  double acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++) acc[t] = 0.0;
-  constexpr int kTile = kGicpBlock * kErrPoints;
-  for (int base = blockIdx.x * kTile; base < n; base += gridDim.x * kTile) {
-    float4 p[kErrPoints], q[kErrPoints];
-    Cov6 m[kErrPoints];
-    bool ok[kErrPoints];
-#pragma unroll
-    for (int u = 0; u < kErrPoints; u++) {
-      const int i = base + u * kGicpBlock + threadIdx.x;
-      const int j = (i < n) ? corr[so + i] : -1;
-      ok[u] = j >= 0;
-      const size_t ii = so + min(i, n - 1);
-      p[u] = spts[ii];
-      q[u] = tp[max(j, 0)];
-      m[u] = mahal[ii];
-    }
-    if (mark_safe) {
-      // Which points can keep their correspondence WHATEVER trial the decision takes?  The last search of a point left a margin
-      // (k_gicp_correspond); a point at x0 p moves by at most slack_rot |x0 p| + slack_trans under any trial pose (k_gicp_solve), so
-      // "moved so far + that < margin" settles it for the pose the next iteration linearises at - one bit per point, and the next
-      // k_gicp_correspond reads the bits (1/128 of the bytes of its margin check) instead of the points and their stored queries.
-#pragma unroll
-      for (int u = 0; u < kErrPoints; u++) {
-        const int i = base + u * kGicpBlock + threadIdx.x;
-        bool safe = i >= n;  // (past the end: nothing to look at)
-        if (i < n) {
-          const float4 qs = qsearch[so + i];
-          const float qx = transform_row(Tf0, p[u].x, p[u].y, p[u].z), qy = transform_row(Tf0 + 4, p[u].x, p[u].y, p[u].z),
-                      qz = transform_row(Tf0 + 8, p[u].x, p[u].y, p[u].z);
-          // (no square roots in this VALU-bound kernel: |x0 p| <= its 1-norm, and "moved < budget" is compared squared)
-          const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
-          const float budget = qs.w - ((slack_rot * reach + slack_trans) * (1.f + 1e-5f) + 2.0e-5f);
-          safe = isfinite(reach) && budget > 0.f && dist2f(qx, qy, qz, qs.x, qs.y, qs.z) < budget * budget * (1.f - 1e-6f);
-        }
-        const unsigned long long bits = __ballot(safe);
-        if (lane_id() == 0) safe_mask[(size_t)pair * mask_words + (size_t)((base + u * kGicpBlock) / kWave + wave_id())] = bits;
-      }
-    }
-    if constexpr (NT == 1) {
-      const Pose xi = tr[0].xi;  // wave-uniform: scalar loads
-#pragma unroll
-      for (int u = 0; u < kErrPoints; u++) acc[0] += ok[u] ? point_error(xi, p[u], q[u], m[u]) : 0.0;
-    } else {
-      // the fp32 -> fp64 conversions of the points and matrices once per tile, not once per trial (the compiler keeps them in the
-      // trial loop: 24 of its ~140 instructions), and the per-trial sums in LDS: a register accumulator chosen by the loop
-      // counter costs NT selects + adds per trial (30 more)
-      double pd[kErrPoints][3], qd[kErrPoints][3], md[kErrPoints][6];
-#pragma unroll
-      for (int u = 0; u < kErrPoints; u++) {
-        pd[u][0] = (double)p[u].x; pd[u][1] = (double)p[u].y; pd[u][2] = (double)p[u].z;
-        qd[u][0] = (double)q[u].x; qd[u][1] = (double)q[u].y; qd[u][2] = (double)q[u].z;
-#pragma unroll
-        for (int k = 0; k < 6; k++) md[u][k] = (double)m[u].v[k];
-      }
-#pragma unroll 1
-      for (int t = 0; t < nt; t++) {
-#pragma clang fp contract(fast)
-        const Pose x = tr[t].xi;  // wave-uniform: scalar loads
-        double e = 0.0;
-#pragma unroll
-        for (int u = 0; u < kErrPoints; u++) {
-          // residual() and cost64() on the converted operands: the same operations in the same order
-          const double dax = x.R[0] * pd[u][0] + x.R[1] * pd[u][1] + x.R[2] * pd[u][2] + x.t[0];
-          const double day = x.R[3] * pd[u][0] + x.R[4] * pd[u][1] + x.R[5] * pd[u][2] + x.t[1];
-          const double daz = x.R[6] * pd[u][0] + x.R[7] * pd[u][1] + x.R[8] * pd[u][2] + x.t[2];
-          const double ex = qd[u][0] - dax, ey = qd[u][1] - day, ez = qd[u][2] - daz;
-          const double a = md[u][0] * ex + md[u][1] * ey + md[u][2] * ez;
-          const double b = md[u][1] * ex + md[u][3] * ey + md[u][4] * ez;
-          const double c = md[u][2] * ex + md[u][4] * ey + md[u][5] * ez;
-          e += ok[u] ? (ex * a + ey * b + ez * c) : 0.0;
-        }
-        accL[t][threadIdx.x] += e;
-      }
-    }
-  }
-  if constexpr (NT > 1) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = accL[t][threadIdx.x];
-    __syncthreads();
-  }
-  // slots past the last trial hold zeros (the decision never reads them)
-  block_sum<NT, 4>(acc, smem);
-  if (threadIdx.x == 0) {
-    double* out = partials + ((size_t)pair * gridDim.x + blockIdx.x) * kPartStride + kTrialSlot + t0;
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-      if (t0 + t < kMaxTrials) out[t] = acc[t];
-  }
-}
-
-// step_lm's accept / reject walk over the pre-evaluated trials + iteration bookkeeping.
-// phase 0: only the first `first` trials have been evaluated (pairs with need_error == 1) — take one if step_lm would, else mark
-// the pair (need_error = 2) for the remaining trials and leave its state alone; phase 1: the full walk for the marked pairs;
-// phase 2: the full walk for pairs with need_error == 1 (all trials evaluated in one launch: batches of a few pairs).
-__global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ state, const LmTrial* __restrict__ trials,
-                                                    const double* __restrict__ partials, int G, GicpDevParams P, int phase, int first) {
-  static_assert(sizeof(LmTrial) == 31 * sizeof(double), "LmTrial is 31 doubles");
-  __shared__ double yi[kMaxTrials];
-  __shared__ LmTrial s_tr[kMaxTrials];  // the trials, fetched by all lanes at once (lane 0 used to walk them through dependent global loads)
-  __shared__ double s_b[6], s_y0, s_lam;
-  __shared__ int s_accepted;
-  const int pair = blockIdx.x;
-  if (!state[pair].active || state[pair].need_error != (phase == 1 ? 2 : 1)) return;
-  const int walk = (phase == 0) ? min(first, P.lm_max_iterations) : P.lm_max_iterations;
-  const int l = threadIdx.x;
-  {
-    const double* tg = reinterpret_cast<const double*>(trials + (size_t)pair * kMaxTrials);
-    double* tl = reinterpret_cast<double*>(s_tr);
-    for (int w = l; w < walk * 31; w += kWave) tl[w] = tg[w];
-    if (l < 6) s_b[l] = state[pair].b[l];
-    if (l == 6) s_y0 = state[pair].y0;
-    if (l == 7) s_lam = state[pair].lambda;
-    if (l == 8) s_accepted = 0;
-  }
-  if (l < P.lm_max_iterations) yi[l] = sum_partials(partials + (size_t)pair * G * kPartStride + kTrialSlot + l, G);
   __syncthreads();
   if (l == 0) {
-    GicpPairState& s = state[pair];  // in place: only the fields of the taken branch move (the state is 1 KB)
-    bool finished = false, marked = false;
-    double lam_next = s_lam, nu = 2.0;
-    for (int t = 0; t < walk && !finished; t++) {
+    GicpPairState& s = *st;  // in place: only the fields of the taken branch move (the state is 1 KB)
+    // the bits of this iteration's linearize pass (written only for a pair that tracked margins, under the budget in the state)
+    const bool marked = margin_step >= 0.0 && s.last_step < margin_step && s.slack_rot >= 0.f;
+    s.mask_valid = (marked && slack_r <= s.slack_rot && slack_t <= s.slack_trans) ? 1 : 0;
+    s.slack_rot = slack_factor * slack_r + 1e-9f;
+    s.slack_trans = slack_factor * slack_t + 1e-7f;
+    bool finished = false;
+    double lam_next = slambda, nu = 2.0;
+    for (int t = 0; t < P.lm_max_iterations && !finished; t++) {
       const LmTrial& tr = s_tr[t];
       double denom = 0;
-      for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - s_b[i]);
-      const double rho = (s_y0 - yi[t]) / denom;
+      for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - sb[i]);
+      const double rho = dec[t] / denom;  // (y0 - yi) / denom
       s.trial = t;
       if (rho < 0) {
         if (!P.force_iterations && is_converged(tr.delta, P.rotation_epsilon, P.transformation_epsilon)) {
@@ -1495,23 +1506,43 @@ __global__ __launch_bounds__(64) void k_gicp_decide(GicpPairState* __restrict__ 
         const double c = 2 * rho - 1;
         s.lambda = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
         s_accepted = 1;  // final_H = H: by 36 lanes, below
-        s.last_error = yi[t];
-        s.yi = yi[t];
+        s.last_error = sums[27] - dec[t];
+        s.yi = s.last_error;
         finish_step(s, P, true);
         finished = true;
       }
     }
-    if (!finished && phase == 0 && P.lm_max_iterations > walk) {  // the first trials rejected: the other trials are evaluated next
-      s.need_error = 2;
-      marked = true;
-    }
-    if (!finished && !marked) {  // every trial rejected: "lm not converged!!"
+    if (!finished) {  // every trial rejected: "lm not converged!!"
       s.lambda = lam_next;
       finish_step(s, P, false);
     }
   }
   __syncthreads();
-  if (s_accepted && l < 36) state[pair].final_H[l] = state[pair].H[l];
+  if (s_accepted && l < 36) st->final_H[l] = sH[l];
+}
+
+__device__ __forceinline__ double point_error(const Pose& x, const float4& p, const float4& q, const Cov6& m) {
+  float ax, ay, az, ex, ey, ez;
+  double dex, dey, dez;
+  residual(x, p, q, ax, ay, az, ex, ey, ez, dex, dey, dez);
+  return cost64(dex, dey, dez, m.v[0], m.v[1], m.v[2], m.v[3], m.v[4], m.v[5]);
+}
+
+// F5 compute_error as the reference writes it - a pass over the points at pose x with the frozen correspondences and Mahalanobis
+// matrices of the last linearisation.  The optimisation prices its trials through the model (k_gicp_step); this kernel is the PROBE
+// the parity tests compare that model with (gicp_cost_probe), for pair 0 of a registration object.
+__global__ __launch_bounds__(kGicpBlock) void k_gicp_cost_probe(const float4* __restrict__ spts, const int* __restrict__ scount, const float4* __restrict__ tp,
+                                                                const int* __restrict__ corr, const Cov6* __restrict__ mahal, Pose x,
+                                                                double* __restrict__ out) {
+  __shared__ double smem[4];
+  const int n = scount[0];
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * kGicpBlock + threadIdx.x; i < n; i += gridDim.x * kGicpBlock) {
+    const int j = corr[i];
+    if (j >= 0) acc[0] += point_error(x, spts[i], tp[j], mahal[i]);
+  }
+  block_sum<1, 4>(acc, smem);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc[0];
 }
 
 __global__ void k_count_active(const GicpPairState* __restrict__ st, int S, int* __restrict__ n_active) {
@@ -1576,13 +1607,16 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     }
   }
   TimedLaunch tl(KF_LINEARIZE, s);
+  const bool mask = tuning().corr_mask && search < 0;
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
-                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.blocks_lin, gb.S);
+                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.blocks_lin, gb.S,
+                     P.optimizer == MI355_OPT_LM ? 1 : 0, (const float4*)gb.qsearch.p, mask ? gb.safe_mask.p : (unsigned long long*)nullptr,
+                     (size_t)div_up((long)gb.cap, 64), (double)tuning().margin_step);
 }
 
 // ---- the LM optimisation of every pair of a batch, in three pieces a caller can interleave with those of other batches --------
 // gicp_align_begin    pair -> target map, guesses, initial state (enqueue only)
-// gicp_align_iterate  iterations [it0, it1): correspond -> linearize -> solve -> error -> decide (enqueue only; a pair that has
+// gicp_align_iterate  iterations [it0, it1): correspond -> linearize -> step (enqueue only; a pair that has
 //                     converged leaves every kernel at once, so iterations enqueued past convergence cost launches, not work)
 // gicp_poll_active    "is any pair still optimising?": the count goes to a pinned host slot behind an event that
 //                     gicp_poll_query tests WITHOUT blocking (round 3 synchronised the stream every four iterations: the one host
@@ -1616,44 +1650,12 @@ void gicp_align_begin(hipStream_t s, GicpBatch& gb, const CloudSet& src, const C
 void gicp_align_iterate(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, int it0, int it1) {
   const int S = gb.S;
   const GicpDevParams P = dev_params(p);
-  const int G = gb.blocks_lin;
+  const Tuning& tn = tuning();
   for (int it = it0; it < it1; it++) {
     launch_linearize(s, gb, src, tgt, P, it);
-    {
-      TimedLaunch tl(KF_SOLVE_DECIDE, s);
-      hipLaunchKernelGGL(k_gicp_solve, dim3(S), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, G, P,
-                         tuning().corr_mask ? (double)tuning().margin_step : -1.0);
-    }
-    if (p.optimizer == MI355_OPT_LM) {
-      auto ke = (P.lm_max_iterations <= 10) ? k_gicp_error<10> : k_gicp_error<kMaxTrials>;
-      auto error = [&](auto kernel, int t0, int t1, int want) {
-        TimedLaunch tl(KF_ERROR, s);
-        hipLaunchKernelGGL(kernel, dim3(G, S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.cap, gb.tgt_of_src.p,
-                           gb.state.p, (const LmTrial*)gb.trials.p, gb.corr.p, gb.mahal.p, gb.partials.p, t0, t1, want, (const float4*)gb.qsearch.p,
-                           tuning().corr_mask ? gb.safe_mask.p : (unsigned long long*)nullptr, (size_t)div_up((long)gb.cap, 64));
-      };
-      auto decide = [&](int phase, int first) {
-        TimedLaunch tl(KF_SOLVE_DECIDE, s);
-        hipLaunchKernelGGL(k_gicp_decide, dim3(S), dim3(64), 0, s, gb.state.p, (const LmTrial*)gb.trials.p, gb.partials.p, G, P, phase, first);
-      };
-      // The first trial alone, the rest only where it was rejected: a converging pair accepts its first trial almost always.  With
-      // forced iterations pairs keep stepping at their optimum, where no trial lowers the cost and all of them have to be evaluated
-      // anyway — measured at 1 024 pairs x 20 forced iterations, k_gicp_error + decide per step: one pass 7.2 ms, 1 / 2 / 3 / 4 first
-      // trials 7.7 / 7.4 / 7.2 / 7.1 ms — so forced iterations keep the one-pass form.
-      const int n_lm = P.lm_max_iterations;
-      int first = tuning().err_first < 0 ? (P.force_iterations ? 0 : 1) : tuning().err_first;
-      first = std::min(first, 4);
-      if (gb.S_geometry >= 8 && first >= 1 && first < n_lm) {
-        if (first == 1) error(k_gicp_error<1>, 0, 1, 1);
-        else error(k_gicp_error<4>, 0, first, 1);
-        decide(0, first);
-        error(ke, first, n_lm, 2);
-        decide(1, first);
-      } else {  // a few pairs: launch-bound, everything in one pass
-        error(ke, 0, n_lm, 1);
-        decide(2, first);
-      }
-    }
+    TimedLaunch tl(KF_STEP, s);
+    hipLaunchKernelGGL(k_gicp_step, dim3(S), dim3(64), 0, s, gb.state.p, (const double*)gb.partials.p, gb.blocks_lin, P, 0,
+                       tn.corr_mask ? (double)tn.margin_step : -1.0, tn.mask_slack);
   }
   MI_LAUNCH_CHECK();
 }
@@ -1888,7 +1890,6 @@ void gicp_first_converged(hipStream_t s, GicpBatch& gb, int* out) {
 __global__ void k_set_pose(GicpPairState* st, Pose x) {
   st[0].x0 = x;
   st[0].active = 1;
-  st[0].need_error = 0;
   st[0].lambda = -1.0;
 }
 
@@ -1932,7 +1933,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
       if (got[(size_t)i] != first[(size_t)i])
         throw ArgError(MI355_ESTATE, search == 1 ? "tile and per-lane correspondence searches disagree" : "group and per-lane correspondence searches disagree");
   }
-  hipLaunchKernelGGL(k_gicp_solve, dim3(1), dim3(64), 0, s, gb.state.p, (LmTrial*)gb.trials.p, gb.partials.p, gb.blocks_lin, P);
+  hipLaunchKernelGGL(k_gicp_step, dim3(1), dim3(64), 0, s, gb.state.p, (const double*)gb.partials.p, gb.blocks_lin, P, 1, -1.0, 0.f);
   MI_LAUNCH_CHECK();
   GicpPairState st;
   MI_HIP(hipMemcpyAsync(&st, gb.state.p, sizeof(st), hipMemcpyDeviceToHost, s));
@@ -1951,6 +1952,52 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
     MI_HIP(hipMemcpy(to.data(), tgt.orig.p, nt * sizeof(int), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) corr_caller_order[so[i]] = c[i] >= 0 ? to[c[i]] : -1;
   }
+}
+
+// Parity probe of the trial-cost model: linearise at T_lin (as gicp_linearize_once), then the cost at T_trial with those frozen
+// correspondences and Mahalanobis matrices - once through the model the optimisation uses (the sums of k_gicp_linearize), once as
+// FastGICP::compute_error writes it, a pass over the points.
+void gicp_trial_cost_probe(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T_lin16,
+                           const double* T_trial16, double* model_cost, double* direct_cost) {
+  double H[36], b[6], y0 = 0;
+  gicp_linearize_once(s, gb, src, tgt, p, T_lin16, H, b, &y0, nullptr);
+  const int G = gb.blocks_lin;
+  std::vector<double> part((size_t)G * kPartStride);
+  MI_HIP(hipMemcpyAsync(part.data(), gb.partials.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  auto to_pose = [](const double* T) {
+    Pose x;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) x.R[3 * r + c] = T[4 * r + c];
+      x.t[r] = T[4 * r + 3];
+    }
+    return x;
+  };
+  const Pose xl = to_pose(T_lin16), xt = to_pose(T_trial16);
+  Pose inv;  // xl^-1 (a rigid transform)
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) inv.R[3 * r + c] = xl.R[3 * c + r];
+  }
+  for (int r = 0; r < 3; r++) inv.t[r] = -(inv.R[3 * r] * xl.t[0] + inv.R[3 * r + 1] * xl.t[1] + inv.R[3 * r + 2] * xl.t[2]);
+  constexpr int kProbeBlocks = 64;
+  DevBuf<double> out;
+  out.ensure(kProbeBlocks);
+  hipLaunchKernelGGL(k_gicp_cost_probe, dim3(kProbeBlocks), dim3(kGicpBlock), 0, s, (const float4*)src.pts.p, (const int*)src.count.p,
+                     (const float4*)tgt.pts.p, (const int*)gb.corr.p, (const Cov6*)gb.mahal.p, xt, out.p);
+  MI_LAUNCH_CHECK();
+  double direct[kProbeBlocks];
+  MI_HIP(hipMemcpyAsync(direct, out.p, sizeof(direct), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  double sums[kPartStride], m[kNModel];
+  for (int k = 0; k < kPartStride; k++) {
+    double sum = 0;
+    for (int g = 0; g < G; g++) sum += part[(size_t)g * kPartStride + k];
+    sums[k] = sum;
+  }
+  for (int k = 0; k < kNModel; k++) m[k] = model_entry(sums, k);
+  *model_cost = y0 - model_decrease(pose_compose(xt, inv), m);
+  double d = 0;
+  for (int g = 0; g < kProbeBlocks; g++) d += direct[g];
+  *direct_cost = d;
 }
 
 }  // namespace mi355

@@ -203,6 +203,15 @@ class FastGICP(_Registration):
         self.ctx.check(self.ctx._lib.mi355_reg_gicp_linearize(self.handle, T.ctypes.data, H.ctypes.data, b.ctypes.data, C.byref(err), corr.ctypes.data))
         return H.reshape(6, 6), b, err.value, corr[: self._n_src]
 
+    def trial_cost(self, T_lin, T_trial):
+        """FastGICP::compute_error(T_trial) with the correspondences / Mahalanobis matrices of a linearisation at T_lin (parity probe):
+        (cost as the optimisation prices its LM trials - from the sums of the linearisation pass -, cost by a pass over the points)."""
+        A = np.ascontiguousarray(T_lin, dtype=np.float64).reshape(16)
+        B = np.ascontiguousarray(T_trial, dtype=np.float64).reshape(16)
+        m, d = C.c_double(0), C.c_double(0)
+        self.ctx.check(self.ctx._lib.mi355_reg_gicp_trial_cost(self.handle, A.ctypes.data, B.ctypes.data, C.byref(m), C.byref(d)))
+        return m.value, d.value
+
 
 class NormalDistributionsTransform(_Registration):
     """pclomp::NormalDistributionsTransform<PointXYZI,PointXYZI> with DIRECT7 (lidar_scan_matcher.cpp:55-72)."""

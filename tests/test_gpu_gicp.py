@@ -41,6 +41,33 @@ def test_linearize_parity(R, small_pair):
         np.testing.assert_allclose(err, err2, rtol=2e-5)
 
 
+def test_trial_cost_model_is_compute_error(R, small_pair, medium_pair):
+    """F5: the optimisation prices LsqRegistration::step_lm's trial poses from sums of the linearisation pass (no pass over the
+    points).  That model is FastGICP::compute_error exactly - same frozen correspondences and Mahalanobis matrices - so it must
+    agree with the pass over the points (the library's own probe kernel) to fp64 rounding, and with the oracle's compute_error to
+    what the fp32 Mahalanobis matrices of the kernel allow (the tolerance of test_linearize_parity)."""
+    for (s, t, T) in (small_pair, medium_pair):
+        cs, ct = O.covariances(s), O.covariances(t)
+        reg = _reg(R, s, t)
+        T_lin = synth.se3(0.3, -0.1, 0.02, 0.01, -0.01, 0.02) @ T
+        _, _, err0, corr, mahal = O.gicp_linearize(s, cs, t, ct, T_lin, 2.0)
+        steps = [np.eye(4), synth.se3(1e-4, -2e-4, 5e-5, 1e-5, 2e-5, -1e-5), synth.se3(0.02, -0.01, 0.005, 1e-3, -2e-3, 1.5e-3),
+                 synth.se3(-0.25, 0.08, -0.02, -0.008, 0.01, -0.015), synth.se3(1.0, -0.5, 0.2, 0.05, -0.04, 0.1)]
+        for D in steps:
+            T_trial = D @ T_lin
+            model, direct = reg.trial_cost(T_lin, T_trial)
+            ref = O.gicp_error(s, t, corr, mahal, T_trial)
+            # model vs the pass over the points: the same fp32 matrices, fp64 sums in a different order
+            assert abs(model - direct) <= 1e-9 * max(direct, err0), (model, direct)
+            np.testing.assert_allclose(direct, ref, rtol=2e-5)
+            np.testing.assert_allclose(model, ref, rtol=2e-5)
+        # the DECREASE of a small step - what the rho test divides - keeps its digits: no difference of two large sums
+        D = synth.se3(2e-5, -1e-5, 1e-5, 2e-6, -1e-6, 1e-6)
+        model, direct = reg.trial_cost(T_lin, D @ T_lin)
+        base, base_direct = reg.trial_cost(T_lin, T_lin)
+        assert abs((base - model) - (base_direct - direct)) <= 1e-6 * abs(base_direct - direct) + 1e-12 * base_direct
+
+
 def test_align_fixed_iterations(R, small_pair):
     s, t, T = small_pair
     reg = _reg(R, s, t, max_iterations=10, force_iterations=1)
