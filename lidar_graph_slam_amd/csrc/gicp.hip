@@ -1257,11 +1257,10 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
       }
     }
   }
-  block_sum<kNAcc, 4>(acc, smem);
-  if (threadIdx.x == 0) {
-    double* out = partials + ((size_t)pair * G + bx) * kPartStride;
-#pragma unroll
-    for (int k = 0; k < kNAcc; k++) out[k] = acc[k];
+  static_assert(kFeat >= kWave * kBlockSumRow, "the wave's factor rows double as the transpose buffer of the block sum");
+  {
+    const double total = block_sum_columns<kNAcc, kWaves>(acc, feat[wv], smem);
+    if (threadIdx.x < kNAcc) partials[((size_t)pair * G + bx) * kPartStride + threadIdx.x] = total;
   }
   if (model) {
     // the four waves' accumulator tiles -> one 8 x 8: element v of lane l is row (l >> 4) + 4 v, column l & 15 (the f64 MFMA's own map);
@@ -1300,8 +1299,15 @@ __device__ __forceinline__ void lm_make_trial(const double* H, const double* b, 
   tr.lambda = lambda;
 }
 
-// After a step_optimize completed: iteration bookkeeping + convergence (F6).
-__device__ __forceinline__ void finish_step(GicpPairState& s, const GicpDevParams& P, bool ok) {
+// After a step_optimize completed: iteration bookkeeping + convergence (F6).  State: GicpPairState itself, or the copy of these
+// fields k_gicp_step keeps in registers (StepFields).
+struct StepFields {
+  int iter, active, converged, first_conv, lm_failed;
+  double last_step;
+  Pose delta;
+};
+template <typename State>
+__device__ __forceinline__ void finish_step(State& s, const GicpDevParams& P, bool ok) {
   s.iter += 1;
   if (!ok) {  // "lm not converged!!" -> break (benchmark mode keeps iterating: fixed work per pair)
     s.lm_failed = 1;
@@ -1361,13 +1367,14 @@ MI_HD double model_decrease(const Pose& delta, const double* m) {
     for (int c = 0; c < 3; c++) W[r][c] = delta.R[3 * r + c] - ((r == c) ? 1.0 : 0.0);
     W[r][3] = delta.t[r];
   }
-  const int kSym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-  const int kSym4[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+  // index of (r, s) among xx xy xz yy yz zz, and of (c, e) among the ten columns
+  auto sym3 = [](int r, int s2) { const int lo = r < s2 ? r : s2, hi = r < s2 ? s2 : r; return lo * 3 - lo * (lo - 1) / 2 + (hi - lo); };
+  auto sym4 = [&](int c, int e) { return (c < 3 && e < 3) ? sym3(c, e) : ((c == 3 && e == 3) ? 9 : 6 + (c < e ? c : e)); };
   double lin = 0.0, quad = 0.0;
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 4; c++) lin += W[r][c] * m[(6 + r) * kModelCols + kSym4[c][3]];
+    for (int c = 0; c < 4; c++) lin += W[r][c] * m[(6 + r) * kModelCols + sym4(c, 3)];
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -1376,7 +1383,7 @@ MI_HD double model_decrease(const Pose& delta, const double* m) {
 #pragma unroll
       for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) q += W[r][c] * W[s2][e] * m[kSym3[r][s2] * kModelCols + kSym4[c][e]];
+        for (int e = 0; e < 4; e++) q += W[r][c] * W[s2][e] * m[sym3(r, s2) * kModelCols + sym4(c, e)];
       quad += q;
     }
   return 2.0 * lin - quad;
@@ -1398,8 +1405,14 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
   __shared__ int s_accepted;
   const int pair = blockIdx.x;
   GicpPairState* st = state + pair;
-  if (!st->active) return;
   const int l = threadIdx.x;
+  // everything the kernel reads of the state, in flight together with the partial sums (the decision below used to find these fields
+  // one dependent load at a time)
+  const int ld_active = st->active, ld_iter = st->iter, ld_converged = st->converged, ld_first_conv = st->first_conv, ld_lm_failed = st->lm_failed;
+  const double ld_lambda = st->lambda, ld_last_step = st->last_step;
+  const float ld_slack_rot = st->slack_rot, ld_slack_trans = st->slack_trans;
+  const double ld_x0 = (l < 9) ? st->x0.R[l] : st->x0.t[min(l, 11) - 9];
+  if (!ld_active) return;
   const double* mine = partials + (size_t)pair * G * kPartStride;
   const bool lm = P.optimizer != MI355_OPT_GN && !sums_only;
   sums[l] = (l < (lm ? kNAcc : kNLin) || (lm && l >= kModelSlot)) ? sum_partials(mine + l, G) : 0.0;
@@ -1430,23 +1443,22 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
     }
     return;
   }
-  // LM: only the fields that change are touched (a copy of the 1 KB state through one lane's scratch cost 15 of the 30 us)
+  // LM: only the fields that change are touched (a copy of the 1 KB state through one lane's scratch cost 15 of the 30 us), and what
+  // the decision reads of the state came in with the first loads of the kernel (ld_*): the walk itself waits for no memory.
   if (l == 0) {
     unpack_normal_equations(sums, sH, sb);
-    double lam = st->lambda;
+    double lam = ld_lambda;
     if (lam < 0.0) {
       double mx = 0;
       for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(sH[7 * i]));
       lam = P.lm_init_lambda_factor * mx;
-      if (!sums_only) st->lambda = lam;
     }
     slambda = lam;
     st->y0 = sums[27];
     st->n_inliers = (int)(sums[28] + 0.5);
     s_accepted = 0;
   }
-  if (l < 9) sx0.R[l] = st->x0.R[l];
-  else if (l < 12) sx0.t[l - 9] = st->x0.t[l - 9];
+  if (l < 12) ((l < 9) ? sx0.R[l] : sx0.t[l - 9]) = ld_x0;
   __syncthreads();
   if (l < 36) st->H[l] = sH[l];
   if (l < 6) st->b[l] = sb[l];
@@ -1468,32 +1480,33 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
     slack_r = (float)(sqrt(fr) * (1.0 + 1e-6)) + 1e-12f;
     slack_t = (float)(sqrt(ft) * (1.0 + 1e-6)) + 1e-12f;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    slack_r = fmaxf(slack_r, __shfl_xor(slack_r, off, kWave));
-    slack_t = fmaxf(slack_t, __shfl_xor(slack_t, off, kWave));
-  }
+  slack_r = wave_reduce64(slack_r, [](float a, float b) { return fmaxf(a, b); });
+  slack_t = wave_reduce64(slack_t, [](float a, float b) { return fmaxf(a, b); });
   __syncthreads();
   if (l == 0) {
-    GicpPairState& s = *st;  // in place: only the fields of the taken branch move (the state is 1 KB)
+    GicpPairState& s = *st;
     // the bits of this iteration's linearize pass (written only for a pair that tracked margins, under the budget in the state)
-    const bool marked = margin_step >= 0.0 && s.last_step < margin_step && s.slack_rot >= 0.f;
-    s.mask_valid = (marked && slack_r <= s.slack_rot && slack_t <= s.slack_trans) ? 1 : 0;
+    const bool marked = margin_step >= 0.0 && ld_last_step < margin_step && ld_slack_rot >= 0.f;
+    s.mask_valid = (marked && slack_r <= ld_slack_rot && slack_t <= ld_slack_trans) ? 1 : 0;
     s.slack_rot = slack_factor * slack_r + 1e-9f;
     s.slack_trans = slack_factor * slack_t + 1e-7f;
-    bool finished = false;
-    double lam_next = slambda, nu = 2.0;
+    StepFields f;
+    f.iter = ld_iter; f.active = 1; f.converged = ld_converged; f.first_conv = ld_first_conv; f.lm_failed = ld_lm_failed; f.last_step = ld_last_step;
+    bool finished = false, moved = false;
+    double lam_out = slambda, lam_next = slambda, nu = 2.0;
+    int t_last = 0;
     for (int t = 0; t < P.lm_max_iterations && !finished; t++) {
       const LmTrial& tr = s_tr[t];
       double denom = 0;
       for (int i = 0; i < 6; i++) denom += tr.d[i] * (tr.lambda * tr.d[i] - sb[i]);
       const double rho = dec[t] / denom;  // (y0 - yi) / denom
-      s.trial = t;
+      t_last = t;
       if (rho < 0) {
         if (!P.force_iterations && is_converged(tr.delta, P.rotation_epsilon, P.transformation_epsilon)) {
-          s.delta = tr.delta;  // step_lm returns true without moving x0 (and without touching lambda)
-          s.lambda = tr.lambda;
-          finish_step(s, P, true);
+          f.delta = tr.delta;  // step_lm returns true without moving x0 (and without touching lambda)
+          s.delta = tr.delta;
+          lam_out = tr.lambda;
+          finish_step(f, P, true);
           finished = true;
         } else {
           lam_next = nu * tr.lambda;
@@ -1502,20 +1515,31 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
       } else {
         s.x0 = tr.xi;
         s.delta = tr.delta;
+        f.delta = tr.delta;
         for (int i = 0; i < 6; i++) s.d[i] = tr.d[i];
         const double c = 2 * rho - 1;
-        s.lambda = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
+        lam_out = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
         s_accepted = 1;  // final_H = H: by 36 lanes, below
         s.last_error = sums[27] - dec[t];
         s.yi = s.last_error;
-        finish_step(s, P, true);
+        finish_step(f, P, true);
         finished = true;
+        moved = true;
       }
     }
     if (!finished) {  // every trial rejected: "lm not converged!!"
-      s.lambda = lam_next;
-      finish_step(s, P, false);
+      lam_out = lam_next;
+      finish_step(f, P, false);
     }
+    (void)moved;
+    s.trial = t_last;
+    s.lambda = lam_out;
+    s.iter = f.iter;
+    s.active = f.active;
+    s.converged = f.converged;
+    s.first_conv = f.first_conv;
+    s.lm_failed = f.lm_failed;
+    s.last_step = f.last_step;
   }
   __syncthreads();
   if (s_accepted && l < 36) st->final_H[l] = sH[l];

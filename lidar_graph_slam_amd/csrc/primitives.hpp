@@ -41,6 +41,40 @@ __device__ __forceinline__ void block_sum(double* acc, double* smem) {
   __syncthreads();
 }
 
+// The same sums through an LDS transpose, for kernels that reduce MANY values per thread: the butterfly above costs 12 ds_bpermute_b32
+// + 6 v_add_f64 per value and wave (738 instructions for the 41 sums of k_gicp_linearize - a quarter of what a block of that kernel
+// executes in its whole life), this one ~10: sixteen values at a time every lane leaves its 16 in a row of `wave_buf`, lane
+// (column c = lane & 15, quarter q = lane >> 4) adds column c over the 16 lanes of quarter q in lane order, and the four quarters meet
+// in two butterfly steps.  Fixed order => bitwise reproducible.  Returns, in thread k < NV, the block's sum of value k (0 elsewhere).
+// wave_buf: 64 x 17 doubles private to the calling wave; smem: NW * NV doubles.
+constexpr int kBlockSumRow = 17;
+template <int NV, int NW>
+__device__ __forceinline__ double block_sum_columns(const double* acc, double* wave_buf, double* smem) {
+  const int lane = lane_id(), w = wave_id();
+  const int col = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c0 = 0; c0 < NV; c0 += 16) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the rows of the previous round have been read)
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if (c0 + k < NV) wave_buf[lane * kBlockSumRow + k] = acc[c0 + k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s += wave_buf[(q * 16 + r) * kBlockSumRow + col];
+    s += __shfl_xor(s, 16, kWave);
+    s += __shfl_xor(s, 32, kWave);
+    if (lane < 16 && c0 + lane < NV) smem[w * NV + c0 + lane] = s;
+  }
+  __syncthreads();
+  double total = 0.0;
+  if ((int)threadIdx.x < NV) {
+#pragma unroll
+    for (int ww = 0; ww < NW; ww++) total += smem[ww * NV + threadIdx.x];
+  }
+  return total;
+}
+
 // ---- wave / row all-reductions without LDS ------------------------------------------------------------------------
 // __shfl_xor compiles to ds_bpermute_b32 on gfx950: an LDS-crossbar round trip (~100 cycles) per step, and the six steps of a
 // wave reduction depend on each other.  The tile kernels reduce a bounding box (6 values), group boxes, radii and counts per tile and
