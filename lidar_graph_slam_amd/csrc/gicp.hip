@@ -49,10 +49,11 @@ struct GicpDevParams {
   float max_corr_d2;
 };
 
-constexpr int kNLin = 29;       // 6 Hrr + 9 Hrt + 6 Htt + 6 b + 1 cost + 1 inlier count
-constexpr int kNAcc = kNLin + 12;  // + the 12 sums of the trial-cost model that are kept in registers (below)
-constexpr int kPartStride = 128;  // doubles per (pair, block): 0..40 the register sums, 48..111 the 8 x 8 tile of the matrix cores
-constexpr int kModelSlot = 48;
+constexpr int kNLin = 8;        // sum M (6: H_tt) + cost + inlier count
+constexpr int kSumCost = 6, kSumCount = 7;
+constexpr int kNAcc = kNLin + 12;  // + the 12 sums of the model below that are kept in registers
+constexpr int kPartStride = 96;  // doubles per (pair, block): 0..19 the register sums, 32..95 the 8 x 8 tile of the matrix cores
+constexpr int kModelSlot = 32;
 // The cost of an LM trial without a pass over the points.  With the correspondences and Mahalanobis matrices of the iteration frozen
 // (FastGICP::compute_error), the cost at the trial pose x_t = delta_t x0 is a quadratic form of W = [dR - I | dt] (3 x 4):
 //   d_t = q - x_t p = d0 - W a~        a~ = (x0 p, 1), d0 = q - x0 p (the residual linearize already has)
@@ -62,6 +63,9 @@ constexpr int kModelSlot = 48;
 // k_gicp_step prices all the trials of step_lm from them: the cost pass (56 B per point and iteration, fp64-issue-bound on ten
 // trials) is gone.  It is the same function of the pose as the reference's loop, evaluated as (decrease from y0), which is better
 // conditioned than the difference of two sums the reference forms for its rho test.
+// The normal equations are linear in the same sums - J = [skew(a) | -I] (fast_gicp_impl.hpp), H = sum J^T M J, b = sum J^T M d0 -
+// so k_gicp_step forms H and b from them too (model_normal_equations) and the linearize pass carries no accumulator of its own for
+// them: 20 fp64 sums per lane + the matrix-core tile instead of round 3's 29 (fp32 products) + round 4's 41.
 // Where the 72 sums live: as the 9 x 10 matrix "model" (rows M_xx M_xy M_xz M_yy M_yz M_zz (M d0)_x (M d0)_y (M d0)_z, columns ax ax,
 // ax ay, ax az, ay ay, ay az, az az, ax, ay, az, 1; a = x0 p) they are
 //   - an 8 x 8 outer product per point on the matrix cores: rows M (6), (M d0)_x, (M d0)_y; columns ax ax, ax ay, ax az, ay ay, ay az,
@@ -1067,9 +1071,6 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 // k_gicp_step has budgeted for this iteration's trials (slack_rot / slack_trans of the pair's state; k_gicp_step validates the
 // budget against the trials it then makes) - the next k_gicp_correspond reads those bits instead of the points.
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
-#ifndef LIN_ABLATE
-#define LIN_ABLATE 0  // timing experiments only (wrong results): 1 no MFMA, 2 no LDS reads either, 3 no model at all, 4 no margin bits
-#endif
 #ifndef LIN_OCC
 #define LIN_OCC 2  // resident blocks per CU (= waves per SIMD) the register allocation aims at
 #endif
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
                                                                const Cov6* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
                                                                const GicpPairState* __restrict__ state, const int* __restrict__ corr,
-                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S, int model,
+                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S,
                                                                const float4* __restrict__ qsearch, unsigned long long* __restrict__ safe_mask,
                                                                size_t mask_words, double margin_step) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
@@ -1100,8 +1101,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
   for (int k = 0; k < 9; k++) Rf[k] = (float)x0.R[k];
   const size_t so = (size_t)pair * scap;
   const float slack_rot = st->slack_rot, slack_trans = st->slack_trans;
-  const bool mark = LIN_ABLATE != 4 && model && safe_mask != nullptr && st->last_step < margin_step && slack_rot >= 0.f;
-  if (LIN_ABLATE == 3) model = 0;
+  const bool mark = safe_mask != nullptr && st->last_step < margin_step && slack_rot >= 0.f;
   float Tf0[12];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -1185,47 +1185,15 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
         float ax, ay, az, ex, ey, ez;
         double dax, day, daz, dex, dey, dez;
         residual64(x0, p, tq[u], dax, day, daz, ax, ay, az, ex, ey, ez, dex, dey, dez);
-        const float Me0 = M.xx * ex + M.xy * ey + M.xz * ez;
-        const float Me1 = M.xy * ex + M.yy * ey + M.yz * ez;
-        const float Me2 = M.xz * ex + M.yz * ey + M.zz * ez;
-        // MS = M * skew(a)
-        const float m0[3] = {M.xx, M.xy, M.xz}, m1[3] = {M.xy, M.yy, M.yz}, m2[3] = {M.xz, M.yz, M.zz};
-        float MS[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const float* mr = (r == 0) ? m0 : ((r == 1) ? m1 : m2);
-          MS[r][0] = mr[1] * az - mr[2] * ay;
-          MS[r][1] = mr[2] * ax - mr[0] * az;
-          MS[r][2] = mr[0] * ay - mr[1] * ax;
-        }
-        // Hrr = skew(a)^T * MS  (symmetric)
-        acc[0] += (double)(az * MS[1][0] - ay * MS[2][0]);
-        acc[1] += (double)(az * MS[1][1] - ay * MS[2][1]);
-        acc[2] += (double)(az * MS[1][2] - ay * MS[2][2]);
-        acc[3] += (double)(ax * MS[2][1] - az * MS[0][1]);
-        acc[4] += (double)(ax * MS[2][2] - az * MS[0][2]);
-        acc[5] += (double)(ay * MS[0][2] - ax * MS[1][2]);
-        // Hrt[i][c] = -(MS)[c][i]
-#pragma unroll
-        for (int i2 = 0; i2 < 3; i2++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) acc[6 + 3 * i2 + c] -= (double)MS[c][i2];
-        // Htt = M
-        acc[15] += (double)M.xx; acc[16] += (double)M.xy; acc[17] += (double)M.xz;
-        acc[18] += (double)M.yy; acc[19] += (double)M.yz; acc[20] += (double)M.zz;
-        // b = J^T M e
-        acc[21] += (double)(az * Me1 - ay * Me2);
-        acc[22] += (double)(ax * Me2 - az * Me0);
-        acc[23] += (double)(ay * Me0 - ax * Me1);
-        acc[24] -= (double)Me0; acc[25] -= (double)Me1; acc[26] -= (double)Me2;
-        acc[27] += cost64(dex, dey, dez, M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
-        acc[28] += 1.0;
-        if (model) {
+        {
 #pragma clang fp contract(fast)
           const double mxx = (double)M.xx, mxy = (double)M.xy, mxz = (double)M.xz, myy = (double)M.yy, myz = (double)M.yz, mzz = (double)M.zz;
-          const double md0x = mxx * dex + mxy * dey + mxz * dez;  // M d0 (the same products as cost64)
+          const double md0x = mxx * dex + mxy * dey + mxz * dez;  // M d0
           const double md0y = mxy * dex + myy * dey + myz * dez;
           const double md0z = mxz * dex + myz * dey + mzz * dez;
+          acc[0] += mxx; acc[1] += mxy; acc[2] += mxz; acc[3] += myy; acc[4] += myz; acc[5] += mzz;
+          acc[kSumCost] += dex * md0x + dey * md0y + dez * md0z;  // d0^T M d0 (cost64's operations)
+          acc[kSumCount] += 1.0;
           // (straight to LDS: the factors kept in registers until the whole wave is here cost the kernel a wave per SIMD)
           featA[0] = mxx; featA[1] = mxy; featA[2] = mxz; featA[3] = myy; featA[4] = myz; featA[5] = mzz; featA[6] = md0x; featA[7] = md0y;
           featB[0] = dax * dax; featB[1] = dax * day; featB[2] = dax * daz; featB[3] = day * day; featB[4] = day * daz;
@@ -1236,11 +1204,11 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
           acc[kNLin + 6] += md0x; acc[kNLin + 7] += md0y; acc[kNLin + 8] += md0z;
           acc[kNLin + 9] += md0z * dax; acc[kNLin + 10] += md0z * day; acc[kNLin + 11] += md0z * daz;
         }
-      } else if (model) {
+      } else {
 #pragma unroll
         for (int k = 0; k < kMfmaDim; k++) { featA[k] = 0.0; featB[k] = 0.0; }
       }
-      if (model && LIN_ABLATE != 2 && __ballot(has)) {  // (wave-uniform)
+      if (__ballot(has)) {  // (wave-uniform)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rows are read by other lanes
         // product step s takes points 8 s .. 8 s + 7: lane (r = lane & 15, k = lane >> 4) holds factor r & 7 of point 8 s + k (r < 8:
         // rows / columns 0-7 of the tile) or of point 8 s + 4 + k (rows / columns 8-15)
@@ -1250,8 +1218,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
 #pragma unroll 4
         for (int step = 0; step < kWave / 8; step++) {
           const double a = rowA[step * 8 * kFeatStride], b = rowB[step * 8 * kFeatStride];
-          if (LIN_ABLATE == 1) macc[0] += a * b;
-          else macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
+          macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile overwrites the rows
       }
@@ -1262,7 +1229,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
     const double total = block_sum_columns<kNAcc, kWaves>(acc, feat[wv], smem);
     if (threadIdx.x < kNAcc) partials[((size_t)pair * G + bx) * kPartStride + threadIdx.x] = total;
   }
-  if (model) {
+  {
     // the four waves' accumulator tiles -> one 8 x 8: element v of lane l is row (l >> 4) + 4 v, column l & 15 (the f64 MFMA's own map);
     // the two diagonal blocks hold the two halves of the points
 #pragma unroll
@@ -1276,17 +1243,6 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
       partials[((size_t)pair * G + bx) * kPartStride + kModelSlot + threadIdx.x] = sum;
     }
   }
-}
-
-__device__ __forceinline__ void unpack_normal_equations(const double* a, double* H, double* b) {
-  // rows/cols 0-2 rotation, 3-5 translation
-  H[0] = a[0]; H[1] = a[1]; H[2] = a[2]; H[7] = a[3]; H[8] = a[4]; H[14] = a[5];
-  H[6] = a[1]; H[12] = a[2]; H[13] = a[4];
-  for (int i = 0; i < 3; i++)
-    for (int c = 0; c < 3; c++) { H[6 * i + 3 + c] = a[6 + 3 * i + c]; H[6 * (3 + c) + i] = a[6 + 3 * i + c]; }
-  H[21] = a[15]; H[22] = a[16]; H[23] = a[17]; H[28] = a[18]; H[29] = a[19]; H[35] = a[20];
-  H[27] = a[16]; H[33] = a[17]; H[34] = a[19];
-  for (int i = 0; i < 6; i++) b[i] = a[21 + i];
 }
 
 __device__ __forceinline__ void lm_make_trial(const double* H, const double* b, const Pose& x0, double lambda, LmTrial& tr) {
@@ -1350,11 +1306,65 @@ MI_HD double model_entry(const double* sums, int idx) {
     if (c < 5) return mf[r * kMfmaDim + c];
     if (c == 5) return sums[kNLin + r];
     if (c < 9) return mf[r * kMfmaDim + c - 1];
-    return sums[15 + r];  // sum M = H_tt
+    return sums[r];  // sum M = H_tt
   }
   if (c < 6) return 0.0;  // (never read)
   if (r < 8) return c < 9 ? mf[r * kMfmaDim + c - 1] : sums[kNLin + 6 + (r - 6)];
   return c < 9 ? sums[kNLin + 9 + (c - 6)] : sums[kNLin + 8];
+}
+
+// index of (r, s) among xx xy xz yy yz zz, and of (c, e), c, e in {x, y, z, 1}, among the ten columns of the model
+MI_HD int model_sym3(int r, int s2) {
+  const int lo = r < s2 ? r : s2, hi = r < s2 ? s2 : r;
+  return lo * 3 - lo * (lo - 1) / 2 + (hi - lo);
+}
+MI_HD int model_sym4(int c, int e) { return (c < 3 && e < 3) ? model_sym3(c, e) : ((c == 3 && e == 3) ? 9 : 6 + (c < e ? c : e)); }
+
+// The normal equations of FastGICP::linearize from the model m (9 x 10): J = [skew(a) | -I] per point (rows/cols 0-2 rotation, 3-5
+// translation), H = sum J^T M J, b = sum J^T M d0.  With skew(a)_ki = -eps_kip a_p:
+//   H_ij (rot, rot)     = sum_{k,l,p,q} eps_kip eps_ljq  sum(M_kl a_p a_q)
+//   H_i,3+j (rot, trans) = sum_{k,p} eps_kip  sum(M_kj a_p)            H_3+i,3+j = sum(M_ij)
+//   b_i (rot) = - sum_{k,p} eps_kip  sum((M d0)_k a_p)                 b_3+i = - sum((M d0)_i)
+// Entry e < 36: H[e] (row-major 6 x 6); 36 <= e < 42: b[e - 36].
+MI_HD double model_normal_entry(const double* m, int e) {
+  auto eps = [](int k, int i, int p) { return ((k - i) * (i - p) * (p - k)) / 2; };  // Levi-Civita on {0, 1, 2}
+  auto Q = [&](int k, int l, int p, int q) { return m[model_sym3(k, l) * kModelCols + model_sym4(p, q)]; };
+  auto L = [&](int k, int p) { return m[(6 + k) * kModelCols + model_sym4(p, 3)]; };
+  if (e >= 36) {
+    const int i = e - 36;
+    if (i >= 3) return -L(i - 3, 3);
+    double v = 0.0;
+    for (int k = 0; k < 3; k++)
+      for (int p = 0; p < 3; p++) {
+        const int s1 = eps(k, i, p);
+        if (s1) v -= s1 * L(k, p);
+      }
+    return v;
+  }
+  const int i = e / 6, j = e % 6;
+  if (i >= 3 && j >= 3) return Q(i - 3, j - 3, 3, 3);
+  if (i < 3 && j < 3) {
+    double v = 0.0;
+    for (int k = 0; k < 3; k++)
+      for (int p = 0; p < 3; p++) {
+        const int s1 = eps(k, i, p);
+        if (!s1) continue;
+        for (int l = 0; l < 3; l++)
+          for (int q = 0; q < 3; q++) {
+            const int s2 = eps(l, j, q);
+            if (s2) v += (s1 * s2) * Q(k, l, p, q);
+          }
+      }
+    return v;
+  }
+  const int r = i < 3 ? i : j, t = (i < 3 ? j : i) - 3;  // (rotation index, translation index): H is symmetric
+  double v = 0.0;
+  for (int k = 0; k < 3; k++)
+    for (int p = 0; p < 3; p++) {
+      const int s1 = eps(k, r, p);
+      if (s1) v += s1 * Q(k, t, p, 3);
+    }
+  return v;
 }
 
 // The decrease y0 - e_t of the cost at the trial pose delta x0, from the sums of k_gicp_linearize (see kModelSlot): m = the 9 x 10
@@ -1367,14 +1377,11 @@ MI_HD double model_decrease(const Pose& delta, const double* m) {
     for (int c = 0; c < 3; c++) W[r][c] = delta.R[3 * r + c] - ((r == c) ? 1.0 : 0.0);
     W[r][3] = delta.t[r];
   }
-  // index of (r, s) among xx xy xz yy yz zz, and of (c, e) among the ten columns
-  auto sym3 = [](int r, int s2) { const int lo = r < s2 ? r : s2, hi = r < s2 ? s2 : r; return lo * 3 - lo * (lo - 1) / 2 + (hi - lo); };
-  auto sym4 = [&](int c, int e) { return (c < 3 && e < 3) ? sym3(c, e) : ((c == 3 && e == 3) ? 9 : 6 + (c < e ? c : e)); };
   double lin = 0.0, quad = 0.0;
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 4; c++) lin += W[r][c] * m[(6 + r) * kModelCols + sym4(c, 3)];
+    for (int c = 0; c < 4; c++) lin += W[r][c] * m[(6 + r) * kModelCols + model_sym4(c, 3)];
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -1383,7 +1390,7 @@ MI_HD double model_decrease(const Pose& delta, const double* m) {
 #pragma unroll
       for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) q += W[r][c] * W[s2][e] * m[sym3(r, s2) * kModelCols + sym4(c, e)];
+        for (int e = 0; e < 4; e++) q += W[r][c] * W[s2][e] * m[model_sym3(r, s2) * kModelCols + model_sym4(c, e)];
       quad += q;
     }
   return 2.0 * lin - quad;
@@ -1414,21 +1421,24 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
   const double ld_x0 = (l < 9) ? st->x0.R[l] : st->x0.t[min(l, 11) - 9];
   if (!ld_active) return;
   const double* mine = partials + (size_t)pair * G * kPartStride;
-  const bool lm = P.optimizer != MI355_OPT_GN && !sums_only;
-  sums[l] = (l < (lm ? kNAcc : kNLin) || (lm && l >= kModelSlot)) ? sum_partials(mine + l, G) : 0.0;
-  sums[kWave + l] = (lm && kWave + l < kModelSlot + kNMfma) ? sum_partials(mine + kWave + l, G) : 0.0;
+  static_assert(kPartStride <= 2 * kWave && kNAcc <= kModelSlot && kModelSlot + kNMfma <= kPartStride, "two sums per lane cover a pair's partials");
+  sums[l] = (l < kNAcc || l >= kModelSlot) ? sum_partials(mine + l, G) : 0.0;
+  if (kWave + l < kPartStride) sums[kWave + l] = sum_partials(mine + kWave + l, G);
   __syncthreads();
-  if (lm) {
-    mdl[l] = model_entry(sums, l);
-    if (kWave + l < kNModel) mdl[kWave + l] = model_entry(sums, kWave + l);
-  }
+  mdl[l] = model_entry(sums, l);
+  if (kWave + l < kNModel) mdl[kWave + l] = model_entry(sums, kWave + l);
+  __syncthreads();
+  if (l < 36) sH[l] = model_normal_entry(mdl, l);
+  else if (l < 42) sb[l - 36] = model_normal_entry(mdl, l);
+  __syncthreads();
   if (P.optimizer == MI355_OPT_GN) {
     if (l == 0) {
       st->mask_valid = 0;
       GicpPairState s = *st;
-      unpack_normal_equations(sums, s.H, s.b);
-      s.y0 = sums[27];
-      s.n_inliers = (int)(sums[28] + 0.5);
+      for (int i = 0; i < 36; i++) s.H[i] = sH[i];
+      for (int i = 0; i < 6; i++) s.b[i] = sb[i];
+      s.y0 = sums[kSumCost];
+      s.n_inliers = (int)(sums[kSumCount] + 0.5);
       if (!sums_only) {
         double nb[6];
         for (int i = 0; i < 6; i++) nb[i] = -s.b[i];
@@ -1446,7 +1456,6 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
   // LM: only the fields that change are touched (a copy of the 1 KB state through one lane's scratch cost 15 of the 30 us), and what
   // the decision reads of the state came in with the first loads of the kernel (ld_*): the walk itself waits for no memory.
   if (l == 0) {
-    unpack_normal_equations(sums, sH, sb);
     double lam = ld_lambda;
     if (lam < 0.0) {
       double mx = 0;
@@ -1454,8 +1463,8 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
       lam = P.lm_init_lambda_factor * mx;
     }
     slambda = lam;
-    st->y0 = sums[27];
-    st->n_inliers = (int)(sums[28] + 0.5);
+    st->y0 = sums[kSumCost];
+    st->n_inliers = (int)(sums[kSumCount] + 0.5);
     s_accepted = 0;
   }
   if (l < 12) ((l < 9) ? sx0.R[l] : sx0.t[l - 9]) = ld_x0;
@@ -1520,7 +1529,7 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
         const double c = 2 * rho - 1;
         lam_out = tr.lambda * fmax(1.0 / 3.0, 1 - c * c * c);
         s_accepted = 1;  // final_H = H: by 36 lanes, below
-        s.last_error = sums[27] - dec[t];
+        s.last_error = sums[kSumCost] - dec[t];
         s.yi = s.last_error;
         finish_step(f, P, true);
         finished = true;
@@ -1634,7 +1643,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
   const bool mask = tuning().corr_mask && search < 0;
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
                      tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.blocks_lin, gb.S,
-                     P.optimizer == MI355_OPT_LM ? 1 : 0, (const float4*)gb.qsearch.p, mask ? gb.safe_mask.p : (unsigned long long*)nullptr,
+                     (const float4*)gb.qsearch.p, mask ? gb.safe_mask.p : (unsigned long long*)nullptr,
                      (size_t)div_up((long)gb.cap, 64), (double)tuning().margin_step);
 }
 
