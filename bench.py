@@ -45,7 +45,6 @@ ALG_BYTES = {
     "k_gicp_linearize": ("source point", 80),    # src pt 16 + src cov 24 + tgt pt 16 + tgt cov 24
     "k_gicp_correspond": ("source point", 32),   # src pt 16 + tgt pt 16 (the 1-NN pass of update_correspondences / fitness row)
     "k_gicp_correspond_tile": ("source point", 32),
-    "k_gicp_error": ("source point", 56),        # src pt 16 + tgt pt 16 + stored Mahalanobis 24
     "k_knn_cov_tile": ("cloud point", 40),       # read 16 + write 24 (neighbour gathers are implementation traffic)
     "k_voxel_centroids": ("raw point", 32),      # read 16 + write <= 16
     "sort_pairs(k_sort_*)": ("sorted element", 64),  # 4 passes x (8 B read + 8 B written) of (key, index) pairs
@@ -322,7 +321,7 @@ def main():
     units_per_step = {
         "k_gicp_linearize": float(n_src.sum()) * args.iters, "k_gicp_correspond": float(n_src.sum()) * args.iters,
         "k_gicp_correspond_tile": float(n_src.sum()) * ktimes.get("k_gicp_correspond_tile", [0, 0])[1] / max(args.steps, 1),
-        "k_gicp_error": float(n_src.sum()) * args.iters, "k_knn_cov_tile": n_pts, "k_voxel_centroids": n_raw,
+        "k_knn_cov_tile": n_pts, "k_voxel_centroids": n_raw,
         "sort_pairs(k_sort_*)": n_raw + n_pts, "hash_build(k_count_cells,k_table_clear,k_gather_insert)": n_pts,
         "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)": n_pts,
     }

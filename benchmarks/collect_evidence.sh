@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash benchmarks/collect_evidence.sh r01'): everything profiles/README.md cites, written
 # under gpurun_out/<round>/; benchmarks/summarize_evidence.py then distils it into profiles/.
 # rocprofv3 is given the program directly (no env/bash hop) and PMC passes carry --kernel-trace only.
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
@@ -27,7 +27,12 @@ timeout 300 python bench.py --pairs 128 --no-cpu-baseline > "$O/bench_128pairs.j
 timeout 600 python bench.py --pairs 1024 --no-cpu-baseline > "$O/bench_1024pairs.json" 2> "$O/bench_1024pairs.err"
 timeout 900 python bench.py --pairs 4096 --no-cpu-baseline --steps 6 --warmup 2 > "$O/bench_4096pairs.json" 2> "$O/bench_4096pairs.err"
 timeout 900 python benchmarks/other_configs.py --scans 200 > "$O/other_configs.txt" 2> "$O/other_configs.err"
-timeout 600 python benchmarks/config5.py --candidates 512 --submaps 8 > "$O/config5_1gpu.json" 2> "$O/config5_1gpu.err"
+# BASELINE config 5 at its stated size (4 096 candidates x 64 sub-maps) through the multi entry on ONE GPU: host views in, results out
+timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 64 --multi-lanes 2 2> "$O/config5_1gpu.err" | tail -1 > "$O/config5_1gpu.json"
+timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 64 --multi-lanes 4 2> "$O/config5_1gpu_4lanes.err" | tail -1 > "$O/config5_1gpu_4lanes.json"
+# the GPU test suite once, for the parity deltas it logs (tests/parity.py -> gpurun_out/parity_deltas.jsonl; `python benchmarks/summarize_parity.py <round>` then writes profiles/<round>_parity_deltas.txt)
+rm -f gpurun_out/parity_deltas.jsonl
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > "$O/pytest_gpu.txt" 2>&1
 MI355_BATCH_SIDE_STREAMS=0 timeout 300 python bench.py --no-cpu-baseline > "$O/bench_serial_streams.json" 2> "$O/bench_serial_streams.err"
 # distil on the box (the raw rocprofv3 output is hundreds of MB; gpurun copies back at most 64 MiB) and drop the raw traces
 EVIDENCE_DST="$O/profiles" python benchmarks/summarize_evidence.py $R > "$O/summarize.log" 2>&1

@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", R)
 DST = os.environ.get("EVIDENCE_DST") or os.path.join(ROOT, "profiles")  # on the GPU box: a small directory under gpurun_out/ (the raw traces stay there)
 
@@ -88,7 +88,7 @@ def main():
     os.makedirs(DST, exist_ok=True)
     bench = last_json(os.path.join(SRC, "bench_default.json"))
     pairs = bench["config"]["pairs_per_gpu_per_step"]
-    for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu",
+    for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu", "config5_1gpu_4lanes",
                  "bench_sor", "bench_1024pairs", "bench_4096pairs", "bench_hostinputs_inflight2"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p):

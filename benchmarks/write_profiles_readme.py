@@ -13,16 +13,15 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(ROOT, "profiles")
 
 NOTES = {
-    "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles taken along a 2-D Hilbert curve over the cloud's two long axes, 16-lane sub-tile candidate lists in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); VALU-bound",
+    "k_knn_cov_tile": "exact 20-NN + covariance of every point: 64-point tiles taken along a 2-D Hilbert curve over the cloud's two long axes, 16-lane sub-tile candidate lists in LDS, (k+2)-deep v_med3 key network (DESIGN §4.4); two waves per SIMD at 37 % VALU issue each, the rest latency",
     "k_gicp_correspond": "F3, incremental and exact: per-lane walks of the voxel hash, margins (DESIGN §4.3); latency-bound",
     "k_gicp_correspond_tile": "F3 while a pair still moves >= 3 cm per step (launched in the first four iterations; the fourth finds no such pair here): 64-point tiles in the k-NN tile order, packed distance/ordinal keys",
     "k_knn_hard": "the 0.3 % of the points the tiles hand over (far field, ties), one wave per query",
     "sort_pairs(k_sort_*)": "per cloud three sorts - voxel index, Morton code of the hash, 2-D Hilbert index of the tile order: in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
     "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order): one gather per lane, runs handed to their head lane by shuffles",
-    "k_gicp_linearize": "F4, streaming: 80 algorithmic B per source point",
-    "k_gicp_error": "F5: all 10 LM trial costs in one pass (fp64, FMAs fused since round 3)",
+    "k_gicp_linearize": "F4 + the sums F5 needs, streaming: 80 algorithmic B per source point; 72 model sums (8 x 8 outer products on fp64 MFMA + 20 registers) from which k_gicp_step forms H, b and every LM trial cost",
     "hash_build(k_count_cells,k_table_clear,k_gather_insert)": "multi-level voxel hash sized to the occupied cells",
-    "k_gicp_solve+k_gicp_decide": "partials -> H, b -> all LM trial poses; accept / reject walk",
+    "k_gicp_step": "partials -> model -> H, b -> all LM trial poses and their costs; accept / reject walk (F5-F9)",
 }
 
 

@@ -1071,6 +1071,9 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 // k_gicp_step has budgeted for this iteration's trials (slack_rot / slack_trans of the pair's state; k_gicp_step validates the
 // budget against the trials it then makes) - the next k_gicp_correspond reads those bits instead of the points.
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+#ifndef LIN_ABLATE
+#define LIN_ABLATE 0
+#endif
 #ifndef LIN_OCC
 #define LIN_OCC 2  // resident blocks per CU (= waves per SIMD) the register allocation aims at
 #endif
@@ -1218,7 +1221,11 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
 #pragma unroll 4
         for (int step = 0; step < kWave / 8; step++) {
           const double a = rowA[step * 8 * kFeatStride], b = rowB[step * 8 * kFeatStride];
+#if LIN_ABLATE == 1  // (timing experiment, wrong results: the products on one VALU instruction instead of the matrix cores)
+          macc[0] += a * b;
+#else
           macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
+#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile overwrites the rows
       }
