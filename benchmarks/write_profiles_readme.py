@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerate profiles/README.md from the committed profiles/<round>_* files (after summarize_evidence.py).
 
-usage: python benchmarks/write_profiles_readme.py r03
+usage: python benchmarks/write_profiles_readme.py r04
 """
 import csv
 import json
@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(ROOT, "profiles")
 
 NOTES = {
@@ -47,12 +47,14 @@ def main():
     top = next(x for x in rows if dom in x["Name"])
     live = rf["timed_region_event_brackets"]
     one = cpu["one_process"]["pairs_per_s_by_omp_threads"]
-    out = f"""# profiles/ — round 3 (MI355X, gfx950, ROCm 7.2)
+    per_launch = int(round(2 * pairs / rf["by_kernel"][dom]["launches_per_step"])) if dom in rf["by_kernel"] else pairs  # clouds per launch of the dominant kernel (a batch runs in parts)
+    out = f"""# profiles/ — round {int(R[1:])} (MI355X, gfx950, ROCm 7.2)
 
 Everything here comes from ONE command family on a fresh 1-GPU box — `python bench.py` (defaults: {pairs} pairs per step = per
 batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distance filter 1.0 m + voxel 0.2 m, k = 20, exactly
 20 LM iterations) — run by `benchmarks/collect_evidence.sh {R}` and distilled by `benchmarks/summarize_evidence.py` /
-`write_profiles_readme.py`.  The `r01_*` / `r02_*` files are the earlier rounds', kept for the history.
+`write_profiles_readme.py`.  The files of earlier rounds (`r01_*` … ) are kept for the history; round 3's experiment logs
+(`r03_knn_*`, `r03_corr_*`, `r03_tile_order_ab.txt`, `r03_watch_lists_ab.txt`) are what DESIGN §4.3 / §4.4 cite for the kernel variants that did not pay.
 
 | file | what |
 |---|---|
@@ -61,11 +63,9 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 | `{R}_pmc_fetch_write.csv` | per-kernel HBM traffic from two separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE …` / `--pmc WRITE_SIZE …` of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` |
 | `{R}_traffic.json` | the `{tj['kernel']}` row of the above (FETCH_SIZE × 2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM), read by `bench.py` into `roofline.traffic` |
 | `{R}_pmc_valu.csv` | SQ counters per launch of every hot kernel at the bench's full batch ({pairs} pairs): `SQ_INSTS_VALU`, `SQ_ACTIVE_INST_VALU`, `SQ_INSTS_LDS`, `SQ_WAIT_ANY`, `SQ_WAVE_CYCLES`, `SQ_LDS_BANK_CONFLICT` … from two `--pmc` passes (`--kernel-trace` only) of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` |
-| `{R}_knn_tile_ablation.txt` | `benchmarks/knn_ablate.sh`: the preparation chain alone (`knn_only.py`, 1 024 clouds) for the library and for timing-only variants of the tile kernel (no covariance epilogue, no kd order; the "norank" variants break the kernel's control flow and only show that) |
-| `{R}_tile_order_ab.txt` | `benchmarks/tile_order_ab.sh` / `tile_sweep.sh`: the k-NN tile kernel with its tiles along the Morton order of the voxel hash and along the 2-D Hilbert curve (phase clocks, split statistics, tunings, 3-wave variants, the union-of-boxes gather that was removed): DESIGN §4.4 |
-| `{R}_corr_tiles_sweep.txt` | `benchmarks/corr_tiles_sweep.sh`: tile search of the correspondences in the first 2 … 5 iterations, per-iteration search counters, before / after the per-lane kernel searched its queue a block's worth at a time: DESIGN §4.3 |
-| `{R}_knn_tile_counters.txt` | the k-NN tile kernel's own per-tile counters (`MI355_KNN_STATS=1`): segments, rounds, gathers, candidates, build trips, rank steps per lane |
-| `{R}_knn_brick_ab.txt`, `{R}_corr_brick_ab.txt`, `{R}_knn_tile_gather_ab.txt` | A/B logs of this round's kernel experiments that did NOT pay (cell bricks for the k-NN and for the correspondence tiles, a wider first gather): DESIGN §4.4 |
+| `{R}_parts_ab.txt` | `benchmarks/parts_ab.sh`: the bench with the batch cut into 1 / 2 / 3 / 4 / 6 parts (the pipeline inside `mi355_batch_*`), one box: DESIGN §3 |
+| `{R}_cumask_ab.txt` | `benchmarks/cumask_ab.sh`: CU-masked streams for the preparation chains / the LM loop (measured, not kept): DESIGN §3 |
+| `{R}_config5_1gpu.json`, `{R}_config5_1gpu_4lanes.json` | BASELINE config 5 at its stated size — 4 096 candidates × 64 sub-maps — through `mi355_multi_batch_register` on ONE GPU with 2 / 4 lanes, host views in (pinned staging), results out: `benchmarks/config5.py --candidates 4096 --submaps 64 --multi-lanes N` |
 | `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |
 | `{R}_bench_sor.json` | `python bench.py --sor`: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2) over the same {pairs}-pair batch — a different workload, never the headline; carries the SOR row |
 | `{R}_bench_hostinputs.json`, `{R}_bench_hostinputs_inflight2.json` | `python bench.py --host-inputs` (and `--inflight 2 --pairs 1024`): HOST buffers handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
@@ -79,16 +79,17 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 * dominant kernel family = the one with the largest own duration × launches per step: **`{dom}`** — also the top row of
   `{R}_kernel_stats_bench_default.csv` (`{top['Name'].split('(')[0].replace('void ', '')}`, {100 * float(top['TotalDurationNs']) / tot_ns:.1f} % of the kernel time).
 * algorithmic bytes per launch = 40 B per cloud point (16 B point read + 24 B covariance written, SURVEY §8d) × Σ points of the
-  {pairs} clouds of a launch = **{rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB**;
+  {per_launch} clouds of a launch (the batch's {pairs} sources or targets run in {pairs // per_launch} parts, DESIGN §3) = **{rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB**;
 * launch duration: **{rf['avg_launch_ms']:.2f} ms** — HIP events on the launching stream inside `bench.py`, around {rf['launches_measured']} launches that have the GPU
   to themselves (two extra steps after the timed region, preparation chains serialised); **{float(top['AverageNs']) / 1e6:.2f} ms** average over the {top['Calls']} launches
   of the rocprofv3 kernel trace of the same command (min {float(top['MinNs']) / 1e6:.2f}, max {float(top['MaxNs']) / 1e6:.2f}) — the two agree.  The event brackets of the TIMED
   region (`roofline.timed_region_event_brackets`) read {live['avg_ms']:.2f} ms: the preparation chains run on two concurrent side streams, but since
-  round 3 the chain that comes second starts its k-NN when the other's is done (`hipStreamWaitEvent`), so a launch neither queues behind
+  round 3 a chain that comes second starts its k-NN when the other's is done (`hipStreamWaitEvent`), so a launch neither queues behind
   nor interleaves with the other one (at 2 048 clouds the two used to interleave and rocprofv3 saw 33.5 ms per launch: 3 % more pairs/s,
   and a duration that was nobody's own); `frac` is still taken from the launches that have the GPU to themselves;
-* achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is VALU-bound
-  (`{R}_pmc_valu.csv`), the HBM roofline is simply the wrong ceiling for it, and the bench says so instead of picking a flattering kernel;
+* achieved = {rf['algorithmic_bytes_per_launch'] / 1e6:.0f} MB / {rf['avg_launch_ms']:.2f} ms = **{rf['achieved']:.1f} GB/s = {100 * rf['frac']:.2f} % of the 8 TB/s HBM peak**: the kernel is bound by its own instruction stream and the latencies inside it
+  (`{R}_pmc_valu.csv`: two waves per SIMD, each issuing VALU 37 % of its cycles and waiting 38 %), the HBM roofline is simply the wrong ceiling for it, and the
+  bench says so instead of picking a flattering kernel;
 * PMC traffic per launch: FETCH_SIZE {tj['fetch_size_kb_raw'] / 1e3:.0f} MB raw × 2 + WRITE_SIZE {tj['write_size_kb'] / 1e3:.0f} MB = **{tj['hbm_bytes_per_launch'] / 1e6:.0f} MB = {tj['hbm_bytes_per_launch'] / rf['algorithmic_bytes_per_launch']:.2f} × algorithmic**
   (the ×2 is the guide's correction for streaming reads; for this kernel's gathers it is an upper bound);
 * `roofline.end_to_end`: algorithmic bytes of the whole step ({e2e['algorithmic_bytes_per_step'] / 1e9:.2f} GB: prefilter 32 B/raw point, covariances 40 B/point,
@@ -110,7 +111,9 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
         total_own += iso * v["launches_per_step"]
         out += (f"| `{name}` | {v['launches_per_step']:.0f} | {iso:.3f} | {iso * v['launches_per_step']:.2f} | "
                 + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {v['total_ms_per_step']:.2f} | {NOTES.get(name, '')} |\n")
-    out += f"\nSum of the own durations: {total_own:.1f} ms against {b['ms_per_step']:.1f} ms per step (the rest: the small kernels outside these families - keys, scans, bounds, copies - and gaps; the two preparation chains hardly overlap: `k_sort_tile` needs a CU's whole LDS and waits for the other chain's k-NN, DESIGN §3 / §8).\n"
+    out += (f"\nSum of the own durations: {total_own:.1f} ms against {b['ms_per_step']:.1f} ms per step.  The families above leave out the small kernels (keys, scans, bounds, copies: "
+            f"see the kernel-stats CSV); what makes the step SHORTER than the sum is the pipeline inside the batch - its parts' preparation chains and LM loops run on "
+            f"internal streams and fill each other's tails (DESIGN §3; with the chains serialised the step is the last line of this paragraph).\n")
     if ser:
         out += f"One batch of {pairs} pairs with the preparation chains serialised (`{R}_bench_serial_streams.json`): {ser['ms_per_step']:.1f} ms/step.\n"
     oc_path = os.path.join(P, f"{R}_other_configs.txt")
@@ -122,7 +125,7 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
 
 | what | value |
 |---|---|
-| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 2: 14 383 and round 1: 11 572, both at 1 024 pairs per step; boxes of the pool differ by a few per cent) |
+| `python bench.py` ({pairs} pairs per step, one batch at a time) | {b['value']:.0f} pairs/s, {b['ms_per_step']:.1f} ms/step (round 3: 18 644; round 2: 14 383 and round 1: 11 572, both at 1 024 pairs per step; boxes of the pool differ by a few per cent) |
 """
     if i2:
         out += f"| `--inflight 2 --pairs 1024` (two batches in flight, the same memory) | {i2['value']:.0f} pairs/s — the LM iterations of one batch overlap the indexing of the next |\n"
@@ -162,6 +165,17 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
 | config 4 at its stated 1 000 scans | `tests/test_gpu_fullsize.py::test_config4_at_its_stated_size_1000_scans` (both ground models): see `{R}_parity_deltas.txt` summary rows |
 | config 5 on one GPU, 512 candidates × 8 sub-maps through `LoopClosure`-style batches | {c5.get('pairs_per_s', 0):.0f} pairs/s incl. sub-map upload and indexing; registration alone: `benchmarks/config5.py` |
 """
+    c5m, c5m4 = maybe("config5_1gpu"), maybe("config5_1gpu_4lanes")
+    if c5m and "pairs_per_s_including_uploads" in c5m:
+        out += (f"| config 5 at its stated size (4 096 candidates × 64 sub-maps) through `mi355_multi_batch_register`, ONE GPU, host views in | "
+                f"{c5m['pairs_per_s_including_uploads']:.0f} pairs/s with {c5m['lanes']} lanes"
+                + (f", {c5m4['pairs_per_s_including_uploads']:.0f} with {c5m4['lanes']}" if c5m4 else "")
+                + f" — uploads ({c5m['bytes_uploaded_per_call'] / 1e9:.2f} GB per call), prefilter, indexing, registration (early stop, {c5m['mean_iterations']:.1f} iterations on average) and fitness included; "
+                f"{c5m['within_5cm_of_truth']} of {c5m['candidates']} within 5 cm of the truth, median {c5m['median_pose_err_m'] * 100:.1f} cm |\n")
+    hb = b.get("h2d_inclusive")
+    if hb:
+        out += f"| `h2d_inclusive` block of the default bench line (3 steps from pinned host buffers after the timed region, results bit-equal) | {hb['value']:.0f} pairs/s, {hb['ms_per_step']:.1f} ms/step |\n"
+
     open(os.path.join(P, "README.md"), "w").write(out)
     print(out[:600])
 

@@ -23,8 +23,9 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning: 2 = mi355_pointcloud2 gained
  * `data_size` (mandatory) and a non-FLOAT32 intensity field is ignored as pcl::fromROSMsg ignores it; 3 = mi355_batch_diagnostics,
- * mi355_multi_lane_allocations, mi355_multi_batch_register_clouds (additions only).  mi355_abi_version() returns the library's. */
-#define MI355_ABI_VERSION 3
+ * mi355_multi_lane_allocations, mi355_multi_batch_register_clouds, mi355_batch_set_*_views; 4 = mi355_reg_gicp_trial_cost (additions only).
+ * mi355_abi_version() returns the library's: a caller compares it with the MI355_ABI_VERSION it was compiled against. */
+#define MI355_ABI_VERSION 4
 int mi355_abi_version(void);
 
 #define MI355_OK 0
