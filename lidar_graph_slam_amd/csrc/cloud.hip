@@ -526,9 +526,6 @@ constexpr bool kTilePrefetch = KNN_TILE_PREFETCH != 0;  // fetch the next tile u
 #ifndef KNN_COV_REGS
 #define KNN_COV_REGS 1  // 0: the covariance epilogue reads its neighbours from LDS point by point (A/B builds)
 #endif
-#ifndef KNN_RANK_SKIP
-#define KNN_RANK_SKIP 0
-#endif
 #ifndef KNN_RANK_BATCH
 #define KNN_RANK_BATCH 1  // 0: the rank loop of round 3 (A/B builds)
 #endif
@@ -867,10 +864,6 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
               const uint32_t key = (t + u < cnt) ? ((d & ~kOrdMask) | (o[u] >> 4)) : SmallestKeys<K + 2>::kEmpty;
 #ifdef KNN_ABL_NO_RANK
               keys.v[u & 1] = min(keys.v[u & 1], key);
-#elif KNN_RANK_SKIP
-              // a key that is not below the lane's current (K+2)-th smallest cannot change its list: when that holds for every lane
-              // of the wave the 22-deep network is skipped (wave-uniform branch)
-              if (__ballot(key < keys.v[K + 1])) keys.insert(key);
 #else
               keys.insert(key);
 #endif

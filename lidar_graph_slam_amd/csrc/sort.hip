@@ -162,15 +162,19 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   const size_t o = (size_t)c * cap + base;
   uint32_t key[kTsE];
   uint32_t il[kTsE];  // local index (high half) | rank inside the wave for the current pass (low half)
-  // element p of the tile lives in wave p / 1536, round (p % 1536) / 64, lane p % 64; padding sorts to the end (all-ones key,
-  // last in the stable order)
+  // The tile's elements are dealt evenly to the 16 waves, `span` consecutive ones each (a multiple of 64): element p lives in wave
+  // p / span, round (p % span) / 64, lane p % 64; padding sorts to the end (all-ones key, last in the stable order).  A voxelised scan
+  // (13 - 17 k points: two of a cloud's three sorts) then takes 13 - 17 rounds per wave, not the 24 of a full tile of which seven waves
+  // ranked nothing but padding.
   // (positions as p0 + a constant, bounds as a constant against lim: one register each instead of 24 live positions)
-  const int p0 = w * kTsSpan + l;
+  const int span = ((len + kTsThreads - 1) / kTsThreads) * kWave;
+  const int rounds = span / kWave;  // <= kTsE
+  const int p0 = w * span + l;
   const int lim = len - p0;  // element r of this lane exists iff r * kWave < lim
   const uint32_t* kin = keys_in + o + p0;
 #pragma unroll
   for (int r = 0; r < kTsE; r++) {
-    key[r] = (r * kWave < lim) ? kin[r * kWave] : 0xFFFFFFFFu;
+    key[r] = (r * kWave < lim && r < rounds) ? kin[r * kWave] : 0xFFFFFFFFu;
     il[r] = (uint32_t)(p0 + r * kWave) << 16;
   }
   const unsigned long long lt_mask = (1ull << l) - 1ull;
@@ -185,20 +189,22 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
     // ---- rank inside the wave: elements of earlier rounds first, then lower lanes
 #pragma unroll
     for (int r = 0; r < kTsE; r++) {
-      const uint32_t d = (key[r] >> shift) & 255u;
-      unsigned long long peers = ~0ull;
+      if (r < rounds) {  // (block-uniform; no `break`: the loop must unroll for key[] / il[] to stay in registers)
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long peers = ~0ull;
 #pragma unroll
-      for (int b = 0; b < 8; b++) {
-        const unsigned long long m = __ballot((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? m : ~m;
+        for (int b = 0; b < 8; b++) {
+          const unsigned long long m = __ballot((d >> b) & 1u);
+          peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const int rank = __popcll(peers & lt_mask);
+        const int before = cnt[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (rank == 0) cnt[w][d] = (uint16_t)(before + __popcll(peers));
+        __builtin_amdgcn_wave_barrier();
+        il[r] = (il[r] & 0xFFFF0000u) | (uint32_t)(before + rank);
+        asm volatile("" : "+v"(il[r]));  // materialise the rank HERE: deferred, the 64-bit peer masks of all 24 elements stay live (and spill)
       }
-      const int rank = __popcll(peers & lt_mask);
-      const int before = cnt[w][d];
-      __builtin_amdgcn_wave_barrier();
-      if (rank == 0) cnt[w][d] = (uint16_t)(before + __popcll(peers));
-      __builtin_amdgcn_wave_barrier();
-      il[r] = (il[r] & 0xFFFF0000u) | (uint32_t)(before + rank);
-      asm volatile("" : "+v"(il[r]));  // materialise the rank HERE: deferred, the 64-bit peer masks of all 24 elements stay live (and spill)
     }
     __syncthreads();
     // ---- exclusive scan of the 256 x 16 counters, digit-major: thread t owns digit t / 4, waves 4 (t % 4) .. + 3
@@ -231,16 +237,20 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
     for (int r = 0; r < kTsE; r++) asm volatile("" : "+v"(key[r]));
 #pragma unroll
     for (int r = 0; r < kTsE; r++) {
-      const int dest = (int)cnt[w][(key[r] >> shift) & 255u] + (int)(il[r] & 0xFFFFu);
-      keyL[dest] = key[r];
-      idxL[dest] = (uint16_t)(il[r] >> 16);
+      if (r < rounds) {
+        const int dest = (int)cnt[w][(key[r] >> shift) & 255u] + (int)(il[r] & 0xFFFFu);
+        keyL[dest] = key[r];
+        idxL[dest] = (uint16_t)(il[r] >> 16);
+      }
       if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // 8 elements in flight, not 24: the registers are full of elements
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kTsE; r++) {
-      key[r] = keyL[p0 + r * kWave];
-      il[r] = (uint32_t)idxL[p0 + r * kWave] << 16;
+      if (r < rounds) {
+        key[r] = keyL[p0 + r * kWave];
+        il[r] = (uint32_t)idxL[p0 + r * kWave] << 16;
+      }
       if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   int* vout = vals_out + o + p0;
 #pragma unroll
   for (int r = 0; r < kTsE; r++) {
-    if (r * kWave < lim) {
+    if (r * kWave < lim && r < rounds) {
       kout[r * kWave] = key[r];
       vout[r * kWave] = base + (int)(il[r] >> 16);
     }
