@@ -136,7 +136,7 @@ struct GicpBatch {
   int blocks_lin = 0;        // streaming kernels geometry
   DevBuf<int> tgt_of_src;
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
-  DevBuf<Cov6> mahal;        // [S*cap] Mahalanobis matrices of the current linearisation
+  DevBuf<Cov6> mahal;        // [cap] Mahalanobis matrices of pair 0's last linearisation: written for the parity probes only (gicp_linearize_once)
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
   DevBuf<unsigned long long> safe_mask;  // [S][cap / 64] bit i of a pair: point i provably keeps its correspondence under EVERY trial pose of the
                                          // current LM iteration (written by the cost pass, read by the next k_gicp_correspond: gicp.hip)

@@ -111,7 +111,6 @@ void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_g
   if (tn.blocks_lin > 0) gb.blocks_lin = tn.blocks_lin;
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
-  gb.mahal.ensure((size_t)S * cap);
   gb.qsearch.ensure((size_t)S * cap);
   gb.safe_mask.ensure((size_t)S * (size_t)div_up((long)cap, 64));
   gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
@@ -1062,7 +1061,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 
 // F4 linearize given the correspondences: Mahalanobis + normal equations, a pure streaming pass — per source point it
 // reads src pt 16 + src cov 24(32) + tgt pt 16 + tgt cov 24(32) B (the 80 algorithmic bytes of SURVEY.md §8d) and the
-// 4-byte correspondence, writes the 24(32)-byte Mahalanobis matrix, and accumulates 21+6+1 terms in fp64 registers.
+// 4-byte correspondence and accumulates the sums below (the Mahalanobis matrices stay in registers: nothing reads them back).
 // `model` (LM): the pass also accumulates the 72 sums of the trial-cost model (see kModelSlot) - 63 more fp64 accumulators per lane
 // would halve the kernel's occupancy, so most of them are an outer product per point on the matrix cores: the lanes of a wave leave the
 // 8 + 8 factors of their points in LDS, and 8 v_mfma_f64_16x16x4_f64 (8 points each: A = factors of the Mahalanobis side, B = of the
@@ -1073,6 +1072,9 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 #ifndef LIN_ABLATE
 #define LIN_ABLATE 0
+#endif
+#ifndef LIN_PIPE
+#define LIN_PIPE 0
 #endif
 #ifndef LIN_OCC
 #define LIN_OCC 2  // resident blocks per CU (= waves per SIMD) the register allocation aims at
@@ -1139,6 +1141,55 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
     }
     return r;
   };
+#if LIN_PIPE
+  // Three stages (A/B build): the correspondence index of tile t + 2 | the source loads and the target gathers of tile t + 1 | the
+  // arithmetic of tile t - the gathers, which need the index, are then a whole iteration old when they are used.
+  auto load_j = [&](int base, int u) -> int {
+    const int i = base + u * kGicpBlock + threadIdx.x;
+    return (i < n) ? corr[so + i] : -1;
+  };
+  auto load_rest = [&](int base, int u, int j) -> Pre {
+    Pre r;
+    const int i = base + u * kGicpBlock + threadIdx.x;
+    r.j = j;
+    if (i < n) {
+      r.p = spts[so + i];
+      r.c = scov[so + i];
+      if (mark) r.qs = qsearch[so + i];
+    }
+    return r;
+  };
+  Pre nxt[kLinPointsPerThread];
+  float4 tqn[kLinPointsPerThread];
+  Cov6 tcvn[kLinPointsPerThread];
+  int jn2[kLinPointsPerThread];
+#pragma unroll
+  for (int u = 0; u < kLinPointsPerThread; u++) {
+    const int j0 = load_j(bx * kLinTile, u);
+    nxt[u] = load_rest(bx * kLinTile, u, j0);
+    tqn[u] = tp[max(j0, 0)];
+    tcvn[u] = tc[max(j0, 0)];
+    jn2[u] = load_j((bx + G) * kLinTile, u);
+  }
+  for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
+    Pre cur[kLinPointsPerThread];
+    float4 tq[kLinPointsPerThread];
+    Cov6 tcv[kLinPointsPerThread];
+#pragma unroll
+    for (int u = 0; u < kLinPointsPerThread; u++) {
+      cur[u] = nxt[u];
+      tq[u] = tqn[u];
+      tcv[u] = tcvn[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kLinPointsPerThread; u++) {
+      const int jn = jn2[u];
+      nxt[u] = load_rest(base + G * kLinTile, u, jn);
+      tqn[u] = tp[max(jn, 0)];
+      tcvn[u] = tc[max(jn, 0)];
+      jn2[u] = load_j(base + 2 * G * kLinTile, u);
+    }
+#else
   Pre nxt[kLinPointsPerThread];
 #pragma unroll
   for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(bx * kLinTile, u);
@@ -1155,6 +1206,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
     }
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(base + G * kLinTile, u);
+#endif
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
@@ -1184,7 +1236,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
         Sym3<float> RCR = sym3_rotate(Rf, CA);
         RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
         const Sym3<float> M = sym3_inverse(RCR);
-        mahal[so + i] = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);
+        if (mahal) mahal[so + i] = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);  // (the parity probe's pass over the points reads them; the optimisation does not)
         float ax, ay, az, ex, ey, ez;
         double dax, day, daz, dex, dey, dez;
         residual64(x0, p, tq[u], dax, day, daz, ax, ay, az, ex, ey, ez, dex, dey, dez);
@@ -1649,7 +1701,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
   TimedLaunch tl(KF_LINEARIZE, s);
   const bool mask = tuning().corr_mask && search < 0;
   hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
-                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.mahal.p, gb.partials.p, gb.blocks_lin, gb.S,
+                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, search >= 0 ? gb.mahal.p : (Cov6*)nullptr, gb.partials.p, gb.blocks_lin, gb.S,
                      (const float4*)gb.qsearch.p, mask ? gb.safe_mask.p : (unsigned long long*)nullptr,
                      (size_t)div_up((long)gb.cap, 64), (double)tuning().margin_step);
 }
@@ -1947,6 +1999,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
     x.t[r] = T16[4 * r + 3];
   }
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, s, gb.state.p, x);
+  gb.mahal.ensure(gb.cap);  // (only this entry point - the parity probes - keeps the Mahalanobis matrices: pair 0's)
   MI_HIP(hipMemsetAsync(gb.corr.p, 0xFF, gb.cap * sizeof(int), s));
   MI_HIP(hipMemsetAsync(gb.qsearch.p, 0xFF, gb.cap * sizeof(float4), s));
   GicpDevParams P = dev_params(p);
