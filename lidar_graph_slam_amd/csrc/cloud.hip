@@ -65,11 +65,22 @@ __global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pts, 
   const int n = counts[c];
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   const float4* p = pts + (size_t)c * cap;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 v = p[i];
-    if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && passes_distance(v, min_distance)) {
-      mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z);
-      mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z);
+  // four independent loads per thread and trip (one load in flight per thread left this streaming reduction at 2 TB/s)
+  constexpr int kU = 4;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += kU * stride) {
+    float4 v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const int i = i0 + u * stride;
+      v[u] = (i < n) ? p[i] : make_float4(NAN, NAN, NAN, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (isfinite(v[u].x) && isfinite(v[u].y) && isfinite(v[u].z) && passes_distance(v[u], min_distance)) {
+        mn[0] = fminf(mn[0], v[u].x); mn[1] = fminf(mn[1], v[u].y); mn[2] = fminf(mn[2], v[u].z);
+        mx[0] = fmaxf(mx[0], v[u].x); mx[1] = fmaxf(mx[1], v[u].y); mx[2] = fmaxf(mx[2], v[u].z);
+      }
     }
   }
 #pragma unroll
@@ -163,19 +174,37 @@ __global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pt
 // unsuccessful probe walks to the end of its cluster — 6.6 dependent loads per 64-cell lookup at load factor 0.5), not to the
 // worst case of 5 entries per point: a 16 k-point cloud has ~6 k occupied cells — a 0.5 MB table that stays in the XCD's L2
 // while the cloud is searched, instead of 4 MB (the clears alone moved 3.2 GB per 1 024-cloud launch).
-__global__ __launch_bounds__(256) void k_count_cells(const uint32_t* __restrict__ keys, GridMeta* __restrict__ meta, size_t cap) {
+// (round 4: a few hundred blocks per cloud that walk it, one atomic per block.  The first version launched cap / 64 one-wave blocks per
+// cloud - a million blocks per 1 024-cloud launch, four fifths of them past the end of their cloud - and took 0.43 ms to read 54 MB.)
+constexpr int kCountBlock = 256, kCountPer = 8;
+__global__ __launch_bounds__(kCountBlock) void k_count_cells(const uint32_t* __restrict__ keys, GridMeta* __restrict__ meta, size_t cap) {
+  __shared__ int wsum[kCountBlock / kWave];
   const int c = blockIdx.y;
   const int n = meta[c].n, top = meta[c].top_level;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t* k = keys + (size_t)c * cap;
   int cnt = 0;
-  if (i < n) {
-    const size_t o = (size_t)c * cap;
-    const uint32_t key = keys[o + i], kprev = (i > 0) ? keys[o + i - 1] : 0u;
-    for (int l = 0; l <= top; l++) cnt += ((i == 0) || ((kprev >> (3 * l)) != (key >> (3 * l)))) ? 1 : 0;
+  for (int base = blockIdx.x * kCountBlock * kCountPer; base < n; base += gridDim.x * kCountBlock * kCountPer) {
+    const int i0 = base + threadIdx.x * kCountPer;
+    uint32_t key[kCountPer + 1];
+    key[0] = (i0 > 0 && i0 <= n) ? k[i0 - 1] : 0u;
+#pragma unroll
+    for (int u = 0; u < kCountPer; u++) key[u + 1] = (i0 + u < n) ? k[i0 + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < kCountPer; u++) {
+      const int i = i0 + u;
+      if (i < n)
+        for (int l = 0; l <= top; l++) cnt += ((i == 0) || ((key[u] >> (3 * l)) != (key[u + 1] >> (3 * l)))) ? 1 : 0;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
-  if (lane_id() == 0 && cnt > 0) atomicAdd(&meta[c].n_cells, cnt);
+  if (lane_id() == 0) wsum[wave_id()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < kCountBlock / kWave; w++) total += wsum[w];
+    if (total > 0) atomicAdd(&meta[c].n_cells, total);
+  }
 }
 
 __global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t slots_cap) {
@@ -282,9 +311,12 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = meta[c];
   const int lane = lane_id();  // (one-wave blocks: kHashBlock)
-  const int i0 = bx * (kWave * kGiGroups) + lane;
-  if (bx * (kWave * kGiGroups) >= m.n) return;
   const size_t o = (size_t)c * cap;
+  HashSlot* tab = table + (size_t)c * slots_cap;
+  // (G blocks per cloud walk its chunks: one block per chunk of the CAPACITY was 262 k blocks per 1 024-cloud launch, four fifths of them
+  // past the end of a voxelised cloud)
+  for (int chunk = bx; chunk * (kWave * kGiGroups) < m.n; chunk += G) {
+  const int i0 = chunk * (kWave * kGiGroups) + lane;
   uint32_t key_[kGiGroups], kprev_[kGiGroups], knext_[kGiGroups];
   int v_[kGiGroups];
   float4 pv_[kGiGroups];
@@ -299,7 +331,6 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
   }
 #pragma unroll
   for (int g = 0; g < kGiGroups; g++) pv_[g] = (i0 + g * kWave < m.n) ? in[o + v_[g]] : make_float4(0.f, 0.f, 0.f, 0.f);
-  HashSlot* tab = table + (size_t)c * slots_cap;
 #pragma unroll
   for (int g = 0; g < kGiGroups; g++) {
     const int i = i0 + g * kWave;
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
       }
     }
   }
+  }
 }
 
 __global__ void k_copy_counts(const int* in, int* out, int B) {
@@ -357,9 +389,9 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
   TimedLaunch tl(KF_HASH_BUILD, s);
-  hipLaunchKernelGGL(k_count_cells, grid, dim3(kHashBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
+  hipLaunchKernelGGL(k_count_cells, dim3(std::max(1, std::min(std::max(8, 1024 / std::max(B, 1)), div_up((long)cap, kCountBlock * kCountPer))), B), dim3(kCountBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
   hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap);
-  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = div_up((long)cap, kHashBlock * kGiGroups);
+  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = std::max(1, std::min(std::max(64, 8192 / std::max(B, 1)), div_up((long)cap, kHashBlock * kGiGroups)));  // (a lone big cloud: thousands of blocks)
   hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
   const bool okeys = tile_order_keys && tuning().knn_tiles == 1 && tuning().tile_order;
   hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(kHashBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
