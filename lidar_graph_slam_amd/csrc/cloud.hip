@@ -1628,10 +1628,22 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
   const int i0 = base + threadIdx.x * 4;
   int v[4];
   uint32_t prev = (i0 > 0 && i0 - 1 < n) ? k[i0 - 1] : kEmptyKey;
+  if (!m.overflow && i0 + 3 < n) {
+    // (the thread's four keys in ONE 16-byte load, its four positions in one store: four 4-byte accesses 16 bytes apart were four
+    // quarter-used wave instructions each way - 0.56 ms per 1 024-cloud launch for 0.55 GB)
+    const uint4 kq = *reinterpret_cast<const uint4*>(k + i0);
+    const uint32_t kk[4] = {kq.x, kq.y, kq.z, kq.w};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    v[j] = (i0 + j < n) ? voxel_head(m, k, in + o, i0 + j, prev, min_distance) : 0;
-    prev = (i0 + j < n) ? k[i0 + j] : kEmptyKey;
+    for (int j = 0; j < 4; j++) {
+      v[j] = (kk[j] != kEmptyKey && (i0 + j == 0 || kk[j] != prev)) ? 1 : 0;
+      prev = kk[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      v[j] = (i0 + j < n) ? voxel_head(m, k, in + o, i0 + j, prev, min_distance) : 0;
+      prev = (i0 + j < n) ? k[i0 + j] : kEmptyKey;
+    }
   }
   const int s = v[0] + v[1] + v[2] + v[3];
   int incl = s;
@@ -1645,10 +1657,14 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
   int wbase = 0;
   for (int w = 0; w < wave_id(); w++) wbase += wsum[w];
   int run = wbase + incl - s;
+  if (i0 + 3 < n) {
+    *reinterpret_cast<int4*>(lo + i0) = make_int4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
+  } else {
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (i0 + j < n) lo[i0 + j] = run;
-    run += v[j];
+    for (int j = 0; j < 4; j++) {
+      if (i0 + j < n) lo[i0 + j] = run;
+      run += v[j];
+    }
   }
   if (threadIdx.x == 255) blocksum[(size_t)c * nblk + blockIdx.x] = wbase + incl;
 }
