@@ -1,3 +1,5 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: cache-side PMC counters (TCC hits / misses, TCP requests and stalls, TA busy) of the LM and k-NN kernels, one rocprofv3 pass per group.
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 for G in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" "TA_BUSY_sum TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
   rm -rf /tmp/pm; timeout 300 rocprofv3 --kernel-trace --pmc $G --output-format csv -d /tmp/pm -- python3 bench.py --no-cpu-baseline --no-h2d --steps 1 --warmup 1 --pairs 1024 --bases 8 > /dev/null 2> /tmp/pm.err || tail -3 /tmp/pm.err
