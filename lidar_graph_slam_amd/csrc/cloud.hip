@@ -680,6 +680,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
   if constexpr (STATS) ph_t = clock64();
   __shared__ float4 cand[kTileMaxCand];         // this wave's candidate list (x, y, z, sorted index)
   __shared__ uint16_t sub[kNSub][kSubRow];      // per sub-tile: positions in cand[] of the candidates inside its grown box
+  __shared__ int gscratch[2 * kWave];           // tile_gather: prefix sums / range starts of the cells of a gather
 #ifdef KNN_ABL_LDS_PAD  // (timing ablation: fewer resident waves per CU)
   __shared__ int lds_pad[KNN_ABL_LDS_PAD / 4];
   if (threadIdx.x == 0 && G < 0) lds_pad[G & 1] = 1;
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
           if constexpr (STATS) st_gathers++;
           const TileBox nb = grow(bb, Rn);
           const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
-          const int n_new = cells.ok ? tile_gather<KNN_GATHER_DEPTH>(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand) : -1;
+          const int n_new = cells.ok ? tile_gather<KNN_GATHER_DEPTH>(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand, gscratch) : -1;
           if constexpr (STATS) { if (!cells.ok) t_fail_cells++; else if (n_new < 0) t_fail_list++; }
           if (n_new < 0) {  // over a budget: split the segment if nothing has been gathered yet, else hand the open lanes over
             if (!has_old && Rw > rmin && Rn > 0.5f * e_max) {

@@ -877,37 +877,29 @@ __device__ __forceinline__ void corr_scan(const float4* __restrict__ cand, int n
 
 // Gather the points of `cells` inside `nb` (and outside `ob`) through the LDS ring, scanning whenever it is full.
 __device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCells& cells_in, const TileBox& nb, const TileBox& ob, bool has_old,
-                                                 float4* cand, float qx, float qy, float qz, CorrBest& best) {
+                                                 float4* cand, float qx, float qy, float qz, CorrBest& best, int* scratch) {
   const int lane = lane_id();
   const unsigned long long below = (1ull << lane) - 1ull;
-  unsigned long long cells = __ballot(cells_in.ce > cells_in.cs);
-  int j = 0, e = 0;
-  auto advance = [&]() -> bool {
-    j += kWave;
-    if (j < e) return true;
-    if (!cells) return false;
-    const int cl = __builtin_ctzll(cells);
-    cells &= cells - 1;
-    j = __builtin_amdgcn_readlane(cells_in.cs, cl);
-    e = __builtin_amdgcn_readlane(cells_in.ce, cl);
-    return true;
-  };
+  // the cells' points as one flat sequence (tile.hpp FlatCells): full 64-lane loads instead of one load per ~6-point cell
+  FlatCells fc;
+  fc.init(cells_in, scratch);
   int n = 0;
-  for (;;) {
-    int jb[kGatherDepth];
-    bool have[kGatherDepth];
+  for (int f0 = 0; f0 < fc.total; f0 += kWave * kGatherDepth) {
+    int idx[kGatherDepth];
     float4 p[kGatherDepth];
 #pragma unroll
     for (int u = 0; u < kGatherDepth; u++) {
-      have[u] = advance();
-      jb[u] = j;
+      const int f = f0 + u * kWave + lane;
+      idx[u] = 0;
       p[u] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-      if (have[u] && j + lane < e) p[u] = g.pts[j + lane];
+      if (f < fc.total) {
+        idx[u] = fc.index_of(f, scratch);
+        p[u] = g.pts[idx[u]];
+      }
     }
-    if (!have[0]) break;
 #pragma unroll
     for (int u = 0; u < kGatherDepth; u++) {
-      if (!have[u]) break;
+      if (f0 + u * kWave >= fc.total) break;
       const bool in = in_box(nb, p[u].x, p[u].y, p[u].z) && !(has_old && in_box(ob, p[u].x, p[u].y, p[u].z));
       const unsigned long long mask = __ballot(in);
       const int cnt = __popcll(mask);
@@ -915,10 +907,9 @@ __device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCe
         corr_scan(cand, n, qx, qy, qz, best);
         n = 0;
       }
-      if (in) cand[n + __popcll(mask & below)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(jb[u] + lane));
+      if (in) cand[n + __popcll(mask & below)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(idx[u]));
       n += cnt;
     }
-    if (!have[kGatherDepth - 1]) break;
   }
   corr_scan(cand, n, qx, qy, qz, best);
 }
@@ -931,7 +922,7 @@ __device__ __forceinline__ float corr_key_ub(uint32_t k) { return __uint_as_floa
 // A round cannot run only when its box needs more than 64 cells at the top level of the hash (it never does for radii of metres).
 constexpr int kCorrSplitPoints = 2048;  // a 64-lane patch whose round-1 cells hold more points than this is split into quarters
 __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float qx, float qy, float qz, float R1, float R1_2, float reach, float reach2,
-                                            bool one_round, float4* cand, CorrBest& best, float& explored2, unsigned long long* stats) {
+                                            bool one_round, float4* cand, CorrBest& best, float& explored2, unsigned long long* stats, int* scratch) {
   const TileBox box = tile_bounds(act, qx, qy, qz);
   const TileBox nb = grow(box, R1 + tile_eps(box, reach));
   const TileCells cells = tile_cells(g, nb, 0x7fffffff);
@@ -939,7 +930,7 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
   if (cells.ok) {
     // everything in the box counts (round 2 skips this box), but only what lies within R1 is known to be complete
     CorrBest b = best;
-    corr_gather_scan(g, cells, nb, nb, false, cand, qx, qy, qz, b);
+    corr_gather_scan(g, cells, nb, nb, false, cand, qx, qy, qz, b, scratch);
     if (act) { best = b; explored2 = R1_2; }
     seen = true;
   }
@@ -965,7 +956,7 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
     return;
   }
   CorrBest b = best;
-  corr_gather_scan(g, cells2, nb2, nb, seen, cand, qx, qy, qz, b);
+  corr_gather_scan(g, cells2, nb2, nb, seen, cand, qx, qy, qz, b, scratch);
   if (act2) { best = b; explored2 = reach2; }
 }
 
@@ -980,6 +971,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
                                                                      unsigned long long* __restrict__ stats, double margin_step,
                                                                      const int* __restrict__ tile_order) {
   __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand + 8];  // (+ 8: corr_scan reads ahead of the entries it uses)
+  __shared__ int gscratch[kGicpBlock / kWave][2 * kWave];         // corr_gather_scan: prefix sums / range starts of a gather's cells
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
@@ -1028,7 +1020,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
       for (int part = 0; part < parts; part++) {
         const bool pact = act && (parts == 1 || (lane >> 4) == part);
         if (!__ballot(pact)) continue;
-        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats);
+        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats, gscratch[wave_id()]);
       }
     }
     // what the keys could not decide (a tie or near-tie of the two smallest, a box that could not be scanned) is left to the

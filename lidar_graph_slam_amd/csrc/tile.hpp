@@ -113,15 +113,82 @@ __device__ __forceinline__ TileCells tile_cells(const GridView& g, const TileBox
   return t;
 }
 
+// The points of a TileCells as ONE sequence of `total` positions (cells in lane order, a cell's points in array order): position f is
+// sorted-array index index_of(f).  A base cell of a voxelised scan holds ~6 points, so walking the cells one 64-lane load per cell -
+// what tile_gather did until round 4 - issued up to 64 loads with a tenth of their lanes active, eight at a time; the flat sequence
+// takes total / 64 full loads.  scratch: 2 x 64 ints of LDS private to the wave (prefix sums, range starts); the position of a lane is
+// found by a 6-step binary search of the prefix sums.
+#ifndef TILE_FLAT
+#define TILE_FLAT 1  // 0: a load per cell (A/B builds)
+#endif
+struct FlatCells {
+  int total;
+  __device__ __forceinline__ void init(const TileCells& c, int* scratch) {
+    const int lane = lane_id();
+    const int sz = max(c.ce - c.cs, 0);
+    int incl = sz;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int t = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (earlier readers of the scratch are done)
+    scratch[lane] = incl - sz;
+    scratch[kWave + lane] = c.cs;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    total = __builtin_amdgcn_readlane(incl, kWave - 1);
+  }
+  // (f < total) the largest cell whose first position is <= f is the cell that holds f: empty cells share their successor's prefix
+  __device__ __forceinline__ int index_of(int f, const int* scratch) const {
+    int lo = 0;
+#pragma unroll
+    for (int step = kWave / 2; step > 0; step >>= 1)
+      if (scratch[lo + step] <= f) lo += step;
+    return scratch[kWave + lo] + (f - scratch[lo]);
+  }
+};
+
 // Append the points of `cells` that lie inside `nb` and (if has_old) outside `ob` to the wave's LDS candidate list
 // cand[n0 ...] as (x, y, z, sorted index).  Returns the new list length, or -1 if it would exceed `cap` (the list is then
 // undefined past n0).  The chunk loads do not depend on each other, so kGatherDepth of them are in flight per wave.
 constexpr int kGatherDepth = 8;
 template <int DEPTH = kGatherDepth>
 __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& cells_in, const TileBox& nb, const TileBox& ob, bool has_old,
-                                           float4* cand, int n0, int cap) {
+                                           float4* cand, int n0, int cap, int* scratch) {
   const int lane = lane_id();
   const unsigned long long below = (1ull << lane) - 1ull;
+#if TILE_FLAT
+  FlatCells fc;
+  fc.init(cells_in, scratch);
+  int n = n0;
+  for (int f0 = 0; f0 < fc.total; f0 += kWave * DEPTH) {
+    int idx[DEPTH];
+    float4 p[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; u++) {
+      const int f = f0 + u * kWave + lane;
+      idx[u] = 0;
+      p[u] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+      if (f < fc.total) {
+        idx[u] = fc.index_of(f, scratch);
+        p[u] = g.pts[idx[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DEPTH; u++) {
+      if (f0 + u * kWave >= fc.total) break;
+      // a lane past the end of the sequence holds +inf coordinates and fails the box test
+      const bool in = in_box(nb, p[u].x, p[u].y, p[u].z) && !(has_old && in_box(ob, p[u].x, p[u].y, p[u].z));
+      const unsigned long long mask = __ballot(in);
+      const int cnt = __popcll(mask);
+      if (n + cnt > cap) return -1;
+      if (in) cand[n + __popcll(mask & below)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(idx[u]));
+      n += cnt;
+    }
+  }
+  return n;
+#else
+  (void)scratch;
   unsigned long long cells = __ballot(cells_in.ce > cells_in.cs);
   int j = 0, e = 0;  // cursor of the chunk iterator (wave-uniform)
   auto advance = [&]() -> bool {
@@ -161,6 +228,7 @@ __device__ __forceinline__ int tile_gather(const GridView& g, const TileCells& c
     if (!have[DEPTH - 1]) break;
   }
   return n;
+#endif
 }
 
 // The K smallest 32-bit keys seen so far, ascending, maintained by a branch-free median network (one v_med3_u32 per
