@@ -1062,12 +1062,6 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 // k_gicp_step has budgeted for this iteration's trials (slack_rot / slack_trans of the pair's state; k_gicp_step validates the
 // budget against the trials it then makes) - the next k_gicp_correspond reads those bits instead of the points.
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
-#ifndef LIN_ABLATE
-#define LIN_ABLATE 0
-#endif
-#ifndef LIN_PIPE
-#define LIN_PIPE 0
-#endif
 #ifndef LIN_OCC
 #define LIN_OCC 2  // resident blocks per CU (= waves per SIMD) the register allocation aims at
 #endif
@@ -1116,6 +1110,8 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
   // Software pipeline over the block's tiles: the correspondence index, the source point and its covariance of the NEXT
   // tile are loaded while the current tile is computed, so the dependent gathers (target point / covariance at corr[i])
   // of a tile are issued as soon as its loop iteration starts — one exposed memory latency per tile instead of two.
+  // (A third stage - the index two tiles ahead, the gathers one tile ahead - was built and measured in round 4: 176 VGPRs, two waves per
+  // SIMD, the same 16.4 ms per step; bounded to three waves it spills and loses 6 %.  The kernel is bound by bytes, not by that latency.)
   struct Pre {
     int j;
     float4 p, qs;
@@ -1133,55 +1129,6 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
     }
     return r;
   };
-#if LIN_PIPE
-  // Three stages (A/B build): the correspondence index of tile t + 2 | the source loads and the target gathers of tile t + 1 | the
-  // arithmetic of tile t - the gathers, which need the index, are then a whole iteration old when they are used.
-  auto load_j = [&](int base, int u) -> int {
-    const int i = base + u * kGicpBlock + threadIdx.x;
-    return (i < n) ? corr[so + i] : -1;
-  };
-  auto load_rest = [&](int base, int u, int j) -> Pre {
-    Pre r;
-    const int i = base + u * kGicpBlock + threadIdx.x;
-    r.j = j;
-    if (i < n) {
-      r.p = spts[so + i];
-      r.c = scov[so + i];
-      if (mark) r.qs = qsearch[so + i];
-    }
-    return r;
-  };
-  Pre nxt[kLinPointsPerThread];
-  float4 tqn[kLinPointsPerThread];
-  Cov6 tcvn[kLinPointsPerThread];
-  int jn2[kLinPointsPerThread];
-#pragma unroll
-  for (int u = 0; u < kLinPointsPerThread; u++) {
-    const int j0 = load_j(bx * kLinTile, u);
-    nxt[u] = load_rest(bx * kLinTile, u, j0);
-    tqn[u] = tp[max(j0, 0)];
-    tcvn[u] = tc[max(j0, 0)];
-    jn2[u] = load_j((bx + G) * kLinTile, u);
-  }
-  for (int base = bx * kLinTile; base < n; base += G * kLinTile) {
-    Pre cur[kLinPointsPerThread];
-    float4 tq[kLinPointsPerThread];
-    Cov6 tcv[kLinPointsPerThread];
-#pragma unroll
-    for (int u = 0; u < kLinPointsPerThread; u++) {
-      cur[u] = nxt[u];
-      tq[u] = tqn[u];
-      tcv[u] = tcvn[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kLinPointsPerThread; u++) {
-      const int jn = jn2[u];
-      nxt[u] = load_rest(base + G * kLinTile, u, jn);
-      tqn[u] = tp[max(jn, 0)];
-      tcvn[u] = tc[max(jn, 0)];
-      jn2[u] = load_j(base + 2 * G * kLinTile, u);
-    }
-#else
   Pre nxt[kLinPointsPerThread];
 #pragma unroll
   for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(bx * kLinTile, u);
@@ -1198,7 +1145,6 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
     }
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) nxt[u] = preload(base + G * kLinTile, u);
-#endif
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
@@ -1265,11 +1211,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
 #pragma unroll 4
         for (int step = 0; step < kWave / 8; step++) {
           const double a = rowA[step * 8 * kFeatStride], b = rowB[step * 8 * kFeatStride];
-#if LIN_ABLATE == 1  // (timing experiment, wrong results: the products on one VALU instruction instead of the matrix cores)
-          macc[0] += a * b;
-#else
           macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
-#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile overwrites the rows
       }
