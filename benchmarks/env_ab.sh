@@ -6,6 +6,6 @@ for rep in $(seq 1 ${REPS:-2}); do
   for cfg in "$@"; do
     echo "== $cfg (run $rep)"
     env $cfg timeout 600 python bench.py --no-cpu-baseline --no-h2d --steps 8 --warmup 2 --bases 8 > /tmp/ab.json 2>/tmp/ab.err || tail -3 /tmp/ab.err
-    python benchmarks/show_bench.py /tmp/ab.json | cut -c1-118 | grep -E "pairs/s|k_gicp_correspond "
+    python benchmarks/show_bench.py /tmp/ab.json | cut -c1-118 | grep -E "pairs/s|correspond |linearize|k_gicp_step"
   done
 done
