@@ -97,10 +97,10 @@ void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_g
   (void)compute_units;
   int G = tn.blocks_per_pair > 0 ? tn.blocks_per_pair : std::max(2, std::min(64, 8192 / std::max(Sg, 1)));
   G = std::max(1, std::min(G, div_up((long)cap, kGicpBlock * gb.ppt)));
-  // (k_gicp_correspond alone, round 4: with the margin bits most of its launches look at a handful of points per pair, and fewer blocks
-  // that each read more mask words win - 2 048 pairs in two parts, 20 launches of 1 024 pairs, blocks per pair 16 / 8 / 4 / 3 / 2 / 1:
-  // 14.9 / 13.1 / 12.2 / 12.05 / 11.95 / 15.6 ms per step, MI355_CORR_BLOCKS)
-  const int Gc = tn.corr_blocks > 0 ? tn.corr_blocks : (Sg >= 1024 ? 2 : G);
+  // (k_gicp_correspond alone, round 4, with the margin bits - MI355_CORR_BLOCKS, 2 048 pairs in two parts: 16 / 8 / 4 / 3 / 2 / 1 blocks per
+  // pair 14.9 / 13.1 / 12.2 / 12.05 / 11.95 / 15.6 ms per step on 8 scenes; on the bench's 32 scenes 4 / 3 / 2: 10.8 / 11.1 / 11.5 ms and
+  // the same step time - the default stays 8 192 / pairs)
+  const int Gc = tn.corr_blocks > 0 ? tn.corr_blocks : G;
   gb.blocks_per_pair = std::max(1, std::min(Gc, div_up((long)cap, kGicpBlock * gb.ppt)));
   // (the tile search likes twice as many: 2 048 pairs 4 / 8 / 16 blocks per pair 16.0 / 15.7 / 15.9 ms per step, 4 096 pairs 2 / 6: 30.8 / 30.2)
   gb.blocks_tile = tn.blocks_per_pair > 0 ? G : std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(Sg, 1))), div_up((long)cap, kGicpBlock)));
