@@ -23,6 +23,7 @@ const Tuning& tuning() {
     geti("MI355_BLOCKS_PER_PAIR", v.blocks_per_pair);
     geti("MI355_PPT", v.corr_ppt);
     geti("MI355_CORR_TILES", v.corr_tiles);
+    geti("MI355_HASH_SLOTS", v.hash_slots_per_cell);
     geti("MI355_CORR_BLOCKS", v.corr_blocks);
     geti("MI355_CORR_STATS", v.corr_stats);
     geti("MI355_CORR_MASK", v.corr_mask);

@@ -207,11 +207,11 @@ __global__ __launch_bounds__(kCountBlock) void k_count_cells(const uint32_t* __r
   }
 }
 
-__global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t slots_cap) {
+__global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t slots_cap, uint32_t per_cell) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= B) return;
   uint32_t slots = 16, lg = 4;
-  while (slots < 4u * (uint32_t)max(meta[c].n_cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  while (slots < per_cell * (uint32_t)max(meta[c].n_cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
   meta[c].hshift = 32 - lg;
   meta[c].hmask = slots - 1;
 }
@@ -390,7 +390,7 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
   TimedLaunch tl(KF_HASH_BUILD, s);
   hipLaunchKernelGGL(k_count_cells, dim3(std::max(1, std::min(std::max(8, 1024 / std::max(B, 1)), div_up((long)cap, kCountBlock * kCountPer))), B), dim3(kCountBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
-  hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap);
+  hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap, (uint32_t)std::max(1, tuning().hash_slots_per_cell));
   const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = std::max(1, std::min(std::max(64, 8192 / std::max(B, 1)), div_up((long)cap, kHashBlock * kGiGroups)));  // (a lone big cloud: thousands of blocks)
   hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
   const bool okeys = tile_order_keys && tuning().knn_tiles == 1 && tuning().tile_order;

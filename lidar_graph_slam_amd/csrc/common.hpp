@@ -107,6 +107,7 @@ struct Tuning {
   float lm_cus = 1.0f;        // MI355_LM_CUS            the same for the LM loops' streams (the FIRST such share of the bits); 1 = all
   int batch_parts = 0;        // MI355_BATCH_PARTS       parts a FAST_GICP batch is cut into (the pipeline of api.hip); 0 = by its size: 2 from 512 pairs, else 1
   float grid_cell = 0.5f;     // MI355_GRID_CELL         base cell of the voxel hash (m)
+  int hash_slots_per_cell = 4; // MI355_HASH_SLOTS        table slots per occupied cell before rounding up to a power of two (load factor 1/8 - 1/4 at 4)
   int corr_blocks = 0;        // MI355_CORR_BLOCKS       blocks per pair of k_gicp_correspond alone; 0 = MI355_BLOCKS_PER_PAIR / its default (8 192 / pairs)
   int corr_tiles = 4;         // MI355_CORR_TILES        iterations (from the first) in which k_gicp_correspond_tile searches the moving pairs; 0 = never
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)
