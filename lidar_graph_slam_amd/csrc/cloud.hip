@@ -47,12 +47,6 @@ void ws_reserve(Workspace& ws, int B, size_t cap) {
 // PointsPreFiltering::distance_filter's predicate (points_prefiltering.cpp:102-112): Eigen Vector3f::norm() — fp32 sqrt of
 // x*x + (y*y + z*z) (the association of Eigen's unrolled 3-element redux, Redux.h redux_novec_unroller) — promoted to double, strict '<' (NaN compares false; min_distance = 0 still drops the all-zero no-return
 // points).  A NEGATIVE min_distance means "no filter" (the voxel grid without a fused distance filter).
-__device__ __forceinline__ bool passes_distance(const float4& p, double min_distance) {
-  if (min_distance < 0.0) return true;
-  const float nrm = sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z));
-  return min_distance < (double)nrm;
-}
-
 // ---- bounding boxes ---------------------------------------------------------------------------------------------
 __global__ void k_bounds_init(uint32_t* bounds, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1589,15 +1583,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ i
   const GridMeta m = vmeta[c];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
-  const float4 p = in[(size_t)c * cap + i];
-  uint32_t key = kEmptyKey;
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !m.overflow && passes_distance(p, min_distance)) {
-    const int mb0 = __float_as_int(m.ox), mb1 = __float_as_int(m.oy), mb2 = __float_as_int(m.oz);
-    const int i0 = (int)(floorf(p.x * m.inv_cell) - (float)mb0);
-    const int i1 = (int)(floorf(p.y * m.inv_cell) - (float)mb1);
-    const int i2 = (int)(floorf(p.z * m.inv_cell) - (float)mb2);
-    key = (uint32_t)(i0 + i1 * m.dx + i2 * m.dx * m.dy);
-  }
+  const uint32_t key = voxel_index_key(m, in[(size_t)c * cap + i], min_distance);
   keys[(size_t)c * cap + i] = key;
   vals[(size_t)c * cap + i] = i;
 }
@@ -1781,8 +1767,14 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   compute_bounds(s, ws, in, cnt_in, B, cap, min_distance);
   hipLaunchKernelGGL(k_voxel_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, cnt_in, ws.vmeta.p, B, leaf, ws.sort_passes.p);
   const dim3 grid(div_up((long)cap, kPointBlock), B);
-  hipLaunchKernelGGL(k_voxel_keys, grid, dim3(kPointBlock), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap, min_distance);
-  sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
+  if (sort_pairs_in_tiles(cap)) {
+    // the tile sort computes a point's voxel index while it loads its tile: no key pass, no (key, index) arrays written and read back
+    const VoxelKeySource vk{in, ws.vmeta.p, min_distance};
+    sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p, &vk);
+  } else {
+    hipLaunchKernelGGL(k_voxel_keys, grid, dim3(kPointBlock), 0, s, in, ws.vmeta.p, ws.keys_a.p, ws.vals_a.p, cap, min_distance);
+    sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
+  }
   const int nblk = div_up((long)cap, kScanTile);
   ws.scan_local.ensure((size_t)B * cap);
   ws.scan_block.ensure((size_t)B * nblk);

@@ -79,7 +79,16 @@ struct CloudSet {
 // Result ends up in (keys_a, vals_a) of the workspace.
 // d_passes (optional, [B] on the device): 8-bit passes segment c really needs (its keys are below 2^(8 d_passes[c]) - 1, or below
 // 2^(8 d_passes[c]) when every segment element carries a real key); honoured by the in-LDS tile path, ignored by the global passes.
-void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes = nullptr);
+// voxel (optional; only where sort_pairs_in_tiles(cap)): the keys are pcl::VoxelGrid's voxel indices of the points `pts` (grid.hpp
+// voxel_index_key), computed by the tile sort itself while it loads a tile - keys_a / vals_a are not read.
+struct VoxelKeySource {
+  const float4* pts;
+  const GridMeta* vmeta;
+  double min_distance;
+};
+bool sort_pairs_in_tiles(size_t cap);  // segments of this capacity go through the in-LDS tile sort + merges (else: global LSD passes)
+void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes = nullptr,
+                const VoxelKeySource* voxel = nullptr);
 // Exclusive scan of ws.flags per cloud: position(i) = ws.scan_local[i] + ws.scan_block[c*nblk + i/1024]; totals[c].
 void scan_flags(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts);
 void scan_blocks(hipStream_t s, Workspace& ws, int B, size_t cap);  // the second stage alone (the caller's kernel did the first)

@@ -16,6 +16,26 @@
 
 namespace mi355 {
 
+// A1: the distance filter's test, and P1: pcl::VoxelGrid's voxel index of a point (k_voxel_meta keeps min_b_ in ox / oy / oz as int bits and
+// div_b_ in dx / dy / dz) - kEmptyKey for a point the filter drops.  Shared by k_voxel_keys and by the tile sort that computes the keys
+// while it loads its tile (sort.hip).
+__device__ __forceinline__ bool passes_distance(const float4& p, double min_distance) {
+  if (min_distance < 0.0) return true;
+  const float nrm = sqrtf(p.x * p.x + (p.y * p.y + p.z * p.z));
+  return min_distance < (double)nrm;
+}
+__device__ __forceinline__ uint32_t voxel_index_key(const GridMeta& m, const float4& p, double min_distance) {
+  uint32_t key = kEmptyKey;
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !m.overflow && passes_distance(p, min_distance)) {
+    const int mb0 = __float_as_int(m.ox), mb1 = __float_as_int(m.oy), mb2 = __float_as_int(m.oz);
+    const int i0 = (int)(floorf(p.x * m.inv_cell) - (float)mb0);
+    const int i1 = (int)(floorf(p.y * m.inv_cell) - (float)mb1);
+    const int i2 = (int)(floorf(p.z * m.inv_cell) - (float)mb2);
+    key = (uint32_t)(i0 + i1 * m.dx + i2 * m.dx * m.dy);
+  }
+  return key;
+}
+
 struct GridView {
   const float4* pts;      // this cloud's sorted points
   const int* orig;        // sorted -> caller index

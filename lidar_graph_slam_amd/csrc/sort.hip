@@ -7,6 +7,7 @@
 // ballots (no LDS atomics on the scatter path) and keeps its 256 digit counters in LDS.  Stability makes the
 // order inside a voxel "ascending point index" — the deterministic rule the oracle follows too.
 #include "engine.hpp"
+#include "grid.hpp"
 #include "primitives.hpp"
 
 namespace mi355 {
@@ -141,10 +142,13 @@ __device__ __forceinline__ void tile_geometry(int n, int& nt, int& tl) {
 
 // A cloud of ONE tile is written straight to (keys_final, vals_final) — where the merge rounds would deliver it — and the merge
 // kernels skip it: a voxelised scan costs one launch's worth of traffic, not three.
+// VOXEL: the keys are the voxel indices of the points vpts (VoxelKeySource), computed here - keys_in is not read.
+template <bool VOXEL>
 __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
                                                           uint32_t* __restrict__ keys_final, int* __restrict__ vals_final,
                                                           const int* __restrict__ counts, size_t cap, int passes_max,
-                                                          const int* __restrict__ seg_passes) {
+                                                          const int* __restrict__ seg_passes, const float4* __restrict__ vpts,
+                                                          const GridMeta* __restrict__ vmeta, double min_distance) {
   __shared__ uint32_t keyL[kTsTile];
   __shared__ uint16_t idxL[kTsTile];
   __shared__ uint16_t cnt[kTsWaves][256];
@@ -171,11 +175,33 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   const int rounds = span / kWave;  // <= kTsE
   const int p0 = w * span + l;
   const int lim = len - p0;  // element r of this lane exists iff r * kWave < lim
-  const uint32_t* kin = keys_in + o + p0;
+  if constexpr (VOXEL) {
+    const GridMeta vm = vmeta[c];
+    const float4* pin = vpts + o + p0;
+    constexpr int kLoadGroup = 6;  // points in flight per lane (24 float4 at once would not fit beside the 48 key / index registers)
+    static_assert(kTsE % kLoadGroup == 0, "load groups");
 #pragma unroll
-  for (int r = 0; r < kTsE; r++) {
-    key[r] = (r * kWave < lim && r < rounds) ? kin[r * kWave] : 0xFFFFFFFFu;
-    il[r] = (uint32_t)(p0 + r * kWave) << 16;
+    for (int r0 = 0; r0 < kTsE; r0 += kLoadGroup) {
+      float4 pv[kLoadGroup];
+#pragma unroll
+      for (int u = 0; u < kLoadGroup; u++) {
+        const int r = r0 + u;
+        pv[u] = (r * kWave < lim && r < rounds) ? pin[r * kWave] : make_float4(NAN, NAN, NAN, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kLoadGroup; u++) {
+        const int r = r0 + u;
+        key[r] = (r * kWave < lim && r < rounds) ? voxel_index_key(vm, pv[u], min_distance) : 0xFFFFFFFFu;
+        il[r] = (uint32_t)(p0 + r * kWave) << 16;
+      }
+    }
+  } else {
+    const uint32_t* kin = keys_in + o + p0;
+#pragma unroll
+    for (int r = 0; r < kTsE; r++) {
+      key[r] = (r * kWave < lim && r < rounds) ? kin[r * kWave] : 0xFFFFFFFFu;
+      il[r] = (uint32_t)(p0 + r * kWave) << 16;
+    }
   }
   const unsigned long long lt_mask = (1ull << l) - 1ull;
   // (fully unrolled: carried through a rolled loop the two register arrays become 32-wide vector values that the compiler
@@ -341,16 +367,25 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
 
 // Sorts B segments of (key, index-in-segment) pairs by the low 8 * passes key bits, stably; the result ends up in
 // (keys_a, vals_a) of the workspace.  vals_a on input must be the identity (vals[i] = i) — every caller's is.
-void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes) {
+bool sort_pairs_in_tiles(size_t cap) { return div_up((long)cap, kTsTile) <= 64; }
+
+void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_counts, int passes, const int* d_passes, const VoxelKeySource* voxel) {
   TimedLaunch tl(KF_SORT, s);
   const int max_tiles = div_up((long)cap, kTsTile);
+  if (voxel && !sort_pairs_in_tiles(cap)) throw std::logic_error("sort_pairs: a voxel key source needs the tile path");
   if (max_tiles <= 64) {  // up to 1.5 M elements per segment: log2(tiles) merge rounds still move less than 4 global passes
     // tile sort a -> b, then ceil(log2(max_tiles)) merge rounds ping-ponging; an odd number of hops ends in b: swap the handles
     int hops = 1;
     for (int run = 1; run < max_tiles; run *= 2) hops++;
     // after `hops` hops (a -> b -> a ...) the result sits in b when hops is odd
-    hipLaunchKernelGGL(k_sort_tile, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
-                       (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes, d_passes);
+    if (voxel)
+      hipLaunchKernelGGL(k_sort_tile<true>, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
+                         (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes, d_passes, voxel->pts,
+                         voxel->vmeta, voxel->min_distance);
+    else
+      hipLaunchKernelGGL(k_sort_tile<false>, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
+                         (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes, d_passes,
+                         (const float4*)nullptr, (const GridMeta*)nullptr, -1.0);
     hops = 1;
     uint32_t* ki = ws.keys_b.p; uint32_t* ko = ws.keys_a.p;
     int* vi = ws.vals_b.p; int* vo = ws.vals_a.p;
