@@ -1726,10 +1726,13 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
     const float4 mine = a;
     int cnt = 1;
     bool open = head;  // still collecting
+    // the key and point of lane + d reach this lane one lane per step: a DPP whole-wave shift in the VALU (v_mov_b32_dpp wave_shl:1), where
+    // __shfl_down(x, d) was a ds_bpermute round trip per value and step that the next step's `take` waited for
+    uint32_t kk = k;
+    float px = mine.x, py = mine.y, pz = mine.z, pw = mine.w;
     for (int d = 1; d < kWave; d++) {
-      const uint32_t kk = __shfl_down(k, d, kWave);
-      const float px = __shfl_down(mine.x, d, kWave), py = __shfl_down(mine.y, d, kWave), pz = __shfl_down(mine.z, d, kWave),
-                  pw = __shfl_down(mine.w, d, kWave);
+      kk = wave_shl1(kk);
+      px = wave_shl1(px); py = wave_shl1(py); pz = wave_shl1(pz); pw = wave_shl1(pw);
       const bool in_wave = lane + d < kWave;
       const bool take = open && in_wave && kk == k;
       if (take) { a.x += px; a.y += py; a.z += pz; a.w += pw; cnt++; }

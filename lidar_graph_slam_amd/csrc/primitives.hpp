@@ -75,6 +75,10 @@ __device__ __forceinline__ double block_sum_columns(const double* acc, double* w
   return total;
 }
 
+// The value of lane + 1 (0 in lane 63): one whole-wave DPP shift, no LDS round trip.
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true)); }
+
 // ---- wave / row all-reductions without LDS ------------------------------------------------------------------------
 // __shfl_xor compiles to ds_bpermute_b32 on gfx950: an LDS-crossbar round trip (~100 cycles) per step, and the six steps of a
 // wave reduction depend on each other.  The tile kernels reduce a bounding box (6 values), group boxes, radii and counts per tile and
