@@ -296,7 +296,10 @@ __device__ __forceinline__ uint32_t tile_order_key(const GridMeta& m, const floa
 
 // (round 4: kGiGroups x 64 consecutive elements per wave, all their loads in flight together - with one element per lane a wave was
 // a chain of dependent operations: sorted index -> point gather -> CAS -> slot store, 90 % of its cycles waiting)
-constexpr int kGiGroups = 4;
+#ifndef GI_GROUPS
+#define GI_GROUPS 4
+#endif
+constexpr int kGiGroups = GI_GROUPS;
 __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
                                                        const GridMeta* __restrict__ meta, float4* __restrict__ pts, int* __restrict__ orig,
                                                        HashSlot* __restrict__ table, size_t cap, size_t slots_cap, int G, int B,
@@ -1665,7 +1668,10 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
 // four dependent memory operations (meta, keys / indices, the gather, the output position) around ~500 instructions - and 8 192
 // resident waves of that shape moved 4.3 GB in 3.9 ms (PMC: 73 % of the wave cycles waiting).  Now the loads of all groups are
 // issued together (four gathers per lane in flight), then every group is folded and written as before.
-constexpr int kVcGroups = 4;
+#ifndef VC_GROUPS
+#define VC_GROUPS 4
+#endif
+constexpr int kVcGroups = VC_GROUPS;
 __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                          const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
                                                          const int* __restrict__ local,
