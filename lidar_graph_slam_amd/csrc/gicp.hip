@@ -843,9 +843,60 @@ struct CorrBest {
   int j1;           // sorted target index behind k1
 };
 
+#ifndef CORR_PK
+#define CORR_PK 1  // 0: one candidate per step from float4 entries (A/B builds)
+#endif
+// CORR_PK: the ring holds the candidates in PAIRS - (x0 x1 y0 y1) (z0 z1 w0 w1) per 32 bytes - so that a lane reads the coordinates of
+// two candidates as aligned register pairs and takes both squared distances with packed fp32 instructions (v_pk_add / v_pk_mul /
+// v_pk_fma_f32: 6 instead of 12 for two candidates, the same IEEE operations in the same order per candidate).
+typedef float corr_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void corr_put(float4* cand, int c, float x, float y, float z, float w) {
+#if CORR_PK
+  float* f = reinterpret_cast<float*>(cand) + 8 * (c >> 1) + (c & 1);
+  f[0] = x; f[2] = y; f[4] = z; f[6] = w;
+#else
+  cand[c] = make_float4(x, y, z, w);
+#endif
+}
+__device__ __forceinline__ float corr_payload(const float4* cand, int c) {
+#if CORR_PK
+  return reinterpret_cast<const float*>(cand)[8 * (c >> 1) + 6 + (c & 1)];
+#else
+  return cand[c].w;
+#endif
+}
 __device__ __forceinline__ void corr_scan(const float4* __restrict__ cand, int n, float qx, float qy, float qz, CorrBest& b) {
   const uint32_t before = b.k1;
   uint32_t k1 = b.k1, k2 = b.k2;
+#if CORR_PK
+  {
+    auto take = [&](float dd, int c) {
+      const uint32_t key = (__float_as_uint(dd) & ~kCorrOrdMask) | (uint32_t)c;
+      k2 = max(min(k1, k2), min(max(k1, k2), key));  // median(k1, k2, key) -> v_med3_u32: the new runner-up
+      k1 = min(k1, key);
+    };
+    const corr_v2f qxv = {qx, qx}, qyv = {qy, qy}, qzv = {qz, qz};
+    const int np = n >> 1;
+#pragma unroll 4
+    for (int p = 0; p < np; p++) {
+      const float4 a = cand[2 * p], c2 = cand[2 * p + 1];  // (x0 x1 y0 y1) (z0 z1 w0 w1)
+      const corr_v2f px = {a.x, a.y}, py = {a.z, a.w}, pz = {c2.x, c2.y};
+      const corr_v2f dx = qxv - px, dy = qyv - py, dz = qzv - pz;
+      const corr_v2f dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      take(dd.x, 2 * p);
+      take(dd.y, 2 * p + 1);
+    }
+    if (n & 1) {
+      const float4 a = cand[2 * np], c2 = cand[2 * np + 1];
+      const float dx = qx - a.x, dy = qy - a.z, dz = qz - c2.x;
+      take(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)), n - 1);
+    }
+    if (k1 != before) b.j1 = __float_as_int(corr_payload(cand, (int)(k1 & kCorrOrdMask)));
+    b.k1 = k1;
+    b.k2 = k2;
+    return;
+  }
+#endif
   auto one = [&](const float4& p, int c) {
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -911,7 +962,7 @@ __device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCe
         corr_scan(cand, n, qx, qy, qz, best);
         n = 0;
       }
-      if (in) cand[n + __popcll(mask & below)] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(idx[u]));
+      if (in) corr_put(cand, n + __popcll(mask & below), p[u].x, p[u].y, p[u].z, __int_as_float(idx[u]));
       n += cnt;
     }
   }
