@@ -870,8 +870,12 @@ __device__ __forceinline__ void corr_scan(const float4* __restrict__ cand, int n
   uint32_t k1 = b.k1, k2 = b.k2;
 #if CORR_PK
   {
+    // (the mask lives in a VGPR: with a literal mask AND a scalar position the and-or needs two constant-bus operands and the compiler
+    // splits it into v_and + v_or)
+    uint32_t keep = ~kCorrOrdMask;
+    asm volatile("" : "+v"(keep));
     auto take = [&](float dd, int c) {
-      const uint32_t key = (__float_as_uint(dd) & ~kCorrOrdMask) | (uint32_t)c;
+      const uint32_t key = (__float_as_uint(dd) & keep) | (uint32_t)c;
       k2 = max(min(k1, k2), min(max(k1, k2), key));  // median(k1, k2, key) -> v_med3_u32: the new runner-up
       k1 = min(k1, key);
     };
