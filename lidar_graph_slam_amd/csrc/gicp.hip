@@ -817,7 +817,7 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
 // One wave takes 64 consecutive source points (Morton order: a compact patch, and so is its rigid transform), gathers the
 // target points of the cells around the patch into LDS once and every lane scans that list for its own query — the scheme
 // of k_knn_cov_tile (tile.hpp) with a 2-element network.  A per-lane walk pays one dependent, divergent load per candidate
-// and per lane; here a candidate costs one coalesced global load per WAVE and, per lane, one LDS broadcast + 9 VALU ops:
+// and per lane; here a candidate costs one coalesced global load per WAVE and, per lane, one LDS broadcast + 9 VALU ops (6 with CORR_PK, below):
 // the squared distance (fma form) with its low kCorrOrdBits mantissa bits replaced by the candidate's position in the list
 // is ONE 32-bit key; v_min_u32 keeps the smallest key, v_med3_u32 the runner-up, no branch, no index bookkeeping.
 //   round 1: radius r1 (most points have their correspondent within a few decimetres);
