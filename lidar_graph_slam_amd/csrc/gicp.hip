@@ -450,7 +450,7 @@ __device__ __forceinline__ int group_min_i(int v) {
 // valid, q, jprev: the same in the lanes of a group.  complete == false: the cube needs more than 64 cells even at the top level
 // (it cannot for a finite reach); the caller searches such a query per lane.
 __device__ __forceinline__ NnState group_search(const GridView& g, bool valid, float qx, float qy, float qz, int jprev, float max_corr_d2,
-                                                bool track_margin) {
+                                                bool track_margin, int* scratch) {
   const GridMeta& m = g.m;
   const int lane = lane_id(), sub = lane & (kGroupW - 1), gbase = lane & ~(kGroupW - 1);
   NnState out{INFINITY, -1, INFINITY, 0.f, true};
@@ -540,33 +540,106 @@ __device__ __forceinline__ NnState group_search(const GridView& g, bool valid, f
         if (resolve_range(g, key[t], sl[t], s0, e0)) { cs[t] = s0; ce[t] = e0; }
       }
   }
-  // ---- scan: every cell by the whole group, kGroupW points per step, two steps in flight
+  // ---- scan: the points of the group's cells as ONE flat sequence (cells in slot-major, lane order), kGroupW points per step and
+  // kGroupDepth steps in flight.  (Until round 4 the group walked its up to 64 cells one after the other, a dependent load per cell
+  // of ~30 points: 10 - 27 memory latencies per query against a 3 x 10^5-point sub-map.)  scratch: 2 x 64 ints of LDS per group -
+  // exclusive prefix sums of the cell sizes and the cells' range starts; a position finds its cell by binary search.
   float d1 = INFINITY, d2nd = INFINITY;
   int j1 = -1;
+  {
+    constexpr int kCells = kGroupW * kGroupSlots;  // 64
+    constexpr int kGroupDepth = 4;
+    int run = 0;  // exclusive prefix over the group's cells, slot-major
+    int excl[kGroupSlots];
 #pragma unroll
-  for (int t = 0; t < kGroupSlots; t++) {
+    for (int t = 0; t < kGroupSlots; t++) {
+      const int sz = max(ce[t] - cs[t], 0);
+      int incl = sz;
 #pragma unroll
-    for (int own = 0; own < kGroupW; own++) {
-      const int s0 = __shfl(cs[t], gbase + own, kWave), e0 = __shfl(ce[t], gbase + own, kWave);
-      if (!__any(e0 > s0)) continue;
-      for (int j = s0 + sub; __any(j < e0); j += 2 * kGroupW) {
-        const bool in0 = j < e0, in1 = j + kGroupW < e0;
-        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-        if (in0) p0 = g.pts[j];
-        if (in1) p1 = g.pts[j + kGroupW];
+      for (int off = 1; off < kGroupW; off <<= 1) {
+        const int v = __shfl_up(incl, off, kWave);
+        if (sub >= off) incl += v;
+      }
+      excl[t] = run + incl - sz;
+      run += __shfl(incl, gbase + kGroupW - 1, kWave);
+    }
+    const int total = run;  // (the same in the lanes of a group)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const float4 pp = u ? p1 : p0;
-          const int jj = j + u * kGroupW;
-          const float dd = dist2f(qx, qy, qz, pp.x, pp.y, pp.z);
-          if ((u ? in1 : in0) && dd <= R2) {
-            if (j1 < 0 || dd < d1 || (dd == d1 && g.orig[jj] < g.orig[j1])) {
-              if (j1 >= 0) d2nd = fminf(d2nd, d1);
-              d1 = dd;
-              j1 = jj;
-            } else if (dd < d2nd) {
-              d2nd = dd;
+    for (int t = 0; t < kGroupSlots; t++) {
+      scratch[t * kGroupW + sub] = excl[t];
+      scratch[kCells + t * kGroupW + sub] = cs[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // Which walk?  A voxelised scan as the target has ~6 points per base cell: one step per cell leaves most of a group's lanes idle and
+    // the flat sequence wins (a lone 64 k pair 1.46 -> 1.28 ms).  A sub-map of twenty overlapped scans has 30 - 60: a step per cell is a
+    // full one, and the flat sequence only adds its binary searches (the odometry stream 2.0 -> 2.2 ms per scan with it): dense groups
+    // keep the walk cell by cell.  (The choice is per wave: both groups of a wave take the same loop.)
+    int nonempty = 0;
+#pragma unroll
+    for (int t = 0; t < kGroupSlots; t++) nonempty += __popcll(__ballot(ce[t] > cs[t]));
+    const long all_points = (long)__shfl(total, 0, kWave) + (long)__shfl(total, kGroupW, kWave);
+    const bool dense = all_points >= 32l * nonempty;  // (16 / 24 / 48: the stream 2.04 / 1.98 / 1.97 ms per scan, the lone pair 1.36 / 1.34 / 1.33 ms)
+    if (dense) {
+#pragma unroll
+      for (int t = 0; t < kGroupSlots; t++) {
+#pragma unroll
+        for (int own = 0; own < kGroupW; own++) {
+          const int s0 = __shfl(cs[t], gbase + own, kWave), e0 = __shfl(ce[t], gbase + own, kWave);
+          if (!__any(e0 > s0)) continue;
+          for (int j = s0 + sub; __any(j < e0); j += 2 * kGroupW) {
+            const bool in0 = j < e0, in1 = j + kGroupW < e0;
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+            if (in0) p0 = g.pts[j];
+            if (in1) p1 = g.pts[j + kGroupW];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              const float4 pq = u ? p1 : p0;
+              const int jq = j + u * kGroupW;
+              const float dd = dist2f(qx, qy, qz, pq.x, pq.y, pq.z);
+              if ((u ? in1 : in0) && dd <= R2) {
+                if (j1 < 0 || dd < d1 || (dd == d1 && g.orig[jq] < g.orig[j1])) {
+                  if (j1 >= 0) d2nd = fminf(d2nd, d1);
+                  d1 = dd;
+                  j1 = jq;
+                } else if (dd < d2nd) {
+                  d2nd = dd;
+                }
+              }
             }
+          }
+        }
+      }
+    } else
+    for (int f0 = 0; __any(f0 < total); f0 += kGroupW * kGroupDepth) {
+      int jj[kGroupDepth];
+      bool in[kGroupDepth];
+      float4 pp[kGroupDepth];
+#pragma unroll
+      for (int u = 0; u < kGroupDepth; u++) {
+        const int f = f0 + u * kGroupW + sub;
+        in[u] = f < total;
+        jj[u] = 0;
+        pp[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[u]) {
+          int lo = 0;
+#pragma unroll
+          for (int step = kCells / 2; step > 0; step >>= 1)
+            if (scratch[lo + step] <= f) lo += step;
+          jj[u] = scratch[kCells + lo] + (f - scratch[lo]);
+          pp[u] = g.pts[jj[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kGroupDepth; u++) {
+        const float dd = dist2f(qx, qy, qz, pp[u].x, pp[u].y, pp[u].z);
+        if (in[u] && dd <= R2) {
+          if (j1 < 0 || dd < d1 || (dd == d1 && g.orig[jj[u]] < g.orig[j1])) {
+            if (j1 >= 0) d2nd = fminf(d2nd, d1);
+            d1 = dd;
+            j1 = jj[u];
+          } else if (dd < d2nd) {
+            d2nd = dd;
           }
         }
       }
@@ -598,6 +671,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_group(const f
                                                                       float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
                                                                       double margin_step) {
   __shared__ int queue[kTile];
+  __shared__ int gscratch[kGicpBlock / kGroupW][2 * kGroupW * kGroupSlots];  // group_search: prefix sums / range starts of a group's cells
   __shared__ int qcount;
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
@@ -636,7 +710,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_group(const f
       const int i = valid ? queue[tq] : 0;
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
-      NnState stq = group_search(g, valid, qx, qy, qz, valid ? corr[so + i] : -1, max_corr_d2, track_margin);
+      NnState stq = group_search(g, valid, qx, qy, qz, valid ? corr[so + i] : -1, max_corr_d2, track_margin, gscratch[threadIdx.x / kGroupW]);
       // (a cube that does not fit 64 cells: one lane of the group walks the hash as k_gicp_correspond would)
       const bool lone = valid && !stq.complete && (threadIdx.x & (kGroupW - 1)) == 0;
       if (lone) stq = lane_search(g, qx, qy, qz, corr[so + i], max_corr_d2, true);
