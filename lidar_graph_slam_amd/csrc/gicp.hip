@@ -581,33 +581,61 @@ __device__ __forceinline__ NnState group_search(const GridView& g, bool valid, f
     const long all_points = (long)__shfl(total, 0, kWave) + (long)__shfl(total, kGroupW, kWave);
     const bool dense = all_points >= 32l * nonempty;  // (16 / 24 / 48: the stream 2.04 / 1.98 / 1.97 ms per scan, the lone pair 1.36 / 1.34 / 1.33 ms)
     if (dense) {
+      // the non-empty cells, compacted into the group's scratch as (start, end) pairs, then walked with the loads of the NEXT cell's first
+      // two steps in flight under the arithmetic of the current one (the walk used to be a dependent load per cell)
+      int n_cells = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
       for (int t = 0; t < kGroupSlots; t++) {
-#pragma unroll
-        for (int own = 0; own < kGroupW; own++) {
-          const int s0 = __shfl(cs[t], gbase + own, kWave), e0 = __shfl(ce[t], gbase + own, kWave);
-          if (!__any(e0 > s0)) continue;
-          for (int j = s0 + sub; __any(j < e0); j += 2 * kGroupW) {
-            const bool in0 = j < e0, in1 = j + kGroupW < e0;
-            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-            if (in0) p0 = g.pts[j];
-            if (in1) p1 = g.pts[j + kGroupW];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              const float4 pq = u ? p1 : p0;
-              const int jq = j + u * kGroupW;
-              const float dd = dist2f(qx, qy, qz, pq.x, pq.y, pq.z);
-              if ((u ? in1 : in0) && dd <= R2) {
-                if (j1 < 0 || dd < d1 || (dd == d1 && g.orig[jq] < g.orig[j1])) {
-                  if (j1 >= 0) d2nd = fminf(d2nd, d1);
-                  d1 = dd;
-                  j1 = jq;
-                } else if (dd < d2nd) {
-                  d2nd = dd;
-                }
-              }
-            }
+        const bool has = ce[t] > cs[t];
+        const unsigned long long mask = (__ballot(has) >> gbase) & ((kGroupW >= 64) ? ~0ull : ((1ull << (kGroupW & 63)) - 1ull));
+        if (has) {
+          const int pos = n_cells + __popcll(mask & ((1ull << sub) - 1ull));
+          scratch[2 * pos] = cs[t];
+          scratch[2 * pos + 1] = ce[t];
+        }
+        n_cells += __popcll(mask);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      auto consider = [&](bool in, int jq, const float4& pq) {
+        const float dd = dist2f(qx, qy, qz, pq.x, pq.y, pq.z);
+        if (in && dd <= R2) {
+          if (j1 < 0 || dd < d1 || (dd == d1 && g.orig[jq] < g.orig[j1])) {
+            if (j1 >= 0) d2nd = fminf(d2nd, d1);
+            d1 = dd;
+            j1 = jq;
+          } else if (dd < d2nd) {
+            d2nd = dd;
           }
+        }
+      };
+      auto fetch = [&](int k, int& s0, int& e0, float4& p0, float4& p1) {
+        s0 = e0 = 0;
+        p0 = p1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n_cells) {
+          s0 = scratch[2 * k];
+          e0 = scratch[2 * k + 1];
+          if (s0 + sub < e0) p0 = g.pts[s0 + sub];
+          if (s0 + sub + kGroupW < e0) p1 = g.pts[s0 + sub + kGroupW];
+        }
+      };
+      int s_nx, e_nx;
+      float4 p0_nx, p1_nx;
+      fetch(0, s_nx, e_nx, p0_nx, p1_nx);
+      const int n_max = max(__shfl(n_cells, 0, kWave), __shfl(n_cells, kGroupW, kWave));  // (both groups of the wave walk together)
+      for (int k = 0; k < n_max; k++) {
+        const int s0 = s_nx, e0 = e_nx;
+        const float4 p0 = p0_nx, p1 = p1_nx;
+        fetch(k + 1, s_nx, e_nx, p0_nx, p1_nx);
+        consider(s0 + sub < e0, s0 + sub, p0);
+        consider(s0 + sub + kGroupW < e0, s0 + sub + kGroupW, p1);
+        for (int j = s0 + sub + 2 * kGroupW; __any(j < e0); j += 2 * kGroupW) {  // a cell of more than 64 points: the rest as before
+          const bool in0 = j < e0, in1 = j + kGroupW < e0;
+          float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+          if (in0) q0 = g.pts[j];
+          if (in1) q1 = g.pts[j + kGroupW];
+          consider(in0, j, q0);
+          consider(in1, j + kGroupW, q1);
         }
       }
     } else
