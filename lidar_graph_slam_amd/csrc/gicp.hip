@@ -1780,8 +1780,13 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     }
     TimedLaunch tl(KF_CORRESPOND, s);
     if (groups && isfinite(P.max_corr_d2)) {
-      constexpr int kTile = 64;
-      const int Gg = std::max(1, std::min(1024, div_up((long)gb.cap, kTile)));
+#ifndef GROUP_TILE
+#define GROUP_TILE 16
+#endif
+      // queries per block: a block searches 8 of them per round (a 32-lane group each), one round after the other - with 64 queries a
+      // block was a chain of 8 rounds and a 16 k-point scan filled half the chip's wave slots (230 us per from-scratch launch of the stream)
+      constexpr int kTile = GROUP_TILE;
+      const int Gg = std::max(1, std::min(4096, div_up((long)gb.cap, kTile)));
       hipLaunchKernelGGL(k_gicp_correspond_group<kTile>, dim3(xcd_grid(Gg, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p,
                          tgt.orig.p, tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p,
                          P.max_corr_d2, Gg, gb.S, (double)tn.margin_step);
