@@ -1781,7 +1781,7 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     TimedLaunch tl(KF_CORRESPOND, s);
     if (groups && isfinite(P.max_corr_d2)) {
 #ifndef GROUP_TILE
-#define GROUP_TILE 16
+#define GROUP_TILE 8
 #endif
       // queries per block: a block searches 8 of them per round (a 32-lane group each), one round after the other - with 64 queries a
       // block was a chain of 8 rounds and a 16 k-point scan filled half the chip's wave slots (230 us per from-scratch launch of the stream)
