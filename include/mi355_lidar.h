@@ -130,7 +130,8 @@ typedef struct mi355_result {
   double trans_probability; /* NDT */
   int n_source;             /* source points actually registered (after any prefilter) */
   int n_target;
-  int n_inliers;            /* correspondences within max_correspondence_distance at the last linearisation (GICP) */
+  int n_inliers;            /* GICP: correspondences within max_correspondence_distance at the last linearisation;
+                               NDT: evaluations (computeDerivatives / computeHessian passes over the source) the pair asked for */
   int status;               /* batch mode: MI355_PAIR_OK, or why the pair was not registered (T = the guess, converged = 0) */
 } mi355_result;
 #define MI355_PAIR_OK 0

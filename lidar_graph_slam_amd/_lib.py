@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_lidar.so")
+# MI355_LIB: another build of the same library (the A/B scripts under benchmarks/ time an older build beside the current one)
+LIB_PATH = os.environ.get("MI355_LIB") or os.path.join(_HERE, "libmi355_lidar.so")
 _LIB = None
 
 METHOD_FAST_GICP, METHOD_NDT_OMP, METHOD_ICP, METHOD_GICP = 0, 1, 2, 3

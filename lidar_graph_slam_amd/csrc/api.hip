@@ -14,7 +14,8 @@ thread_local int g_family_override = -1;
 const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
                                                  "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
                                                  "k_gicp_step", "k_fitness",
-                                                 "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)"};
+                                                 "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)",
+                                                 "ndt_target_prep(k_ndt_bounds,keys,heads,scan,size,clear)", "ndt_target_sort(k_sort_tile,k_sort_merge)", "k_ndt_leaves(k_ndt_leaf_sums,k_ndt_leaf_finalize)", "k_ndt_derivatives", "k_ndt_advance"};
 const Tuning& tuning() {
   static const Tuning t = [] {
     Tuning v;
@@ -45,6 +46,7 @@ const Tuning& tuning() {
     getf("MI355_LM_CUS", v.lm_cus);
     getf("MI355_GRID_CELL", v.grid_cell);
     geti("MI355_KNN_STATS", v.knn_stats);
+    geti("MI355_NDT_WAVES", v.ndt_waves);
     return v;
   }();
   return t;
@@ -126,13 +128,15 @@ struct mi355_reg {
   DevBuf<int> cnt_src, cnt_tgt;
   CloudSet src, tgt;
   GicpBatch gb;
-  NdtTarget* ndt = nullptr;
+  NdtTargets* ndt = nullptr;
+  NdtSolver* ndt_solver = nullptr;
   size_t n_src = 0, n_tgt = 0;
   bool has_src = false, has_tgt = false, aligned = false;
   float last_T[16];
   DevBuf<float4> aligned_dev;
   ~mi355_reg() {
-    if (ndt) ndt_target_destroy(ndt);
+    if (ndt) ndt_targets_destroy(ndt);
+    if (ndt_solver) ndt_solver_destroy(ndt_solver);
   }
 };
 
@@ -150,8 +154,11 @@ struct mi355_batch {
   int method = MI355_METHOD_FAST_GICP;
   mi355_gicp_params gp;
   mi355_ndt_params np;       // method == MI355_METHOD_NDT_OMP
-  NdtBatch* ndt = nullptr;
-  std::vector<int> ndt_src_counts, ndt_tgt_counts;  // points per cloud after the prefilter (host copies)
+  NdtTargets* ndt = nullptr;  // every target's voxel Gaussians, built by one launch sequence per mi355_batch_set_targets*
+  NdtSolver* ndt_solver = nullptr;
+  int ndt_max_src = 0;        // no source holds more points than this (the counts before the prefilter: nothing is read back)
+  const float4* ndt_tgt_pts = nullptr;  // the targets as the leaf builder took them (after the prefilter): their NN voxel hash -
+  const int* ndt_tgt_cnt = nullptr;     // what getFitnessScore searches - is built only when a fitness is asked for
   int n_sources = 0, n_targets = 0;          // live slots (mi355_batch_set_live; = the allocation after mi355_batch_create)
   int alloc_sources = 0, alloc_targets = 0;  // slots the buffers were sized for
   size_t cap = 0;
@@ -219,7 +226,8 @@ struct mi355_batch {
     for (auto& pt : parts) pt->prep_pending[0] = pt->prep_pending[1] = pt->knn_pending[0] = pt->knn_pending[1] = false;
   }
   ~mi355_batch() {
-    if (ndt) ndt_batch_destroy(ndt);
+    if (ndt) ndt_targets_destroy(ndt);
+    if (ndt_solver) ndt_solver_destroy(ndt_solver);
     parts.clear();
     for (auto& e : pin_free)
       if (e) (void)hipEventDestroy(e);
@@ -572,6 +580,8 @@ static void adopt_bfgs_params(mi355_reg* r) {  // the covariance path reads gp
   r->gp.regularization_method = MI355_REG_PLANE;
 }
 
+static void reg_build_ndt_target(mi355_reg* reg, bool keep_fp64_leaves = false);
+
 // ---- registration object -------------------------------------------------------------------------------------------
 extern "C" mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* params) {
   if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP && method != MI355_METHOD_GICP))
@@ -602,7 +612,10 @@ extern "C" mi355_reg* mi355_reg_create(mi355_ctx* ctx, int method, const void* p
     delete r;
     return nullptr;
   }
-  if (method == MI355_METHOD_NDT_OMP) r->ndt = ndt_target_create();
+  if (method == MI355_METHOD_NDT_OMP) {
+    r->ndt = ndt_targets_create();
+    r->ndt_solver = ndt_solver_create();
+  }
   for (int i = 0; i < 16; i++) r->last_T[i] = (i % 5 == 0) ? 1.f : 0.f;
   return r;
 }
@@ -646,10 +659,22 @@ extern "C" int mi355_reg_set_params(mi355_reg* reg, const void* params) {
     if (grid_changed && reg->has_tgt)
       return guarded(reg->ctx, [&] {
         MI_HIP(hipSetDevice(reg->ctx->device));
-        ndt_build_target(reg->ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
+        reg_build_ndt_target(reg);
       });
   }
   return MI355_OK;
+}
+
+// N1 of a registration object: its target is a set of ONE.  The fp64 leaves (computeHessian after a refined line search, the parity
+// read-back of every occupied voxel) are built when something asks for them: the staged target points stay on the device.
+static void reg_build_ndt_target(mi355_reg* reg, bool keep_fp64_leaves) {
+  const int bound = (int)reg->n_tgt;
+  ws_reserve(reg->ws, 1, std::max<size_t>(reg->n_tgt, 1));
+  ndt_build_targets(reg->ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->cnt_tgt.p, &bound, 1, std::max<size_t>(reg->n_tgt, 1), reg->np,
+                    keep_fp64_leaves || reg->np.legacy_mt_skip == 0);
+}
+static void reg_need_fp64_leaves(mi355_reg* reg) {
+  if (!ndt_targets_have_fp64_leaves(*reg->ndt)) reg_build_ndt_target(reg, true);
 }
 
 static void reg_upload(mi355_reg* reg, const mi355_cloud_view* cloud, DevBuf<float4>& stage, DevBuf<int>& cnt) {
@@ -683,7 +708,7 @@ extern "C" int mi355_reg_set_target(mi355_reg* reg, const mi355_cloud_view* clou
       reg->tgt.alloc(1, reg->n_tgt);
       build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
     } else {
-      ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
+      reg_build_ndt_target(reg);
       reg->tgt.alloc(1, reg->n_tgt);
       reg->tgt_grid_stale = true;  // getFitnessScore needs the NN structure of the target as well: mi355_reg_fitness builds it
     }
@@ -744,7 +769,10 @@ extern "C" int mi355_reg_align(mi355_reg* reg, const float guess16[16], mi355_re
     } else {
       float I[16];
       for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
-      ndt_align(ctx->stream, reg->ws, *reg->ndt, reg->stage_src.p, reg->n_src, reg->np, guess16 ? guess16 : I, result);
+      // a batch of one: the More-Thuente state advances on the device, nothing is read back between evaluations
+      if (reg->np.legacy_mt_skip == 0) reg_need_fp64_leaves(reg);
+      ndt_solve(ctx->stream, *reg->ndt, *reg->ndt_solver, 1, reg->stage_src.p, reg->n_src, reg->cnt_src.p, (int)reg->n_src, nullptr, guess16 ? guess16 : I, reg->np);
+      ndt_solver_results(*reg->ndt_solver, result, nullptr);
       result->n_source = (int)reg->n_src;
       result->n_target = (int)reg->n_tgt;
     }
@@ -809,7 +837,8 @@ extern "C" int mi355_reg_ndt_derivatives(mi355_reg* reg, const double p6[6], dou
   mi355_ctx* ctx = reg->ctx;
   return guarded(ctx, [&] {
     reg_require(reg);
-    ndt_derivatives(ctx->stream, reg->ws, *reg->ndt, reg->stage_src.p, reg->n_src, reg->np, p6, score, grad6, hess36, hessian_fp64 != 0);
+    if (hessian_fp64) reg_need_fp64_leaves(reg);
+    ndt_derivatives(ctx->stream, *reg->ndt, *reg->ndt_solver, reg->stage_src.p, reg->n_src, reg->np, p6, score, grad6, hess36, hessian_fp64 != 0);
   });
 }
 
@@ -817,7 +846,9 @@ extern "C" int mi355_reg_ndt_num_cells(mi355_reg* reg, size_t* n_cells) {
   if (!reg || !n_cells || reg->method != MI355_METHOD_NDT_OMP) return MI355_EINVAL;
   return guarded(reg->ctx, [&] {
     if (!reg->has_tgt) throw ArgError(MI355_ESTATE, "setInputTarget has not been called");
-    *n_cells = ndt_num_cells(*reg->ndt);
+    MI_HIP(hipSetDevice(reg->ctx->device));
+    reg_need_fp64_leaves(reg);  // (the read-back lists every occupied voxel, the default build only those that get a leaf)
+    *n_cells = ndt_num_cells(reg->ctx->stream, *reg->ndt, 0);
   });
 }
 
@@ -827,6 +858,7 @@ extern "C" int mi355_reg_ndt_cells(mi355_reg* reg, int64_t* leaf_idx, int* leaf_
   return guarded(reg->ctx, [&] {
     if (!reg->has_tgt) throw ArgError(MI355_ESTATE, "setInputTarget has not been called");
     MI_HIP(hipSetDevice(reg->ctx->device));
+    reg_need_fp64_leaves(reg);
     ndt_cells(reg->ctx->stream, *reg->ndt, leaf_idx, leaf_n, mean3, cov9, icov9, min_b3, div_b3);
   });
 }
@@ -1121,7 +1153,7 @@ extern "C" int mi355_reg_set_target_cloud(mi355_reg* reg, mi355_cloud* cloud) {
       reg->tgt.alloc(1, reg->n_tgt);
       build_grid(ctx->stream, reg->ws, reg->stage_tgt.p, reg->cnt_tgt.p, reg->tgt, ctx->grid_cell);
     } else {
-      ndt_build_target(ctx->stream, reg->ws, *reg->ndt, reg->stage_tgt.p, reg->n_tgt, reg->np);
+      reg_build_ndt_target(reg);
       reg->tgt.alloc(1, reg->n_tgt);
       reg->tgt_grid_stale = true;
     }
@@ -1233,7 +1265,10 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
       // the LM loops run AHEAD of the (lowest-priority) preparation chains: their short kernels get the freed wave slots first
       if (N > 1) create_stream(&pt.lm_stream, prio_hi, tuning().lm_cus, true, ctx->compute_units);
     }
-    if (method == MI355_METHOD_NDT_OMP) b->ndt = ndt_batch_create(n_sources, n_targets);
+    if (method == MI355_METHOD_NDT_OMP) {
+      b->ndt = ndt_targets_create();
+      b->ndt_solver = ndt_solver_create();
+    }
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
       create_stream(&sd.stream, prio_lo, N > 1 ? tuning().prep_cus : 1.f, false, ctx->compute_units);
@@ -1287,18 +1322,25 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     const int* cnt = pt.cnt_in[k].p;
     Workspace& ws = pt.ws[k];
     if (pf && (pf->min_distance > 0 || pf->leaf_size > 0 || pf->mean_k > 0))
-      run_prefilter(s, ws, pt.sor_set[k], ctx->grid_cell, *pf, n, b->cap, in, pt.cnt_in[k].p, ws.stage_a, ws.stage_b, ws.count_a, ws.count_b, &pts, &cnt, &set);
-    build_grid(s, ws, pts, cnt, set, ctx->grid_cell, b->method == MI355_METHOD_FAST_GICP);
+      run_prefilter(s, ws, pt.sor_set[k], ctx->grid_cell, *pf, n, b->cap, in, pt.cnt_in[k].p, ws.stage_a, ws.stage_b, ws.count_a, ws.count_b, &pts, &cnt,
+                    (b->method == MI355_METHOD_NDT_OMP && targets) ? nullptr : &set);  // (NDT targets are not indexed next: their leaves are built)
     if (b->method == MI355_METHOD_NDT_OMP) {
-      // NDT (one part): the sources are just points; every target gets its voxel Gaussians (N1).  The leaf builder sizes its launches
-      // on the host, so the counts after the prefilter are read back here (one sync per set call, none per alignment).
-      std::vector<int>& hc = targets ? b->ndt_tgt_counts : b->ndt_src_counts;
-      hc.resize((size_t)n);
-      MI_HIP(hipMemcpyAsync(hc.data(), set.count.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-      MI_HIP(hipStreamSynchronize(s));
-      if (targets)
-        for (int u = 0; u < n; u++) ndt_batch_set_target(s, ws, *b->ndt, u, set.pts.p + (size_t)u * b->cap, (size_t)hc[(size_t)u], b->np);
+      // NDT (one part).  Every target gets its voxel Gaussians (N1) - all of them by ONE launch sequence, sized from the counts the
+      // caller gave (an upper bound of what a prefilter leaves): nothing is read back, nothing synchronises.  The NN voxel hash of the
+      // targets' points is what getFitnessScore searches: built at align time, and only when a fitness is asked for.  The sources are
+      // points in the voxel hash's Morton order (neighbouring lanes of the derivative pass read the same leaves).
+      if (targets) {
+        ndt_build_targets(s, ws, *b->ndt, pts, b->cap, cnt, pt.h_counts[k].data(), n, b->cap, b->np, b->np.legacy_mt_skip == 0);
+        b->ndt_tgt_pts = pts;
+        b->ndt_tgt_cnt = cnt;
+        set.built = false;
+      } else {
+        build_grid(s, ws, pts, cnt, set, ctx->grid_cell, false);
+        b->ndt_max_src = 0;
+        for (int i = 0; i < n; i++) b->ndt_max_src = std::max(b->ndt_max_src, pt.h_counts[k][(size_t)i]);
+      }
     } else {
+      build_grid(s, ws, pts, cnt, set, ctx->grid_cell, true);
       // (batches only: for ONE cloud - a registration object, the scan matcher's sub-map - the sort costs more than the search gains:
       // measured 2.19 instead of 1.99 ms per scan on the config-4 stream)
       build_tile_order(s, ws, set);
@@ -1319,7 +1361,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
   }
   if (side_streams) sd.pending = true;
   if (targets) {
-    b->tgt.built = true;
+    b->tgt.built = b->method == MI355_METHOD_FAST_GICP;
     b->tgt.has_cov = b->method == MI355_METHOD_FAST_GICP;
   }
 }
@@ -1503,10 +1545,14 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
       batch_wait_side(b, main, 1);
       // blocks until every pair has converged (the More-Thuente states advance on the device; the host polls a counter)
       gicp_set_map(main, pt.gb, tgt_of_src, b->n_targets);
-      ndt_batch_align(main, *b->ndt, pt.src.pts.p, b->cap, b->ndt_src_counts.data(), tgt_of_src, guesses16, b->np);
+      ndt_solve(main, *b->ndt, *b->ndt_solver, b->n_sources, pt.src.pts.p, b->cap, pt.src.count.p, b->ndt_max_src, tgt_of_src, guesses16, b->np);
       if (b->with_fitness) {
+        if (!b->tgt.built) {  // the NN voxel hash of the targets, from the points their leaves were built from (on the targets' workspace)
+          build_grid(main, pt.ws[0], b->ndt_tgt_pts, b->ndt_tgt_cnt, pt.tgt, b->ctx->grid_cell, false);
+          b->tgt.built = true;
+        }
         std::vector<float> T((size_t)b->n_sources * 16);
-        ndt_batch_results(*b->ndt, nullptr, T.data());
+        ndt_solver_results(*b->ndt_solver, nullptr, T.data());
         gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
       }
     } else {
@@ -1596,11 +1642,7 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     MI_HIP(hipSetDevice(b->ctx->device));
     if (b->method == MI355_METHOD_NDT_OMP) {
       Part& pt = *b->parts[0];
-      ndt_batch_results(*b->ndt, results, nullptr);
-      for (int i = 0; i < b->n_sources; i++) {
-        results[i].n_source = b->ndt_src_counts[(size_t)i];
-        results[i].n_target = b->ndt_tgt_counts[(size_t)pt.gb.h_map[(size_t)i]];
-      }
+      ndt_solver_results(*b->ndt_solver, results, nullptr);
       if (fitness) gicp_fitness_values(b->stream(), pt.gb, fitness);
     } else {
       for (auto& pt : b->parts)  // (the batch's stream has joined every part's)
@@ -1671,7 +1713,6 @@ extern "C" int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets
     b->n_sources = n_sources;
     b->n_targets = b->tgt.B = n_targets;
     batch_layout(b);
-    if (b->ndt) ndt_batch_set_live(*b->ndt, n_sources, n_targets);
     b->has_src = b->has_tgt = b->aligned = false;
   });
 }

@@ -117,6 +117,7 @@ struct Tuning {
                               //                         and the next k_gicp_correspond reads those bits instead of the points (gicp.hip); 0 = the margin check of round 3
   float mask_slack = 2.f;     // MI355_MASK_SLACK        that budget: this many times what the trials of the previous iteration moved the pose by
   int corr_stats = 0;         // MI355_CORR_STATS        1 = count what the correspondence tiles scan, print after every align
+  int ndt_waves = 32768;      // MI355_NDT_WAVES         waves of k_ndt_derivatives over a batch (each pair gets its share, >= 16, at most one point per lane)
   int knn_stats = 0;          // MI355_KNN_STATS         1 = after every covariance launch, synchronise and print to stderr how many
                               //                         points the tile kernel handed over to k_knn_hard (tuning aid, host side only)
 };
@@ -127,7 +128,7 @@ const Tuning& tuning();
 // (mi355_batch_set_timing).  The durations are read after the streams have been synchronised (mi355_batch_kernel_times).
 enum KernelFamily : int {
   KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_CORRESPOND_TILE, KF_LINEARIZE, KF_STEP,
-  KF_FITNESS, KF_SOR, KF_COUNT
+  KF_FITNESS, KF_SOR, KF_NDT_TARGET, KF_NDT_SORT, KF_NDT_LEAVES, KF_NDT_DERIV, KF_NDT_ADVANCE, KF_COUNT
 };
 extern const char* const kKernelFamilyName[KF_COUNT];
 struct KernelTimers {

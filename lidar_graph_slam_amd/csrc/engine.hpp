@@ -221,28 +221,31 @@ void gicp_bfgs_align(hipStream_t s, BfgsScratch& sc, const CloudSet& src, const 
                      const float* guess16, mi355_result* out);
 
 // ---- ndt.hip -------------------------------------------------------------------------------------------------
-struct NdtTarget;
-struct NdtState;
-NdtTarget* ndt_target_create();
-void ndt_target_destroy(NdtTarget*);
-void ndt_build_target(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_pts, size_t n, const mi355_ndt_params& p);
-void ndt_align(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_src, size_t n, const mi355_ndt_params& p, const float* guess16,
-               mi355_result* out);
-void ndt_derivatives(hipStream_t s, Workspace& ws, NdtTarget& t, const float4* d_src, size_t n, const mi355_ndt_params& p, const double* p6,
+// U targets' voxel Gaussians (N1) in compact arrays; a registration object's target is a set of one.
+struct NdtTargets;
+NdtTargets* ndt_targets_create();
+void ndt_targets_destroy(NdtTargets*);
+bool ndt_targets_have_fp64_leaves(const NdtTargets& t);
+// cloud u = d_pts[u * pitch ... + count[u]) in any point order; counts on the device, h_bound[u] >= count[u] known to the host (it
+// sizes the allocations: nothing is read back, nothing synchronises).  ws: reserved for (U, cap), cap >= every count.
+// keep_fp64_leaves: for computeHessian (legacy_mt_skip = 0) and the parity read-back (ndt_cells).
+void ndt_build_targets(hipStream_t s, Workspace& ws, NdtTargets& t, const float4* d_pts, size_t pitch, const int* d_counts, const int* h_bound, int U,
+                       size_t cap, const mi355_ndt_params& p, bool keep_fp64_leaves);
+size_t ndt_num_cells(hipStream_t s, NdtTargets& t, int u);  // synchronises (reads the grid geometry back once per build)
+void ndt_cells(hipStream_t s, NdtTargets& t, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3);
+// The Newton / More-Thuente state of P pairs, resident in HBM and advanced on the device (graph_based_slam.cpp:101-119 lets the
+// loop-closure back end register its candidates with NDT_OMP; a registration object is a solver of one pair).
+struct NdtSolver;
+NdtSolver* ndt_solver_create();
+void ndt_solver_destroy(NdtSolver*);
+// src: [P][src_pitch] points (any order), counts on the device, none above max_count.  Blocks until every pair is done.
+void ndt_solve(hipStream_t s, NdtTargets& t, NdtSolver& sv, int P, const float4* d_src, size_t src_pitch, const int* d_src_counts, int max_count,
+               const int* tgt_of_src_host, const float* guesses_host, const mi355_ndt_params& p);
+// out[i].n_inliers = the evaluations (passes over the source) pair i asked for
+void ndt_solver_results(NdtSolver& sv, mi355_result* out, float* T16_all);
+int ndt_solver_rounds(const NdtSolver& sv);
+// parity probe: computeDerivatives of one source against target 0 at the pose p6
+void ndt_derivatives(hipStream_t s, NdtTargets& t, NdtSolver& sv, const float4* d_src, size_t n, const mi355_ndt_params& p, const double* p6,
                      double* score, double* grad6, double* hess36, bool hessian_fp64);
-size_t ndt_num_cells(NdtTarget& t);
-void ndt_cells(hipStream_t s, NdtTarget& t, int64_t* leaf_idx, int* leaf_n, double* mean3, double* cov9, double* icov9, int* min_b3, int* div_b3);
-// P pairs against U targets with the More-Thuente state of every pair resident in HBM (graph_based_slam.cpp:101-119 lets the
-// loop-closure back end register its candidates with NDT_OMP)
-struct NdtBatch;
-NdtBatch* ndt_batch_create(int P, int U);
-void ndt_batch_destroy(NdtBatch*);
-void ndt_batch_set_live(NdtBatch& b, int P_live, int U_live);  // register the first P_live pairs against the first U_live targets only
-void ndt_batch_set_target(hipStream_t s, Workspace& ws, NdtBatch& b, int u, const float4* d_pts, size_t n, const mi355_ndt_params& p);
-void ndt_batch_align(hipStream_t s, NdtBatch& b, const float4* d_src, size_t src_cap, const int* h_counts, const int* tgt_of_src_host,
-                     const float* guesses_host, const mi355_ndt_params& p);
-void ndt_batch_results(NdtBatch& b, mi355_result* out, float* T16_all);
-size_t ndt_batch_num_cells(NdtBatch& b, int u);
-int ndt_batch_rounds(const NdtBatch& b);
 
 }  // namespace mi355

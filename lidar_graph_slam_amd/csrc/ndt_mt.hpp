@@ -2,11 +2,10 @@
 // iteration, computeStepLengthMT (More & Thuente 1994 as PCL / ndt_omp restate it) and the convergence test, written ONCE
 // as a resumable state machine over ~1.5 KB of per-pair state.  Every step that needs the point cloud — computeDerivatives
 // (fp32, with or without the Hessian) or computeHessian (fp64) — is a REQUEST the executor answers with the 28 reduced sums;
-// ndt_advance() consumes them and runs on to the next request.  Two executors share it:
-//   * ndt_align       (one pair):  the host advances the state, one kernel launch + 224-byte read-back per request;
-//   * ndt_batch_align (P pairs):   k_ndt_batch_advance advances every pair's state on the device, nothing is read back
-//                                  between requests (the host only polls the number of unfinished pairs every few rounds).
-// Everything is MI_HD, so both compile from the same text.
+// ndt_advance() consumes them and runs on to the next request.
+// ndt_solve (ndt.hip) runs it for P pairs at once — a registration object is P = 1 —: k_ndt_advance advances every pair's state on
+// the device, nothing is read back between requests (the host only polls the number of unfinished pairs every few rounds).
+// Everything is MI_HD: tests/host_math_harness.cpp compiles the same text on the CPU.
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -167,6 +166,83 @@ MI_HD double ndt_trial_value(double a_l, double f_l, double g_l, double a_u, dou
   return ndt_cubic_min(a_u, f_u, g_u, a_t, f_t, g_t);
 }
 
+// delta_p = JacobiSVD(H).solve(-g) (N2).  For a symmetric H the SVD solve is the eigen-decomposition solve, i.e. H^-1 rhs unless H is
+// rank-deficient to working precision (singular values below 6 eps sigma_max are dropped).  NDT Hessians are indefinite away from the
+// optimum, so the shortcut is Gaussian elimination with partial pivoting (registers, ~1 k instructions; every index a compile-time
+// constant, the run-time pivot row applied as "for every candidate row: if (piv == c) swap"): when its pivots span less than 1e9
+// and the residual confirms the solution, no singular value is anywhere near the SVD's truncation threshold and both give H^-1 rhs
+// to ~cond * eps.  Everything else — rank-deficient, empty, NaN — takes the cyclic Jacobi, whose ~10^5 dependent fp64 instructions
+// on ONE lane set the duration of k_ndt_advance in round 5's first measurement (7.7 of the 42 ms of a 1 024-pair step).
+MI_HD bool lu6_solve(const double* A_in, const double* rhs, double* x, double& piv_min, double& piv_max) {
+  constexpr int N = 6;
+  double A[N * N], b[N];
+#pragma unroll
+  for (int i = 0; i < N * N; i++) A[i] = A_in[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) b[i] = rhs[i];
+  piv_min = 1.7976931348623157e308;
+  piv_max = 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    int piv = k;
+    double best = fabs(A[k * N + k]);
+#pragma unroll
+    for (int i = k + 1; i < N; i++)
+      if (fabs(A[i * N + k]) > best) { best = fabs(A[i * N + k]); piv = i; }
+#pragma unroll
+    for (int c = k + 1; c < N; c++) {
+      if (piv == c) {
+#pragma unroll
+        for (int j = 0; j < N; j++) { const double t = A[k * N + j]; A[k * N + j] = A[c * N + j]; A[c * N + j] = t; }
+        { const double t = b[k]; b[k] = b[c]; b[c] = t; }
+      }
+    }
+    piv_min = fmin(piv_min, best);
+    piv_max = fmax(piv_max, best);
+    if (!(best > 0.0)) ok = false;  // (also NaN)
+    if (ok) {
+      const double inv = 1.0 / A[k * N + k];
+#pragma unroll
+      for (int i = k + 1; i < N; i++) {
+        const double f = A[i * N + k] * inv;
+#pragma unroll
+        for (int j = k + 1; j < N; j++) A[i * N + j] -= f * A[k * N + j];
+        b[i] -= f * b[k];
+      }
+    }
+  }
+  if (!ok) return false;
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    double s = b[i];
+#pragma unroll
+    for (int j = i + 1; j < N; j++) s -= A[i * N + j] * x[j];
+    x[i] = s / A[i * N + i];
+  }
+  return true;
+}
+
+MI_HD void ndt_newton_solve(const double* H, const double* rhs, double* x) {
+  double lo, hi;
+  if (lu6_solve(H, rhs, x, lo, hi) && lo > 1.0e-9 * hi) {
+    // residual check: ||H x - rhs||_inf <= 1e-9 (||H||_inf ||x||_inf + ||rhs||_inf)
+    double rmax = 0, hmax = 0, xmax = 0, bmax = 0;
+    bool finite = true;
+    for (int i = 0; i < 6; i++) {
+      double r = -rhs[i], hr = 0;
+      for (int j = 0; j < 6; j++) { r += H[6 * i + j] * x[j]; hr += fabs(H[6 * i + j]); }
+      rmax = fmax(rmax, fabs(r));
+      hmax = fmax(hmax, hr);
+      xmax = fmax(xmax, fabs(x[i]));
+      bmax = fmax(bmax, fabs(rhs[i]));
+      finite = finite && (x[i] == x[i]);
+    }
+    if (finite && xmax < 1.0e300 && rmax <= 1.0e-9 * (hmax * xmax + bmax)) return;
+  }
+  svd6_solve_sym(H, rhs, x);
+}
+
 constexpr double kNdtMu = 1.e-4, kNdtNu = 0.9;
 constexpr int kNdtMaxStepIterations = 10;
 
@@ -248,7 +324,7 @@ MI_HD void ndt_advance(NdtPairState& st, const double* sums, const NdtConsts& c)
     if (go == NEWTON) {
       double ng[6], delta_p[6];
       for (int k = 0; k < 6; k++) ng[k] = -st.grad[k];
-      svd6_solve_sym(st.hess, ng, delta_p);
+      ndt_newton_solve(st.hess, ng, delta_p);
       double nrm = 0;
       for (int k = 0; k < 6; k++) nrm += delta_p[k] * delta_p[k];
       nrm = sqrt(nrm);

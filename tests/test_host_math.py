@@ -60,6 +60,40 @@ def test_ldlt6_and_svd6(hm):
     np.testing.assert_allclose(x, np.linalg.solve(S, b), rtol=1e-8)
 
 
+def test_ndt_newton_solve_is_the_svd_solve(hm):
+    """ndt_mt.hpp ndt_newton_solve: the pivoted-elimination shortcut (well-conditioned Hessians, definite or not) and the Jacobi
+    fallback both give JacobiSVD(H).solve(rhs) — the rank-truncating solve for a singular H included."""
+    rng = np.random.default_rng(11)
+    x, y = np.empty(6), np.empty(6)
+    for sign in (1.0, -1.0):
+        for _ in range(20):
+            A = rng.normal(size=(6, 6))
+            H = np.ascontiguousarray(sign * (A @ A.T + 0.1 * np.eye(6)) * rng.uniform(1e-2, 1e4))
+            b = rng.normal(size=6)
+            hm.hm_ndt_newton(_p(H), _p(b), _p(x))
+            hm.hm_svd6(_p(H), _p(b), _p(y))
+            np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12 * np.abs(y).max())
+            np.testing.assert_allclose(x, np.linalg.solve(H, b), rtol=1e-8)
+    for _ in range(20):  # indefinite (NDT Hessians are, away from the optimum)
+        S = rng.normal(size=(6, 6))
+        S = np.ascontiguousarray(S + S.T)
+        b = rng.normal(size=6)
+        hm.hm_ndt_newton(_p(S), _p(b), _p(x))
+        hm.hm_svd6(_p(S), _p(b), _p(y))
+        np.testing.assert_allclose(x, y, rtol=1e-8, atol=1e-11 * np.abs(y).max())
+    # near-singular and singular Hessians take the Jacobi path: the same numbers as svd6_solve_sym, bit for bit
+    Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+    R5 = np.ascontiguousarray(Q @ np.diag([3.0, 2.0, 1.0, 0.5, 0.1, 0.0]) @ Q.T)
+    R5 = np.ascontiguousarray(0.5 * (R5 + R5.T))
+    ill = np.ascontiguousarray(Q @ np.diag([1.0, 1.0, 1.0, 1.0, 1.0, 1e-12]) @ Q.T)
+    ill = np.ascontiguousarray(0.5 * (ill + ill.T))
+    for H in (R5, ill, np.zeros((6, 6))):
+        b = rng.normal(size=6)
+        hm.hm_ndt_newton(_p(H), _p(b), _p(x))
+        hm.hm_svd6(_p(H), _p(b), _p(y))
+        np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("method,name", [(0, "NONE"), (1, "MIN_EIG"), (2, "NORMALIZED_MIN_EIG"), (3, "PLANE"), (4, "FROBENIUS")])
 def test_regularisation_vs_numpy(hm, method, name):
     rng = np.random.default_rng(2)
