@@ -245,8 +245,8 @@ def main():
         "pose_error_vs_truth": {"median_m": round(float(np.median(errs[:, 0])), 4), "p95_m": round(float(np.percentile(errs[:, 0], 95)), 4),
                                 "within_0.3m": float(ok_truth.mean())},
         "gpu_vs_oracle": oracle,
-        "roofline": {"bound": "hbm", "kernel": by[0]["kernel"], "achieved": by[0]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": by[0]["frac_of_hbm_peak"],
+        "roofline": {"bound": "hbm", "kernel": by[0]["kernel"], "achieved": by[0].get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": by[0].get("frac_of_hbm_peak"),
                      "end_to_end_frac": round(total_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "by_kernel": by, "seconds_ray_casting_on_host": round(t_cast, 1),
     }
