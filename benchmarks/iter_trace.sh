@@ -7,7 +7,7 @@ import csv, glob
 f=sorted(glob.glob('/tmp/itr/*/*_kernel_trace.csv'))[-1]
 rows=[r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-for pat in ('k_gicp_correspond<','k_gicp_correspond_tile','k_gicp_linearize','k_gicp_step'):
+for pat in ('k_gicp_correspond<','k_gicp_correspond_tile','k_gicp_linearize','k_gicp_research','k_gicp_step'):
     d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in rows if pat in r['Kernel_Name']]
     print(pat, len(d), 'last 20-22 launches (us):', ' '.join(f'{x:.0f}' for x in d[-22:]))
 PY

@@ -417,10 +417,10 @@ class BatchRegistration:
 
     def kernel_times(self):
         """{kernel family: (total ms, launches)} since the last call; synchronises the batch."""
-        buf = (L.KernelTime * 16)()
+        buf = (L.KernelTime * 32)()
         n = C.c_int(0)
-        self.ctx.check(self.ctx._lib.mi355_batch_kernel_times(self.handle, buf, 16, C.byref(n)))
-        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(min(n.value, 16))}
+        self.ctx.check(self.ctx._lib.mi355_batch_kernel_times(self.handle, buf, 32, C.byref(n)))
+        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(min(n.value, 32))}
 
     def close(self):
         if getattr(self, "handle", None):
