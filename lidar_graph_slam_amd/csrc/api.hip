@@ -13,7 +13,7 @@ thread_local KernelTimers* g_timers = nullptr;
 thread_local int g_family_override = -1;
 const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
                                                  "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
-                                                 "k_gicp_research", "k_gicp_step", "k_fitness",
+                                                 "k_gicp_step", "k_fitness",
                                                  "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)",
                                                  "ndt_target_prep(k_ndt_bounds,keys,heads,scan,size,clear)", "ndt_target_sort(k_sort_tile,k_sort_merge)", "k_ndt_leaves(k_ndt_leaf_sums,k_ndt_leaf_finalize)", "k_ndt_derivatives", "k_ndt_advance"};
 const Tuning& tuning() {
@@ -27,10 +27,9 @@ const Tuning& tuning() {
     geti("MI355_HASH_SLOTS", v.hash_slots_per_cell);
     geti("MI355_CORR_BLOCKS", v.corr_blocks);
     geti("MI355_CORR_STATS", v.corr_stats);
-    geti("MI355_CORR_FOLD", v.corr_fold);
-    geti("MI355_SETTLE_MAX", v.settle_max);
-    getf("MI355_SETTLE_STEP", v.settle_step);
+    geti("MI355_CORR_MASK", v.corr_mask);
     geti("MI355_CORR_GROUPS", v.corr_groups);
+    getf("MI355_MASK_SLACK", v.mask_slack);
     getf("MI355_CORR_R1", v.corr_r1);
     getf("MI355_MARGIN_STEP", v.margin_step);
     geti("MI355_BLOCKS_LIN", v.blocks_lin);

@@ -113,10 +113,9 @@ struct Tuning {
   float corr_r1 = 0.5f;       // MI355_CORR_R1           first-round radius of a correspondence tile (m)
   int corr_groups = 1;        // MI355_CORR_GROUPS       0 = per-lane correspondence search also for batches of < 8 pairs (no lane groups)
   float margin_step = 0.03f;  // MI355_MARGIN_STEP       a pair tracks search margins once its last accepted step moved it by less than this (m at a 50 m lever arm)
-  int corr_fold = 1;          // MI355_CORR_FOLD         1 = the linearize pass checks the search margins of SETTLED pairs itself and searches the few points
-                              //                         that left theirs (k_gicp_correspond skips those pairs); 0 = every pair through k_gicp_correspond
-  float settle_step = 0.002f; // MI355_SETTLE_STEP       a margin-tracking pair settles once its accepted step is below this (m at a 50 m lever arm) ...
-  int settle_max = 512;       // MI355_SETTLE_MAX        ... and at most this many of its points were searched again in the iteration
+  int corr_mask = 1;          // MI355_CORR_MASK         1 = the linearize pass marks the points whose search margin survives the step budgeted for the iteration
+                              //                         and the next k_gicp_correspond reads those bits instead of the points (gicp.hip); 0 = the margin check of round 3
+  float mask_slack = 2.f;     // MI355_MASK_SLACK        that budget: this many times what the trials of the previous iteration moved the pose by
   int corr_stats = 0;         // MI355_CORR_STATS        1 = count what the correspondence tiles scan, print after every align
   int ndt_waves = 32768;      // MI355_NDT_WAVES         waves of k_ndt_derivatives over a batch (each pair gets its share, >= 16, at most one point per lane)
   int knn_stats = 0;          // MI355_KNN_STATS         1 = after every covariance launch, synchronise and print to stderr how many
@@ -128,7 +127,7 @@ const Tuning& tuning();
 // HIP events recorded on the LAUNCHING stream around the launches of a family, only while a batch has timing enabled
 // (mi355_batch_set_timing).  The durations are read after the streams have been synchronised (mi355_batch_kernel_times).
 enum KernelFamily : int {
-  KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_CORRESPOND_TILE, KF_LINEARIZE, KF_RESEARCH, KF_STEP,
+  KF_KNN_COV_TILE = 0, KF_KNN_HARD, KF_VOXEL_CENTROIDS, KF_SORT, KF_HASH_BUILD, KF_CORRESPOND, KF_CORRESPOND_TILE, KF_LINEARIZE, KF_STEP,
   KF_FITNESS, KF_SOR, KF_NDT_TARGET, KF_NDT_SORT, KF_NDT_LEAVES, KF_NDT_DERIV, KF_NDT_ADVANCE, KF_COUNT
 };
 extern const char* const kKernelFamilyName[KF_COUNT];

@@ -147,8 +147,9 @@ struct GicpBatch {
   DevBuf<int> corr;          // [S*cap] target (sorted) index per sorted source point
   DevBuf<Cov6> mahal;        // [cap] Mahalanobis matrices of pair 0's last linearisation: written for the parity probes only (gicp_linearize_once)
   DevBuf<float4> qsearch;    // [S*cap] query position of the last full NN search + how far it may move (w)
-  DevBuf<int> again_list, again_cnt;  // settled pairs: the points that left their search margins, listed per wave of k_gicp_linearize (gicp.hip)
-  DevBuf<double> partials;   // [S][blocks + 1][kPartStride = 96]: normal equations + trial-cost model (gicp.hip)
+  DevBuf<unsigned long long> safe_mask;  // [S][cap / 64] bit i of a pair: point i provably keeps its correspondence under EVERY trial pose of the
+                                         // current LM iteration (written by the cost pass, read by the next k_gicp_correspond: gicp.hip)
+  DevBuf<double> partials;   // [S][blocks][kPartStride = 96]: normal equations + trial-cost model (gicp.hip)
   DevBuf<GicpPairState> state;
   static constexpr int kPolls = 2;  // "any pair still active?" polls in flight (gicp_poll_active / gicp_poll_query)
   DevBuf<int> n_active;

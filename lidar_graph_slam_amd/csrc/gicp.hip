@@ -28,10 +28,9 @@ struct GicpPairState {
   int iter, trial, active, converged, n_inliers, lm_failed, status;
   double last_step;  // size of the last accepted update (metres at 50 m lever arm): picks the search mode of the next iteration
   int first_conv;    // iterations run when is_converged first held (-1: never) - what fast_gicp runs without force_iterations
-  int settled;       // the pair's steps have become small: k_gicp_linearize checks the search margins of its points itself (and searches
-                     // the few that have left theirs before it adds them up), k_gicp_correspond leaves the pair alone (k_gicp_step decides)
-  int viol;          // points of this pair that were searched again in the current iteration (atomicAdd by the searching blocks of
-                     // k_gicp_correspond / k_gicp_linearize; read and cleared by k_gicp_step)
+  int mask_valid;    // the "safe" bits of this pair (GicpBatch::safe_mask) hold for the pose the next k_gicp_correspond will see
+  float slack_rot, slack_trans;  // the budget of the current iteration: its search-margin bits hold while no trial pose moves a point at distance r
+                                 // from the origin by more than slack_rot * r + slack_trans (k_gicp_step sets and checks it; < 0: none yet)
 };
 
 // One Levenberg-Marquardt trial step.  step_lm's trial sequence is fully determined by (H, b, lambda): trial t uses
@@ -79,15 +78,6 @@ constexpr int kModelRows = 9, kModelCols = 10, kNModel = kModelRows * kModelCols
 constexpr int kFeatStride = 9;  // LDS row stride of a point's 8 factors (doubles; odd: the lanes of a wave write whole rows)
 constexpr int kGicpBlock = 256;
 constexpr int kMaxTrials = 16;  // lm_max_iterations is capped here (fast_gicp default 10)
-constexpr int kLinWaves = kGicpBlock / kWave;
-constexpr int kLinFeat = 2 * kWave * kFeatStride;
-// Entries a wave of k_gicp_linearize can list: the points it sees (its share of the block's tiles).
-__host__ __device__ inline int lin_list_pitch(size_t cap, int G, int ppt) {
-  const int tile = kGicpBlock * ppt;
-  const int tiles = (int)((cap + (size_t)G * tile - 1) / ((size_t)G * tile));
-  return tiles * kWave * ppt;
-}
-
 
 void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_geometry) {
   const Tuning& tn = tuning();
@@ -126,12 +116,8 @@ void gicp_alloc(GicpBatch& gb, int S_own, size_t cap, int compute_units, int S_g
   gb.tgt_of_src.ensure(S);
   gb.corr.ensure((size_t)S * cap);
   gb.qsearch.ensure((size_t)S * cap);
-  gb.partials.ensure((size_t)S * (std::max(G, gb.blocks_lin) + 1) * kPartStride);
-  if (tn.corr_fold && Sg >= 8) {  // the lists of k_gicp_linearize's waves (gicp_fold)
-    const int lp = tn.lin_ppt == 1 ? 1 : (tn.lin_ppt == 2 ? 2 : 4);
-    gb.again_list.ensure((size_t)S * gb.blocks_lin * kLinWaves * lin_list_pitch(cap, gb.blocks_lin, lp));
-    gb.again_cnt.ensure((size_t)S * gb.blocks_lin * kLinWaves);
-  }
+  gb.safe_mask.ensure((size_t)S * (size_t)div_up((long)cap, 64));
+  gb.partials.ensure((size_t)S * std::max(G, gb.blocks_lin) * kPartStride);
   gb.state.ensure(S);
   gb.n_active.ensure(GicpBatch::kPolls);
   gb.h_active.ensure(GicpBatch::kPolls);
@@ -192,8 +178,8 @@ __global__ void k_gicp_init(GicpPairState* st, const float* __restrict__ guesses
   if (scount && (scount[p] < k_min || tcount[tgt_of_src[p]] < k_min)) { s.active = 0; s.status = MI355_PAIR_TOO_FEW_POINTS; }
   s.last_step = 1.0e9;
   s.first_conv = -1;
-  s.settled = 0;
-  s.viol = 0;
+  s.mask_valid = 0;
+  s.slack_rot = s.slack_trans = -1.f;
   st[p] = s;
 }
 
@@ -777,23 +763,22 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
                                                                 const int* __restrict__ torig,
                                                                 const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                                size_t tslots, const int* __restrict__ tgt_of_src,
-                                                               GicpPairState* __restrict__ state, int* __restrict__ corr,
+                                                               const GicpPairState* __restrict__ state, int* __restrict__ corr,
                                                                 float4* __restrict__ qsearch, float max_corr_d2, int G, int S,
                                                                 int tiles_took_the_moving_pairs, double margin_step,
                                                                 unsigned long long* __restrict__ stats = nullptr, int iteration = 0,
-                                                                int all_pairs = 0) {
+                                                                const unsigned long long* __restrict__ safe_mask = nullptr, size_t mask_words = 0) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
+  constexpr int kMaskTiles = 64;  // tiles of a block whose "safe" words are fetched in one go
   __shared__ int queue[kLinTile + kGicpBlock];  // what is left of the earlier tiles (< one block's worth) + this tile's
   __shared__ int qcount;
+  constexpr int kUnsafeCap = 2048;  // points of a block that are not marked safe: listed when they are at most this many
+  __shared__ int ulist[kUnsafeCap];
+  __shared__ int ucount;
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
-  GicpPairState* st = state + pair;
+  const GicpPairState* st = state + pair;
   if (!st->active) return;
-  // A SETTLED pair (k_gicp_step: it tracks margins, its last step was a millimetre or less and few of its points left their margins)
-  // is not looked at here at all: k_gicp_linearize, which reads every point anyway, checks the margins and searches the odd point
-  // that has left its own.  (Round 4 made this launch cheap for such pairs - "margin-safe" bits written by the linearize pass - but a
-  // launch whose 8 k blocks each wait out a chain of dependent loads to find nothing still took 0.27 ms, 30 times per step.)
-  if (st->settled && !all_pairs) return;
   // margins only pay once the updates are small enough to stay inside them (cm); before that every point is searched again:
   // k_gicp_correspond_tile does that for whole tiles at once (the first iterations), this kernel with the plain 1-NN search
   // A pair k_gicp_correspond_tile has just been through: only what it left behind (NaN margin: ties between its keys, boxes it
@@ -812,13 +797,49 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     Tf[4 * r + 3] = (float)x0.t[r];
   }
   const size_t so = (size_t)pair * scap;
-  if (threadIdx.x == 0) qcount = 0;
+  // The cost pass of the previous iteration has marked the points whose margin survives every trial pose it evaluated (safe_mask): a
+  // pair that tracks margins looks at the OTHER points only - a few per cent of them once the pose has settled (the margins of a
+  // voxelised cloud are spread over centimetres; the poses of the last iterations move by fractions of a millimetre).  The words of
+  // all this block's tiles come in with one load per thread, their zero bits become a list in LDS, and the margin check runs over
+  // that list: a block is then three memory latencies - words, listed points, the odd search - where the tile loop below is a chain
+  // of dependent loads and three barriers per 256 points (0.5 ms per iteration at 2 048 pairs, whatever the bytes).
+  constexpr int kWordsPerTile = kLinTile / kWave;
+  const bool masked = safe_mask != nullptr && st->mask_valid && (st->last_step < margin_step) && (n <= kMaskTiles * G * kLinTile);
+  bool use_list = false;
+  int n_list = 0;
+  if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
   __syncthreads();
-  int searched = 0;  // (thread 0: points this block searched)
+  if (masked) {
+    const unsigned long long* mw = safe_mask + (size_t)pair * mask_words;
+    for (int w = threadIdx.x; w < kMaskTiles * kWordsPerTile; w += kGicpBlock) {
+      const int tile_no = w / kWordsPerTile;  // this block's tile_no-th tile: points (bx + tile_no G) kLinTile ..., and the word of them this thread reads
+      const long first = (long)(bx + (long)tile_no * G) * kLinTile + (long)(w % kWordsPerTile) * kWave;
+      if (first >= n) continue;
+      unsigned long long bits = ~mw[first / kWave];  // (the cost pass sets the bits past the end of the cloud)
+      if (!bits) continue;
+      int pos = atomicAdd(&ucount, __popcll(bits));
+      while (bits) {
+        const int bit = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (pos < kUnsafeCap) ulist[pos] = (int)first + bit;
+        pos++;
+      }
+    }
+    __syncthreads();
+    n_list = ucount;
+    use_list = n_list <= kUnsafeCap;  // (more than that - a pair that has just started to track margins: the tile loop)
+  }
   for (int step = 0;; step++) {
-    const int base = (bx + step * G) * kLinTile;
-    if (base >= n) break;
-    const bool last_tile = base + G * kLinTile >= n;
+    int base = 0;
+    bool last_tile;
+    if (use_list) {
+      if (step * kLinTile >= n_list) break;
+      last_tile = (step + 1) * kLinTile >= n_list;
+    } else {
+      base = (bx + step * G) * kLinTile;
+      if (base >= n) break;
+      last_tile = base + G * kLinTile >= n;
+    }
     // ---- phase 1: which points of this tile need a new nearest-neighbour search?  
     // The last full search of a point left, at query position qs.xyz, a margin qs.w: while the query has moved less
     // than that, its nearest neighbour provably cannot change (triangle inequality on the nearest / runner-up
@@ -828,8 +849,15 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     // margins - the first iterations of margin tracking - a tile alone fills one or two of the block's four waves, partly).
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
-      const int i = base + u * kGicpBlock + threadIdx.x;
-      if (i >= n) continue;
+      int i;
+      if (use_list) {
+        const int at = step * kLinTile + u * kGicpBlock + (int)threadIdx.x;
+        if (at >= n_list) continue;
+        i = ulist[at];
+      } else {
+        i = base + u * kGicpBlock + threadIdx.x;
+        if (i >= n) continue;
+      }
       const float4 p = spts[so + i];
       const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
       const float4 qs = qsearch[so + i];
@@ -852,7 +880,6 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     while (nq >= kGicpBlock || (last_tile && nq > 0)) {  // whole waves go round together: the cooperative part needs all 64 lanes
       const int take = min(nq, kGicpBlock);
       if (stats && threadIdx.x == 0) atomicAdd(&stats[8 + 4 * min(iteration, 63)], (unsigned long long)take);
-      searched += take;
       nq -= take;
       const int tq = nq + threadIdx.x;
       const bool valid = (int)threadIdx.x < take;
@@ -886,7 +913,6 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
     if (threadIdx.x == 0) qcount = nq;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && searched > 0) atomicAdd(&st->viol, searched);
 }
 
 // ---- the same for a pair whose pose still moves by more than any margin absorbs: every point is searched, by TILES -------
@@ -1193,114 +1219,26 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
 // would halve the kernel's occupancy, so most of them are an outer product per point on the matrix cores: the lanes of a wave leave the
 // 8 + 8 factors of their points in LDS, and 8 v_mfma_f64_16x16x4_f64 (8 points each: A = factors of the Mahalanobis side, B = of the
 // transformed point) add the 8 x 8 products of all 64 points to an accumulator tile of 4 doubles per lane; 12 sums stay in registers.
-//
-// F3 INSIDE F4 (round 5) — upstream, update_correspondences IS the head of linearize.  For a SETTLED pair (GicpPairState::settled)
-// this pass also is the margin check of the incremental correspondence search: it has the point in registers, so "has the query moved
-// out of the margin its last search left?" costs the stored query (16 B per point) and five instructions.  The few points that have
-// are kept out of the sums and listed (every wave appends to a list of its own, in (tile, lane) order); k_gicp_research, one block
-// per pair right behind this kernel, searches them again, stores the new correspondences and margins and adds the points to one more
-// row of the pair's partial sums.  (The search inlined HERE — a wave flushing its list before the block reduces — was built first:
-// 248 VGPRs instead of 150, two blocks per CU instead of three, and this kernel, which is bound by bytes, went from 11.3 to 19.4 ms
-// per step.)  Order of the fp64 additions: fixed by the data alone — bitwise reproducible, whatever the number of parts.
+// `safe_mask` (LM, pairs that track search margins): the pass marks the points whose margin survives a move of the pose by the slack
+// k_gicp_step has budgeted for this iteration's trials (slack_rot / slack_trans of the pair's state; k_gicp_step validates the
+// budget against the trials it then makes) - the next k_gicp_correspond reads those bits instead of the points.
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 #ifndef LIN_OCC
 #define LIN_OCC 2  // resident blocks per CU (= waves per SIMD) the register allocation aims at
 #endif
-
-// One point's share of the sums (has: it has a correspondent) and the wave's eight matrix-core steps over its 64 points.
-// acc / macc: this lane's accumulators; featw: the wave's factor rows in LDS (kLinFeat doubles).
-__device__ __forceinline__ void lin_contribute(bool has, const Pose& x0, const float* Rf, const float4& p, const Cov6& c, const float4& tq,
-                                               const Cov6& tcv, Cov6* mahal_out, double* acc, mfma_acc_t& macc, double* featw) {
-  const int lane = lane_id();
-  double* featA = featw + lane * kFeatStride;
-  double* featB = featw + kWave * kFeatStride + lane * kFeatStride;
-  if (has) {
-    const Sym3<float> CA = cov6_unpack(c);
-    const Sym3<float> CB = cov6_unpack(tcv);
-    Sym3<float> RCR = sym3_rotate(Rf, CA);
-    RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
-    const Sym3<float> M = sym3_inverse(RCR);
-    if (mahal_out) *mahal_out = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);  // (the parity probe's pass over the points reads them; the optimisation does not)
-    float ax, ay, az, ex, ey, ez;
-    double dax, day, daz, dex, dey, dez;
-    residual64(x0, p, tq, dax, day, daz, ax, ay, az, ex, ey, ez, dex, dey, dez);
-    {
-#pragma clang fp contract(fast)
-      const double mxx = (double)M.xx, mxy = (double)M.xy, mxz = (double)M.xz, myy = (double)M.yy, myz = (double)M.yz, mzz = (double)M.zz;
-      const double md0x = mxx * dex + mxy * dey + mxz * dez;  // M d0
-      const double md0y = mxy * dex + myy * dey + myz * dez;
-      const double md0z = mxz * dex + myz * dey + mzz * dez;
-      acc[0] += mxx; acc[1] += mxy; acc[2] += mxz; acc[3] += myy; acc[4] += myz; acc[5] += mzz;
-      acc[kSumCost] += dex * md0x + dey * md0y + dez * md0z;  // d0^T M d0 (cost64's operations)
-      acc[kSumCount] += 1.0;
-      // (straight to LDS: the factors kept in registers until the whole wave is here cost the kernel a wave per SIMD)
-      featA[0] = mxx; featA[1] = mxy; featA[2] = mxz; featA[3] = myy; featA[4] = myz; featA[5] = mzz; featA[6] = md0x; featA[7] = md0y;
-      featB[0] = dax * dax; featB[1] = dax * day; featB[2] = dax * daz; featB[3] = day * day; featB[4] = day * daz;
-      featB[5] = dax; featB[6] = day; featB[7] = daz;
-      const double azaz = daz * daz;
-      acc[kNLin + 0] += mxx * azaz; acc[kNLin + 1] += mxy * azaz; acc[kNLin + 2] += mxz * azaz;
-      acc[kNLin + 3] += myy * azaz; acc[kNLin + 4] += myz * azaz; acc[kNLin + 5] += mzz * azaz;
-      acc[kNLin + 6] += md0x; acc[kNLin + 7] += md0y; acc[kNLin + 8] += md0z;
-      acc[kNLin + 9] += md0z * dax; acc[kNLin + 10] += md0z * day; acc[kNLin + 11] += md0z * daz;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < kMfmaDim; k++) { featA[k] = 0.0; featB[k] = 0.0; }
-  }
-  if (__ballot(has)) {  // (wave-uniform)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rows are read by other lanes
-    // product step s takes points 8 s .. 8 s + 7: lane (r = lane & 15, k = lane >> 4) holds factor r & 7 of point 8 s + k (r < 8:
-    // rows / columns 0-7 of the tile) or of point 8 s + 4 + k (rows / columns 8-15)
-    const int r = lane & 15, kq = lane >> 4;
-    const double* rowA = featw + (kq + 4 * (r >> 3)) * kFeatStride + (r & 7);
-    const double* rowB = rowA + kWave * kFeatStride;
-#pragma unroll 4
-    for (int step = 0; step < kWave / 8; step++) {
-      const double a = rowA[step * 8 * kFeatStride], b = rowB[step * 8 * kFeatStride];
-      macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile overwrites the rows
-  }
-}
-
-// The block's sums -> one row of the pair's partials (W waves; feat: [W][kLinFeat], smem: W * kNAcc doubles).
-template <int W>
-__device__ __forceinline__ void lin_reduce_store(const double* acc, const mfma_acc_t& macc, double (*feat)[kLinFeat], double* smem, double* __restrict__ row) {
-  static_assert(kLinFeat >= kWave * kBlockSumRow, "the wave's factor rows double as the transpose buffer of the block sum");
-  const int lane = lane_id(), wv = wave_id();
-  {
-    const double total = block_sum_columns<kNAcc, W>(acc, feat[wv], smem);
-    if (threadIdx.x < kNAcc) row[threadIdx.x] = total;
-  }
-  {
-    // the four waves' accumulator tiles -> one 8 x 8: element v of lane l is row (l >> 4) + 4 v, column l & 15 (the f64 MFMA's own map);
-    // the two diagonal blocks hold the two halves of the points
-#pragma unroll
-    for (int v = 0; v < 4; v++) feat[wv][((lane >> 4) + 4 * v) * 16 + (lane & 15)] = macc[v];
-    __syncthreads();
-    if (threadIdx.x < kNMfma) {
-      const int i = threadIdx.x / kMfmaDim, j = threadIdx.x % kMfmaDim;
-      double sum = 0.0;
-#pragma unroll
-      for (int w = 0; w < W; w++) sum += feat[w][i * 16 + j] + feat[w][(i + 8) * 16 + j + 8];
-      row[kModelSlot + threadIdx.x] = sum;
-    }
-  }
-}
-
-// rows: rows of partial sums per pair (G, + 1 for k_gicp_research's when fold).  again_list / again_cnt: [S][G kLinWaves][pitch] /
-// [S][G kLinWaves] the points of settled pairs that have left their search margins, per wave (fold only).
 template <int kLinPointsPerThread>
 __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const float4* __restrict__ spts, const Cov6* __restrict__ scov,
                                                                const int* __restrict__ scount, size_t scap, const float4* __restrict__ tpts,
                                                                const Cov6* __restrict__ tcov, size_t tcap, const int* __restrict__ tgt_of_src,
-                                                               const GicpPairState* __restrict__ state, int* __restrict__ corr,
-                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S, int rows,
-                                                               const float4* __restrict__ qsearch, int* __restrict__ again_list,
-                                                               int* __restrict__ again_cnt, int fold) {
+                                                               const GicpPairState* __restrict__ state, const int* __restrict__ corr,
+                                                               Cov6* __restrict__ mahal, double* __restrict__ partials, int G, int S,
+                                                               const float4* __restrict__ qsearch, unsigned long long* __restrict__ safe_mask,
+                                                               size_t mask_words, double margin_step) {
   constexpr int kLinTile = kGicpBlock * kLinPointsPerThread;
-  __shared__ double smem[kLinWaves * kNAcc];
-  __shared__ double feat[kLinWaves][kLinFeat];  // per wave: the factors of its 64 points; at the end: its accumulator tile
+  constexpr int kWaves = kGicpBlock / kWave;
+  constexpr int kFeat = 2 * kWave * kFeatStride;
+  __shared__ double smem[kWaves * kNAcc];
+  __shared__ double feat[kWaves][kFeat];  // per wave: the factors of its 64 points; at the end: its accumulator tile
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const GicpPairState* st = state + pair;
@@ -1314,7 +1252,8 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
 #pragma unroll
   for (int k = 0; k < 9; k++) Rf[k] = (float)x0.R[k];
   const size_t so = (size_t)pair * scap;
-  const bool check = fold != 0 && st->settled != 0;  // (pair-uniform)
+  const float slack_rot = st->slack_rot, slack_trans = st->slack_trans;
+  const bool mark = safe_mask != nullptr && st->last_step < margin_step && slack_rot >= 0.f;
   float Tf0[12];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -1327,10 +1266,8 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
   for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
   mfma_acc_t macc = {0.0, 0.0, 0.0, 0.0};
   const int lane = lane_id(), wv = wave_id();
-  const unsigned long long below = (1ull << lane) - 1ull;
-  const int pitch = lin_list_pitch(scap, G, kLinPointsPerThread);
-  int* mylist = again_list + ((size_t)pair * G * kLinWaves + (size_t)bx * kLinWaves + wv) * pitch;
-  int nq = 0;  // entries of this wave's list (wave-uniform)
+  double* featA = feat[wv] + lane * kFeatStride;
+  double* featB = feat[wv] + kWave * kFeatStride + lane * kFeatStride;
   // Software pipeline over the block's tiles: the correspondence index, the source point and its covariance of the NEXT
   // tile are loaded while the current tile is computed, so the dependent gathers (target point / covariance at corr[i])
   // of a tile are issued as soon as its loop iteration starts — one exposed memory latency per tile instead of two.
@@ -1349,7 +1286,7 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
       r.j = corr[so + i];
       r.p = spts[so + i];
       r.c = scov[so + i];
-      if (check) r.qs = qsearch[so + i];
+      if (mark) r.qs = qsearch[so + i];
     }
     return r;
   };
@@ -1372,133 +1309,97 @@ __global__ __launch_bounds__(kGicpBlock, LIN_OCC) void k_gicp_linearize(const fl
 #pragma unroll
     for (int u = 0; u < kLinPointsPerThread; u++) {
       const int i = base + u * kGicpBlock + threadIdx.x;
-      int j = cur[u].j;
+      const int j = cur[u].j;
       const float4 p = cur[u].p;
-      if (check) {
-        // k_gicp_correspond's phase 1: the last search of this point left, at query position qs.xyz, a margin qs.w — while the query has
-        // moved less than that its nearest neighbour provably cannot change (and stays inside max_corr if it was)
-        bool again = false;
+      if (mark) {
+        // Which points keep their correspondence wherever this iteration's step ends?  The last search of a point left a margin
+        // (k_gicp_correspond); a point at x0 p moves by at most slack_rot |x0 p| + slack_trans under any pose within the budget, so
+        // "moved so far + that < margin" settles it for the pose the next iteration linearises at - one bit per point, and the next
+        // k_gicp_correspond reads the bits (1/128 of the bytes of its margin check) instead of the points and their stored queries.
+        bool safe = i >= n;  // (past the end: nothing to look at)
         if (i < n) {
           const float4 qs = cur[u].qs;
           const float qx = transform_row(Tf0, p.x, p.y, p.z), qy = transform_row(Tf0 + 4, p.x, p.y, p.z), qz = transform_row(Tf0 + 8, p.x, p.y, p.z);
-          if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) {
-            if (j >= 0) corr[so + i] = -1;
-            j = -1;
-          } else {
-            again = !(sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z)) < qs.w);
-          }
+          // (no square roots: |x0 p| <= its 1-norm, and "moved < budget" is compared squared)
+          const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
+          const float budget = qs.w - ((slack_rot * reach + slack_trans) * (1.f + 1e-5f) + 2.0e-5f);
+          safe = isfinite(reach) && budget > 0.f && dist2f(qx, qy, qz, qs.x, qs.y, qs.z) < budget * budget * (1.f - 1e-6f);
         }
-        const unsigned long long am = __ballot(again);
-        if (am) {
-          if (again) {
-            mylist[nq + __popcll(am & below)] = i;
-            j = -1;  // (not in this block's sums: k_gicp_research adds it with its new correspondent)
-          }
-          nq += __popcll(am);
+        const unsigned long long bits = __ballot(safe);
+        // (the last tile of a pair may reach past the pair's row of words when the capacity is not a multiple of the tile: those words
+        // would be the next pair's first ones, marked "safe" behind its back)
+        const size_t word = (size_t)((base + u * kGicpBlock) / kWave + wv);
+        if (lane == 0 && word < mask_words) safe_mask[(size_t)pair * mask_words + word] = bits;
+      }
+      const bool has = j >= 0;  // (not past the end, and a correspondence)
+      if (has) {
+        const Sym3<float> CA = cov6_unpack(cur[u].c);
+        const Sym3<float> CB = cov6_unpack(tcv[u]);
+        Sym3<float> RCR = sym3_rotate(Rf, CA);
+        RCR.xx += CB.xx; RCR.xy += CB.xy; RCR.xz += CB.xz; RCR.yy += CB.yy; RCR.yz += CB.yz; RCR.zz += CB.zz;
+        const Sym3<float> M = sym3_inverse(RCR);
+        if (mahal) mahal[so + i] = cov6_pack(M.xx, M.xy, M.xz, M.yy, M.yz, M.zz);  // (the parity probe's pass over the points reads them; the optimisation does not)
+        float ax, ay, az, ex, ey, ez;
+        double dax, day, daz, dex, dey, dez;
+        residual64(x0, p, tq[u], dax, day, daz, ax, ay, az, ex, ey, ez, dex, dey, dez);
+        {
+#pragma clang fp contract(fast)
+          const double mxx = (double)M.xx, mxy = (double)M.xy, mxz = (double)M.xz, myy = (double)M.yy, myz = (double)M.yz, mzz = (double)M.zz;
+          const double md0x = mxx * dex + mxy * dey + mxz * dez;  // M d0
+          const double md0y = mxy * dex + myy * dey + myz * dez;
+          const double md0z = mxz * dex + myz * dey + mzz * dez;
+          acc[0] += mxx; acc[1] += mxy; acc[2] += mxz; acc[3] += myy; acc[4] += myz; acc[5] += mzz;
+          acc[kSumCost] += dex * md0x + dey * md0y + dez * md0z;  // d0^T M d0 (cost64's operations)
+          acc[kSumCount] += 1.0;
+          // (straight to LDS: the factors kept in registers until the whole wave is here cost the kernel a wave per SIMD)
+          featA[0] = mxx; featA[1] = mxy; featA[2] = mxz; featA[3] = myy; featA[4] = myz; featA[5] = mzz; featA[6] = md0x; featA[7] = md0y;
+          featB[0] = dax * dax; featB[1] = dax * day; featB[2] = dax * daz; featB[3] = day * day; featB[4] = day * daz;
+          featB[5] = dax; featB[6] = day; featB[7] = daz;
+          const double azaz = daz * daz;
+          acc[kNLin + 0] += mxx * azaz; acc[kNLin + 1] += mxy * azaz; acc[kNLin + 2] += mxz * azaz;
+          acc[kNLin + 3] += myy * azaz; acc[kNLin + 4] += myz * azaz; acc[kNLin + 5] += mzz * azaz;
+          acc[kNLin + 6] += md0x; acc[kNLin + 7] += md0y; acc[kNLin + 8] += md0z;
+          acc[kNLin + 9] += md0z * dax; acc[kNLin + 10] += md0z * day; acc[kNLin + 11] += md0z * daz;
         }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kMfmaDim; k++) { featA[k] = 0.0; featB[k] = 0.0; }
       }
-      lin_contribute(j >= 0, x0, Rf, p, cur[u].c, tq[u], tcv[u], (mahal && j >= 0) ? mahal + so + i : nullptr, acc, macc, feat[wv]);
-    }
-  }
-  if (fold && lane == 0) again_cnt[(size_t)pair * G * kLinWaves + (size_t)bx * kLinWaves + wv] = nq;
-  lin_reduce_store<kLinWaves>(acc, macc, feat, smem, partials + ((size_t)pair * rows + bx) * kPartStride);
-}
-
-// The points k_gicp_linearize has listed (settled pairs: they left their search margins), ONE WAVE per pair (a pair lists tens of points
-// per iteration; as a 256-thread block - 190 VGPRs, two per CU - a 2 048-pair launch was four rounds of one search latency each:
-// 0.22 ms): searched again - the
-// per-lane walk of the target's voxel hash seeded with the old correspondent, the stragglers by the whole wave, as k_gicp_correspond's
-// phase 2 -, stored with their new margins, and added up into row G of the pair's partial sums (zeros when nothing was listed).
-// The lists are walked wave by wave, entry by entry: the order of the additions is fixed by the data.
-constexpr int kResearchBlock = kWave;
-__global__ __launch_bounds__(kResearchBlock, 3) void k_gicp_research(const float4* __restrict__ spts, const Cov6* __restrict__ scov, size_t scap,
-                                                             const float4* __restrict__ tpts, const Cov6* __restrict__ tcov, const int* __restrict__ torig,
-                                                             const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
-                                                             size_t tslots, const int* __restrict__ tgt_of_src, GicpPairState* __restrict__ state,
-                                                             int* __restrict__ corr, float4* __restrict__ qsearch, double* __restrict__ partials, int G,
-                                                             int rows, int pitch, const int* __restrict__ again_list, const int* __restrict__ again_cnt,
-                                                             float max_corr_d2) {
-  constexpr int kMaxLists = 64 * kLinWaves;  // blocks_lin <= 64
-  __shared__ double smem[kNAcc];
-  __shared__ double feat[1][kLinFeat];
-  __shared__ int first[kMaxLists + 1];  // first[r]: entries of the lists before list r
-  const int pair = blockIdx.x;
-  GicpPairState* st = state + pair;
-  if (!st->active) return;
-  double* row = partials + ((size_t)pair * rows + G) * kPartStride;
-  const int nl = G * kLinWaves;
-  const int* cnt = again_cnt + (size_t)pair * nl;
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int r = 0; r < nl; r++) { first[r] = run; run += st->settled ? cnt[r] : 0; }
-    first[nl] = run;
-  }
-  __syncthreads();
-  const int total = first[nl];
-  if (total == 0) {
-    for (int k = threadIdx.x; k < kPartStride; k += kResearchBlock) row[k] = 0.0;
-    return;
-  }
-  const int t = tgt_of_src[pair];
-  const float4* tp = tpts + (size_t)t * tcap;
-  const Cov6* tc = tcov + (size_t)t * tcap;
-  const GridView g = grid_view(tpts, torig, ttable, tmeta, t, tcap, tslots);
-  const float reach_coop2 = search_reach2(g, max_corr_d2, true);
-  const Pose x0 = st->x0;
-  float Rf[9], Tf0[12];
-#pragma unroll
-  for (int k = 0; k < 9; k++) Rf[k] = (float)x0.R[k];
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) Tf0[4 * r + c] = Rf[3 * r + c];
-    Tf0[4 * r + 3] = (float)x0.t[r];
-  }
-  const size_t so = (size_t)pair * scap;
-  double acc[kNAcc];
-#pragma unroll
-  for (int k = 0; k < kNAcc; k++) acc[k] = 0.0;
-  mfma_acc_t macc = {0.0, 0.0, 0.0, 0.0};
-  const int lane = lane_id(), wv = wave_id();
-  for (int e0 = 0; e0 < total; e0 += kResearchBlock) {
-    const int e = e0 + (int)threadIdx.x;
-    const bool valid = e < total;
-    int i = 0;
-    if (valid) {  // the list that holds entry e: the last one that starts at or before it
-      int lo = 0, hi = nl;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (first[mid] <= e) lo = mid; else hi = mid;
+      if (__ballot(has)) {  // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rows are read by other lanes
+        // product step s takes points 8 s .. 8 s + 7: lane (r = lane & 15, k = lane >> 4) holds factor r & 7 of point 8 s + k (r < 8:
+        // rows / columns 0-7 of the tile) or of point 8 s + 4 + k (rows / columns 8-15)
+        const int r = lane & 15, kq = lane >> 4;
+        const double* rowA = feat[wv] + (kq + 4 * (r >> 3)) * kFeatStride + (r & 7);
+        const double* rowB = rowA + kWave * kFeatStride;
+#pragma unroll 4
+        for (int step = 0; step < kWave / 8; step++) {
+          const double a = rowA[step * 8 * kFeatStride], b = rowB[step * 8 * kFeatStride];
+          macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile overwrites the rows
       }
-      i = again_list[((size_t)pair * nl + lo) * pitch + (e - first[lo])];
     }
-    const float4 p = spts[so + i];
-    const float qx = transform_row(Tf0, p.x, p.y, p.z), qy = transform_row(Tf0 + 4, p.x, p.y, p.z), qz = transform_row(Tf0 + 8, p.x, p.y, p.z);
-    NnState ns{INFINITY, -1, INFINITY, 0.f, true};
-    if (valid) ns = lane_search(g, qx, qy, qz, corr[so + i], max_corr_d2, true);
-    unsigned long long hard = __ballot(valid && !ns.complete);  // the queries the fine levels could not finish, one at a time, by the whole wave
-    while (hard) {
-      const int hl = __builtin_ctzll(hard);
-      hard &= hard - 1;
-      const float hx = lane_f(qx, hl), hy = lane_f(qy, hl), hz = lane_f(qz, hl);
-      const NnState cs = coop_search(g, hx, hy, hz, reach_coop2);
-      if (lane == hl) ns = cs;
-    }
-    int j = -1;
-    if (valid) {
-      float margin;
-      finish_search(ns, max_corr_d2, true, j, margin);
-      corr[so + i] = j;
-      qsearch[so + i] = make_float4(qx, qy, qz, margin);
-    }
-    const bool has = valid && j >= 0;
-    Cov6 c = {}, tcv = {};
-    float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has) { c = scov[so + i]; tq = tp[j]; tcv = tc[j]; }
-    lin_contribute(has, x0, Rf, p, c, tq, tcv, nullptr, acc, macc, feat[0]);
   }
-  if (threadIdx.x == 0) atomicAdd(&st->viol, total);
-  lin_reduce_store<1>(acc, macc, feat, smem, row);
+  static_assert(kFeat >= kWave * kBlockSumRow, "the wave's factor rows double as the transpose buffer of the block sum");
+  {
+    const double total = block_sum_columns<kNAcc, kWaves>(acc, feat[wv], smem);
+    if (threadIdx.x < kNAcc) partials[((size_t)pair * G + bx) * kPartStride + threadIdx.x] = total;
+  }
+  {
+    // the four waves' accumulator tiles -> one 8 x 8: element v of lane l is row (l >> 4) + 4 v, column l & 15 (the f64 MFMA's own map);
+    // the two diagonal blocks hold the two halves of the points
+#pragma unroll
+    for (int v = 0; v < 4; v++) feat[wv][((lane >> 4) + 4 * v) * 16 + (lane & 15)] = macc[v];
+    __syncthreads();
+    if (threadIdx.x < kNMfma) {
+      const int i = threadIdx.x / kMfmaDim, j = threadIdx.x % kMfmaDim;
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) sum += feat[w][i * 16 + j] + feat[w][(i + 8) * 16 + j + 8];
+      partials[((size_t)pair * G + bx) * kPartStride + kModelSlot + threadIdx.x] = sum;
+    }
+  }
 }
 
 __device__ __forceinline__ void lm_make_trial(const double* H, const double* b, const Pose& x0, double lambda, LmTrial& tr) {
@@ -1656,11 +1557,10 @@ MI_HD double model_decrease(const Pose& delta, const double* m) {
 // (lane t: LDL^T solve, se3_exp, trial pose, its cost through the model), then lane 0 walks the trials as step_lm does - accept /
 // reject by rho, lambda update, convergence test, iteration bookkeeping - no host round trip and no pass over the points.
 // sums_only: the normal equations and y0 go to the state and nothing else happens (gicp_linearize_once).
-// settle_step >= 0: a pair that tracked search margins in this iteration (last_step < margin_step), whose accepted step is below
-// settle_step and of whose points at most settle_max were searched again becomes SETTLED - the next k_gicp_linearize checks its margins
-// itself and k_gicp_correspond skips it - until an iteration says otherwise.
+// margin_step >= 0: the search-margin bits k_gicp_linearize wrote for this pair hold if the trials stayed inside the slack it had
+// budgeted; the budget of the next iteration is slack_factor x what these trials took.
 __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ state, const double* __restrict__ partials, int G, GicpDevParams P,
-                                                  int sums_only, double margin_step, double settle_step, int settle_max) {
+                                                  int sums_only, double margin_step, float slack_factor) {
   __shared__ double sums[kPartStride], mdl[kNModel];
   __shared__ double sH[36], sb[6], slambda;
   __shared__ Pose sx0;
@@ -1674,7 +1574,7 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
   // one dependent load at a time)
   const int ld_active = st->active, ld_iter = st->iter, ld_converged = st->converged, ld_first_conv = st->first_conv, ld_lm_failed = st->lm_failed;
   const double ld_lambda = st->lambda, ld_last_step = st->last_step;
-  const int ld_viol = st->viol;
+  const float ld_slack_rot = st->slack_rot, ld_slack_trans = st->slack_trans;
   const double ld_x0 = (l < 9) ? st->x0.R[l] : st->x0.t[min(l, 11) - 9];
   if (!ld_active) return;
   const double* mine = partials + (size_t)pair * G * kPartStride;
@@ -1690,8 +1590,7 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
   __syncthreads();
   if (P.optimizer == MI355_OPT_GN) {
     if (l == 0) {
-      st->settled = 0;
-      st->viol = 0;
+      st->mask_valid = 0;
       GicpPairState s = *st;
       for (int i = 0; i < 36; i++) s.H[i] = sH[i];
       for (int i = 0; i < 6; i++) s.b[i] = sb[i];
@@ -1730,6 +1629,7 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
   if (l < 36) st->H[l] = sH[l];
   if (l < 6) st->b[l] = sb[l];
   if (sums_only) return;
+  float slack_r = 0.f, slack_t = 0.f;
   if (l < P.lm_max_iterations) {
     // lambda of trial l: step_lm multiplies by nu = 2, 4, 8, ... after each rejection
     double lam = slambda, nu = 2.0;
@@ -1738,10 +1638,24 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
     lm_make_trial(sH, sb, sx0, lam, tr);
     s_tr[l] = tr;
     dec[l] = model_decrease(tr.delta, mdl);
+    // how far a point can move between x0 and this trial pose: x_t p - x0 p = (dR - I)(x0 p) + dt, so at most
+    // ||dR - I||_F |x0 p| + |dt|
+    double fr = 0, ft = 0;
+    for (int k = 0; k < 9; k++) { const double v = tr.delta.R[k] - ((k % 4 == 0) ? 1.0 : 0.0); fr += v * v; }
+    for (int k = 0; k < 3; k++) ft += tr.delta.t[k] * tr.delta.t[k];
+    slack_r = (float)(sqrt(fr) * (1.0 + 1e-6)) + 1e-12f;
+    slack_t = (float)(sqrt(ft) * (1.0 + 1e-6)) + 1e-12f;
   }
+  slack_r = wave_reduce64(slack_r, [](float a, float b) { return fmaxf(a, b); });
+  slack_t = wave_reduce64(slack_t, [](float a, float b) { return fmaxf(a, b); });
   __syncthreads();
   if (l == 0) {
     GicpPairState& s = *st;
+    // the bits of this iteration's linearize pass (written only for a pair that tracked margins, under the budget in the state)
+    const bool marked = margin_step >= 0.0 && ld_last_step < margin_step && ld_slack_rot >= 0.f;
+    s.mask_valid = (marked && slack_r <= ld_slack_rot && slack_t <= ld_slack_trans) ? 1 : 0;
+    s.slack_rot = slack_factor * slack_r + 1e-9f;
+    s.slack_trans = slack_factor * slack_t + 1e-7f;
     StepFields f;
     f.iter = ld_iter; f.active = 1; f.converged = ld_converged; f.first_conv = ld_first_conv; f.lm_failed = ld_lm_failed; f.last_step = ld_last_step;
     bool finished = false, moved = false;
@@ -1792,9 +1706,6 @@ __global__ __launch_bounds__(64) void k_gicp_step(GicpPairState* __restrict__ st
     s.first_conv = f.first_conv;
     s.lm_failed = f.lm_failed;
     s.last_step = f.last_step;
-    // every point of a pair that tracked margins in this iteration holds a valid margin; small steps leave almost all of them valid
-    s.settled = (settle_step >= 0.0 && f.active && ld_last_step < margin_step && f.last_step < settle_step && ld_viol <= settle_max) ? 1 : 0;
-    s.viol = 0;
   }
   __syncthreads();
   if (s_accepted && l < 36) st->final_H[l] = sH[l];
@@ -1850,10 +1761,6 @@ static GicpDevParams dev_params(const mi355_gicp_params& p) {
   return P;
 }
 
-// F3 inside F4 (k_gicp_linearize / k_gicp_research): where k_gicp_correspond, which honours GicpPairState::settled, is the per-lane search
-// kernel - batches of >= 8 pairs
-static bool gicp_fold(const GicpBatch& gb) { return tuning().corr_fold != 0 && gb.S_geometry >= 8 && gb.again_list.p != nullptr; }
-
 // search: -1 = by iteration and batch size; gicp_linearize_once forces 0 = per-lane walks only, 1 = tiles (+ per-lane leftovers),
 // 2 = lane groups
 static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const GicpDevParams& P, int iteration,
@@ -1889,23 +1796,17 @@ static void launch_linearize(hipStream_t s, GicpBatch& gb, const CloudSet& src, 
     } else {
       hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
                          tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2,
-                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step, gb.corr_stats.p, iteration, 0);
+                         gb.blocks_per_pair, gb.S, tiles ? 1 : 0, (double)tn.margin_step, gb.corr_stats.p, iteration,
+                         (tn.corr_mask && search < 0) ? (const unsigned long long*)gb.safe_mask.p : (const unsigned long long*)nullptr,
+                         (size_t)div_up((long)gb.cap, 64));
     }
   }
-  const int fold = gicp_fold(gb) && search < 0 ? 1 : 0;
-  const int pitch = lin_list_pitch(gb.cap, gb.blocks_lin, lin_ppt == 1 ? 1 : (lin_ppt == 2 ? 2 : 4));
-  {
-    TimedLaunch tl(KF_LINEARIZE, s);
-    hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
-                       tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, search >= 0 ? gb.mahal.p : (Cov6*)nullptr, gb.partials.p, gb.blocks_lin, gb.S,
-                       gb.blocks_lin + fold, (const float4*)gb.qsearch.p, gb.again_list.p, gb.again_cnt.p, fold);
-  }
-  if (fold) {
-    TimedLaunch tl(KF_RESEARCH, s);
-    hipLaunchKernelGGL(k_gicp_research, dim3(gb.S), dim3(kResearchBlock), 0, s, src.pts.p, src.cov.p, src.cap, tgt.pts.p, tgt.cov.p, tgt.orig.p, tgt.table.p,
-                       tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, gb.partials.p, gb.blocks_lin,
-                       gb.blocks_lin + 1, pitch, (const int*)gb.again_list.p, (const int*)gb.again_cnt.p, P.max_corr_d2);
-  }
+  TimedLaunch tl(KF_LINEARIZE, s);
+  const bool mask = tuning().corr_mask && search < 0;
+  hipLaunchKernelGGL(kl, dim3(xcd_grid(gb.blocks_lin, gb.S)), dim3(kGicpBlock), 0, s, src.pts.p, src.cov.p, src.count.p, src.cap,
+                     tgt.pts.p, tgt.cov.p, tgt.cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, search >= 0 ? gb.mahal.p : (Cov6*)nullptr, gb.partials.p, gb.blocks_lin, gb.S,
+                     (const float4*)gb.qsearch.p, mask ? gb.safe_mask.p : (unsigned long long*)nullptr,
+                     (size_t)div_up((long)gb.cap, 64), (double)tuning().margin_step);
 }
 
 // ---- the LM optimisation of every pair of a batch, in three pieces a caller can interleave with those of other batches --------
@@ -1948,9 +1849,8 @@ void gicp_align_iterate(hipStream_t s, GicpBatch& gb, const CloudSet& src, const
   for (int it = it0; it < it1; it++) {
     launch_linearize(s, gb, src, tgt, P, it);
     TimedLaunch tl(KF_STEP, s);
-    const bool fold = gicp_fold(gb);
-    hipLaunchKernelGGL(k_gicp_step, dim3(S), dim3(64), 0, s, gb.state.p, (const double*)gb.partials.p, gb.blocks_lin + (fold ? 1 : 0), P, 0,
-                       (double)tn.margin_step, fold ? (double)tn.settle_step : -1.0, tn.settle_max);
+    hipLaunchKernelGGL(k_gicp_step, dim3(S), dim3(64), 0, s, gb.state.p, (const double*)gb.partials.p, gb.blocks_lin, P, 0,
+                       tn.corr_mask ? (double)tn.margin_step : -1.0, tn.mask_slack);
   }
   MI_LAUNCH_CHECK();
 }
@@ -2043,17 +1943,19 @@ void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& s
   out.ensure(2);
   MI_HIP(hipMemsetAsync(out.p, 0, 2 * sizeof(unsigned long long), s));
   auto kc = gb.ppt == 1 ? k_gicp_correspond<1> : k_gicp_correspond<4>;
-  auto correspond = [&]() {  // every pair, settled or not
+  auto correspond = [&](bool with_mask) {
     hipLaunchKernelGGL(kc, dim3(xcd_grid(gb.blocks_per_pair, S)), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p, tgt.table.p,
                        tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, gb.corr.p, gb.qsearch.p, P.max_corr_d2, gb.blocks_per_pair, S, 0,
-                       (double)tuning().margin_step, (unsigned long long*)nullptr, 0, 1);
+                       (double)tuning().margin_step, (unsigned long long*)nullptr, 0,
+                       (with_mask && tuning().corr_mask) ? (const unsigned long long*)gb.safe_mask.p : (const unsigned long long*)nullptr,
+                       (size_t)div_up((long)gb.cap, 64));
   };
   hipLaunchKernelGGL(k_gicp_set_active, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, S, 1, saved.p);
-  correspond();  // incremental: correspondences and margins as the last iteration left them, checked at the final pose
+  correspond(true);  // incremental: margins - and the "safe" bits - as the last iteration left them, at the final pose
   MI_HIP(hipMemcpyAsync(inc.p, gb.corr.p, (size_t)S * src.cap * sizeof(int), hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_gicp_reset_search, dim3(std::max(1, std::min(64, div_up((long)src.cap, 1024))), S), dim3(256), 0, s, (const int*)src.count.p, gb.corr.p,
                      gb.qsearch.p, src.cap);
-  correspond();  // from scratch: NaN margins, every point searched
+  correspond(false);  // from scratch: NaN margins, every point searched
   hipLaunchKernelGGL(k_gicp_compare_corr, dim3(16, S), dim3(256), 0, s, (const int*)src.count.p, gb.state.p, (const int*)inc.p, (const int*)gb.corr.p, src.cap, out.p);
   hipLaunchKernelGGL(k_gicp_set_active, dim3(div_up(S, 64)), dim3(64), 0, s, gb.state.p, S, 0, saved.p);
   unsigned long long h[2];
@@ -2227,7 +2129,7 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
       if (got[(size_t)i] != first[(size_t)i])
         throw ArgError(MI355_ESTATE, search == 1 ? "tile and per-lane correspondence searches disagree" : "group and per-lane correspondence searches disagree");
   }
-  hipLaunchKernelGGL(k_gicp_step, dim3(1), dim3(64), 0, s, gb.state.p, (const double*)gb.partials.p, gb.blocks_lin, P, 1, -1.0, -1.0, 0);
+  hipLaunchKernelGGL(k_gicp_step, dim3(1), dim3(64), 0, s, gb.state.p, (const double*)gb.partials.p, gb.blocks_lin, P, 1, -1.0, 0.f);
   MI_LAUNCH_CHECK();
   GicpPairState st;
   MI_HIP(hipMemcpyAsync(&st, gb.state.p, sizeof(st), hipMemcpyDeviceToHost, s));
