@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--n-azimuth", type=int, default=1024, help="1024 = 65 536 rays per scan")
     ap.add_argument("--capacity", type=int, default=65536)
     ap.add_argument("--max-iterations", type=int, default=64)
-    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "NDT_OMP"], help="registration engine of the batch (graph_based_slam.cpp:80-119)")
+    ap.add_argument("--method", default="FAST_GICP", choices=["FAST_GICP", "NDT_OMP", "ICP"], help="registration engine of the batch (graph_based_slam.cpp:80-152; ICP is that node's yaml default)")
     ap.add_argument("--min-good", type=float, default=0.9, help="fail unless this fraction of the pairs lands within 5 cm / 5 mrad of the truth")
     ap.add_argument("--multi-lanes", type=int, default=0, help="ONE process, this many lanes on device 0 through mi355_multi_batch_register (host views in, "
                     "results out: uploads included in the rate) instead of one rank per GPU")
@@ -179,12 +179,13 @@ def main():
             parts.append(place(c, P))
         return np.concatenate(parts, axis=0)
 
-    cap = max(args.capacity, 5 * 20000 if args.n_azimuth >= 1024 else 0)
+    cap = max(args.capacity, 5 * 22000 if args.n_azimuth >= 1024 else 0)
     t0 = time.perf_counter()
     out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, cap, rank=rank, world=world, ctx=ctx,
                                       target_prefilter=loop_batch.voxel_prefilter(0.5), method=args.method,
                                       **(dict(max_iterations=args.max_iterations) if args.method == "FAST_GICP"
-                                         else dict(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01)))
+                                         else dict(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01) if args.method == "NDT_OMP"
+                                         else dict(max_iterations=100, max_correspondence_distance=30.0, transformation_epsilon=1e-8, euclidean_fitness_epsilon=1e-6)))
     t_total = time.perf_counter() - t0
     if rank == 0:
         from lidar_graph_slam_amd import synth as S_

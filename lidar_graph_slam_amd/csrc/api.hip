@@ -154,6 +154,9 @@ struct mi355_batch {
   int method = MI355_METHOD_FAST_GICP;
   mi355_gicp_params gp;
   mi355_ndt_params np;       // method == MI355_METHOD_NDT_OMP
+  mi355_icp_params ip;       // method == MI355_METHOD_ICP
+  IcpBatch* icp = nullptr;
+  int icp_max_src = 0;       // no source holds more points than this (the counts before the prefilter)
   NdtTargets* ndt = nullptr;  // every target's voxel Gaussians, built by one launch sequence per mi355_batch_set_targets*
   NdtSolver* ndt_solver = nullptr;
   int ndt_max_src = 0;        // no source holds more points than this (the counts before the prefilter: nothing is read back)
@@ -228,6 +231,7 @@ struct mi355_batch {
   ~mi355_batch() {
     if (ndt) ndt_targets_destroy(ndt);
     if (ndt_solver) ndt_solver_destroy(ndt_solver);
+    if (icp) icp_batch_destroy(icp);
     parts.clear();
     for (auto& e : pin_free)
       if (e) (void)hipEventDestroy(e);
@@ -763,7 +767,7 @@ extern "C" int mi355_reg_align(mi355_reg* reg, const float guess16[16], mi355_re
     } else if (reg->method == MI355_METHOD_ICP) {
       float I[16];
       for (int i = 0; i < 16; i++) I[i] = (i % 5 == 0) ? 1.f : 0.f;
-      icp_align(ctx->stream, reg->icp, reg->tgt, reg->stage_src.p, reg->n_src, reg->ip, guess16 ? guess16 : I, result);
+      icp_align(ctx->stream, reg->icp, reg->tgt, reg->stage_src.p, reg->cnt_src.p, reg->n_src, reg->ip, guess16 ? guess16 : I, result);
       result->n_source = (int)reg->n_src;
       result->n_target = (int)reg->n_tgt;
     } else {
@@ -1224,8 +1228,9 @@ static int target_part_of(const mi355_batch* b, int t) {
 }
 
 extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity) {
-  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP) || n_sources <= 0 || n_targets <= 0 || capacity == 0) {
-    if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP or NDT_OMP)";
+  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP) || n_sources <= 0 || n_targets <= 0 ||
+      capacity == 0) {
+    if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP, NDT_OMP or ICP)";
     return nullptr;
   }
   auto* b = new mi355_batch();
@@ -1233,8 +1238,15 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
   b->method = method;
   mi355_gicp_default_params(&b->gp);
   mi355_ndt_default_params(&b->np);
+  mi355_icp_default_params(&b->ip);
   if (params && method == MI355_METHOD_FAST_GICP) b->gp = *(const mi355_gicp_params*)params;
   if (params && method == MI355_METHOD_NDT_OMP) b->np = *(const mi355_ndt_params*)params;
+  if (params && method == MI355_METHOD_ICP) b->ip = *(const mi355_icp_params*)params;
+  if (method == MI355_METHOD_ICP && b->ip.ransac_iterations != 0) {
+    ctx->err = "ICP: only setRANSACIterations(0) (graph_based_slam.cpp:150) is built";
+    delete b;
+    return nullptr;
+  }
   b->n_sources = b->alloc_sources = n_sources;
   b->n_targets = b->alloc_targets = n_targets;
   b->cap = capacity;
@@ -1252,7 +1264,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
       pt.cap_s = div_up(n_sources, N);
       pt.cap_t = div_up(n_targets, N);
       pt.src.alloc(pt.cap_s, capacity);
-      if (method == MI355_METHOD_NDT_OMP) gicp_alloc_fitness_only(pt.gb, n_sources, capacity);  // getFitnessScore is the point-to-point one for every method
+      if (method != MI355_METHOD_FAST_GICP) gicp_alloc_fitness_only(pt.gb, n_sources, capacity);  // getFitnessScore is the point-to-point one for every method
       else gicp_alloc(pt.gb, pt.cap_s, capacity, ctx->compute_units, n_sources);
       for (int k = 0; k < 2; k++) {
         const int nb = k == 0 ? pt.cap_t : pt.cap_s;
@@ -1269,6 +1281,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
       b->ndt = ndt_targets_create();
       b->ndt_solver = ndt_solver_create();
     }
+    if (method == MI355_METHOD_ICP) b->icp = icp_batch_create();
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
       create_stream(&sd.stream, prio_lo, N > 1 ? tuning().prep_cus : 1.f, false, ctx->compute_units);
@@ -1339,6 +1352,14 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
         b->ndt_max_src = 0;
         for (int i = 0; i < n; i++) b->ndt_max_src = std::max(b->ndt_max_src, pt.h_counts[k][(size_t)i]);
       }
+    } else if (b->method == MI355_METHOD_ICP) {
+      // point-to-point ICP: the targets' NN voxel hash is all it needs; the sources are points in that hash's Morton order
+      // (neighbouring lanes of k_icp_step walk the same cells of the target)
+      build_grid(s, ws, pts, cnt, set, ctx->grid_cell, false);
+      if (!targets) {
+        b->icp_max_src = 0;
+        for (int i = 0; i < n; i++) b->icp_max_src = std::max(b->icp_max_src, pt.h_counts[k][(size_t)i]);
+      }
     } else {
       build_grid(s, ws, pts, cnt, set, ctx->grid_cell, true);
       // (batches only: for ONE cloud - a registration object, the scan matcher's sub-map - the sort costs more than the search gains:
@@ -1361,7 +1382,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
   }
   if (side_streams) sd.pending = true;
   if (targets) {
-    b->tgt.built = b->method == MI355_METHOD_FAST_GICP;
+    b->tgt.built = b->method != MI355_METHOD_NDT_OMP;  // (NDT: the targets' point hash is built when a fitness is asked for)
     b->tgt.has_cov = b->method == MI355_METHOD_FAST_GICP;
   }
 }
@@ -1555,6 +1576,18 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
         ndt_solver_results(*b->ndt_solver, nullptr, T.data());
         gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
       }
+    } else if (b->method == MI355_METHOD_ICP) {
+      Part& pt = *b->parts[0];
+      batch_wait_side(b, main, 0);
+      batch_wait_side(b, main, 1);
+      // blocks until every pair is done (the fits and PCL's convergence criteria run on the device; the host polls a counter)
+      gicp_set_map(main, pt.gb, tgt_of_src, b->n_targets);
+      icp_batch_align(main, *b->icp, b->n_sources, pt.src.pts.p, b->cap, pt.src.count.p, (size_t)b->icp_max_src, b->tgt, tgt_of_src, guesses16, b->ip);
+      if (b->with_fitness) {
+        std::vector<float> T((size_t)b->n_sources * 16);
+        icp_batch_results(*b->icp, nullptr, T.data());
+        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
+      }
     } else {
       // every part's LM loop on its stream, behind the chains it needs: its own sources' and those of the targets its pairs name
       const bool forked = b->lm_stream(0) != main;
@@ -1640,9 +1673,10 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     if (!b->aligned) throw ArgError(MI355_ESTATE, "mi355_batch_align has not been called");
     if (fitness && !b->with_fitness) throw ArgError(MI355_ESTATE, "fitness was not requested in mi355_batch_align");
     MI_HIP(hipSetDevice(b->ctx->device));
-    if (b->method == MI355_METHOD_NDT_OMP) {
+    if (b->method != MI355_METHOD_FAST_GICP) {
       Part& pt = *b->parts[0];
-      ndt_solver_results(*b->ndt_solver, results, nullptr);
+      if (b->method == MI355_METHOD_NDT_OMP) ndt_solver_results(*b->ndt_solver, results, nullptr);
+      else icp_batch_results(*b->icp, results, nullptr);
       if (fitness) gicp_fitness_values(b->stream(), pt.gb, fitness);
     } else {
       for (auto& pt : b->parts)  // (the batch's stream has joined every part's)

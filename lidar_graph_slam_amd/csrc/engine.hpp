@@ -200,14 +200,23 @@ void gicp_trial_cost_probe(hipStream_t s, GicpBatch& gb, const CloudSet& src, co
                            const double* T_trial16, double* model_cost, double* direct_cost);
 
 // ---- icp.hip -------------------------------------------------------------------------------------------------
+// pcl::IterativeClosestPoint for S pairs at once (every pair's state in HBM, advanced on the device); a registration object is a
+// batch of one.
+struct IcpBatch;
+IcpBatch* icp_batch_create();
+void icp_batch_destroy(IcpBatch*);
+// src: [S][spitch] points in any order, counts on the device, none above max_count; tgt: built sets (the NN voxel hash is all
+// point-to-point ICP needs); pair p registers against target tgt_of_src_host[p] (nullptr: p).  Blocks until every pair is done.
+void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, size_t spitch, const int* d_src_counts, size_t max_count, const CloudSet& tgt,
+                     const int* tgt_of_src_host, const float* guesses_host, const mi355_icp_params& p);
+void icp_batch_results(IcpBatch& b, mi355_result* out, float* T16_all);
 struct IcpScratch {
-  DevBuf<float4> cur;        // the source as moved so far (input_transformed)
-  DevBuf<double> partials, sums;
-  PinnedBuf<double> h_sums;
+  IcpBatch* batch = nullptr;
+  ~IcpScratch();
 };
-// pcl::IterativeClosestPoint::align: source `d_src` (caller order, n points) against a built target set
-void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4* d_src, size_t n, const mi355_icp_params& p, const float* guess16,
-               mi355_result* out);
+// pcl::IterativeClosestPoint::align: source `d_src` (caller order, n points, the count also on the device) against a built target set
+void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4* d_src, const int* d_src_count, size_t n, const mi355_icp_params& p,
+               const float* guess16, mi355_result* out);
 
 // ---- gicp_bfgs.hip ---------------------------------------------------------------------------------------------
 struct BfgsScratch {

@@ -98,17 +98,9 @@ void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows,
   std::vector<mi355_result> r((size_t)S);
   std::vector<double> f((size_t)S);
   const mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
-  if (params_.registration_method == MI355_METHOD_ICP || params_.registration_method == MI355_METHOD_GICP) {
-    // one candidate at a time as the reference does (:315-321), everything device-resident
-    if (!ls.pairwise && params_.registration_method == MI355_METHOD_ICP) {
-      auto icp = std::make_shared<IterativeClosestPoint>(ctx);
-      icp->setMaxCorrespondenceDistance(30);  // :145-149
-      icp->setMaximumIterations(100);
-      icp->setTransformationEpsilon(1e-8);
-      icp->setEuclideanFitnessEpsilon(1e-6);
-      icp->setRANSACIterations(0);  // :149 (hard-coded there; the yaml's ransac_iteration is read for "GICP" only)
-      ls.pairwise = icp;
-    } else if (!ls.pairwise) {
+  if (params_.registration_method == MI355_METHOD_GICP) {
+    // pclomp's BFGS GICP: one candidate at a time as the reference does (:315-321), everything device-resident
+    if (!ls.pairwise) {
       auto gicp = std::make_shared<GeneralizedIterativeClosestPoint>(ctx);
       gicp->setMaxCorrespondenceDistance(params_.correspondence_distance);  // :133-139
       gicp->setMaximumIterations(params_.max_iteration);
@@ -142,12 +134,21 @@ void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows,
     np.step_size = params_.step_size;
     np.resolution = params_.ndt_resolution;
     np.max_iterations = params_.max_iteration;
-    const bool ndt = params_.registration_method == MI355_METHOD_NDT_OMP;
+    mi355_icp_params ip{};
+    mi355_icp_default_params(&ip);   // :145-149 (hard-coded there; the yaml's ransac_iteration is read for "GICP" only)
+    ip.max_correspondence_distance = 30;
+    ip.max_iterations = 100;
+    ip.transformation_epsilon = 1e-8;
+    ip.euclidean_fitness_epsilon = 1e-6;
+    ip.ransac_iterations = 0;
+    const int method = params_.registration_method;
+    const void* mp = method == MI355_METHOD_NDT_OMP ? (const void*)&np : (method == MI355_METHOD_ICP ? (const void*)&ip : (const void*)&gp);
+    const size_t mps = method == MI355_METHOD_NDT_OMP ? sizeof(np) : (method == MI355_METHOD_ICP ? sizeof(ip) : sizeof(gp));
     std::vector<mi355_cloud*> th, sh;
     for (auto& c : submap) th.push_back(c->get());
     for (auto& c : source) sh.push_back(c->get());
     // the lane's batch object outlives close() (grow-only) and runs its live slots only
-    ls.lane.register_batch(params_.registration_method, ndt ? (const void*)&np : (const void*)&gp, ndt ? sizeof(np) : sizeof(gp), sh, th, tgt_of_src,
+    ls.lane.register_batch(method, mp, mps, sh, th, tgt_of_src,
                            nullptr /* align(*output): identity guess, :318 */, nullptr, &pf, /*with_fitness=*/true, r.data(), f.data());
   }
   for (int s = 0; s < S; s++) {

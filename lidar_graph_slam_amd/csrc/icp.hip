@@ -2,39 +2,78 @@
 // (graph_based_slam.param.yaml:9; graph_based_slam.cpp:142-151, called at :315-322).  Point-to-point ICP is the same
 // data-parallel pass as GICP's update_correspondences + linearize with a smaller reduction: per source point an exact 1-NN
 // in the target's voxel hash (32 algorithmic bytes: source point + target point) and 17 fp64 sums (count, sum p, sum q,
-// sum p q^T, sum d2) from which the host fits the rigid transform (Horn's quaternion method = the rotation Umeyama's SVD
-// returns) and evaluates PCL's DefaultConvergenceCriteria.  One launch + a 136-byte read-back per iteration: the loop is
-// serial by definition (every iteration moves the cloud it searches from).
+// sum p q^T, sum d2), from which icp_fit.hpp fits the rigid transform and evaluates PCL's DefaultConvergenceCriteria.
+// BATCHED (round 5): S pairs against the targets tgt_of_src names, every pair's state in HBM — k_icp_step moves and searches the
+// sources of all pairs still iterating, k_icp_advance (one thread per pair) adds a pair's block partials in block order, fits and
+// decides; nothing is read back between iterations, the host polls the number of unfinished pairs every few iterations.  A
+// registration object is a batch of one (round 4: one launch + a 136-byte read-back + a stream synchronisation per iteration), so
+// LoopClosureCore with the reference's default yaml is one launch sequence for all its candidates.
 #include "engine.hpp"
 #include "grid.hpp"
+#include "icp_fit.hpp"
 #include "primitives.hpp"
 
 namespace mi355 {
 
-constexpr int kIcpAcc = 17;
 constexpr int kIcpBlock = 256;
+constexpr int kIcpPartStride = 24;
 
-struct Mat4f16 {
-  float m[16];
+struct IcpBatch {
+  int S = 0, G = 1;
+  DevBuf<IcpPairState> state;
+  DevBuf<float4> cur;        // [S][pitch] the sources as moved so far (input_transformed)
+  size_t pitch = 0;
+  DevBuf<int> tgt_of_src, n_active;
+  DevBuf<float> guesses;
+  DevBuf<double> partials;   // [S][G][kIcpPartStride]
+  PinnedBuf<int> h_active;
+  PinnedBuf<IcpPairState> h_state;
+  std::vector<int> h_map;
+  std::vector<float> h_guess;
+  int rounds = 0;
 };
+IcpBatch* icp_batch_create() { return new IcpBatch(); }
+void icp_batch_destroy(IcpBatch* b) { delete b; }
 
-// cur[i] <- T_inc * cur[i] (pcl::transformPointCloud arithmetic), then the correspondence sums at the NEW positions... no:
-// PCL estimates the correspondences on the cloud as it stands, fits, THEN moves the cloud.  So one launch = [move by the
-// previous iteration's fit] + [correspondences and sums at the moved positions]; the first launch moves by the guess.
-__global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict__ in, float4* __restrict__ cur, int n, Mat4f16 T,
-                                                        const float4* __restrict__ tpts, const int* __restrict__ torig,
-                                                        const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
-                                                        size_t tslots, float max_d2, double* __restrict__ partials) {
+__global__ void k_icp_begin(IcpPairState* __restrict__ st, const float* __restrict__ guesses, const int* __restrict__ scount,
+                            const GridMeta* __restrict__ tmeta, const int* __restrict__ tgt_of_src, int S) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S) return;
+  float g[16];
+  for (int k = 0; k < 16; k++) g[k] = guesses[16 * p + k];
+  icp_begin(st[p], g, scount[p], tmeta[tgt_of_src[p]].n);
+  if (scount[p] <= 0) { st[p].active = 0; }  // nothing to register: reported as PCL reports a failed fit (not converged, the guess)
+}
+
+// cur[i] <- Tinc * (in or cur)[i] (pcl::transformPointCloud arithmetic), then the correspondences and sums at the moved positions:
+// PCL estimates the correspondences on the cloud as it stands, fits, THEN moves the cloud — so one launch = [move by the previous
+// iteration's fit] + [correspondences and sums]; the first launch moves the input by the guess.  grid = xcd_grid(G, S): the blocks
+// of a pair share an XCD (its target's points and hash table in ONE L2); blocks of finished pairs leave at once.
+__global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict__ src, size_t spitch, float4* __restrict__ cur, size_t cpitch,
+                                                        const IcpPairState* __restrict__ state, const float4* __restrict__ tpts,
+                                                        const int* __restrict__ torig, const HashSlot* __restrict__ ttable,
+                                                        const GridMeta* __restrict__ tmeta, size_t tcap, size_t tslots,
+                                                        const int* __restrict__ tgt_of_src, float max_d2, int G, int S,
+                                                        double* __restrict__ partials) {
   __shared__ double smem[4 * kIcpAcc];
-  const GridView g = grid_view(tpts, torig, ttable, tmeta, 0, tcap, tslots);
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
+  const IcpPairState& st = state[pair];
+  if (!st.active) return;
+  const int n = st.n;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.Tinc[k];
+  const float4* in = st.moved ? cur + (size_t)pair * cpitch : src + (size_t)pair * spitch;
+  float4* out = cur + (size_t)pair * cpitch;
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
   double acc[kIcpAcc];
 #pragma unroll
   for (int k = 0; k < kIcpAcc; k++) acc[k] = 0.0;
-  for (int i = blockIdx.x * kIcpBlock + threadIdx.x; i < n; i += gridDim.x * kIcpBlock) {
+  for (int i = bx * kIcpBlock + threadIdx.x; i < n; i += G * kIcpBlock) {
     const float4 p0 = in[i];
-    const float4 p = make_float4(transform_row(T.m, p0.x, p0.y, p0.z), transform_row(T.m + 4, p0.x, p0.y, p0.z),
-                                 transform_row(T.m + 8, p0.x, p0.y, p0.z), p0.w);
-    cur[i] = p;
+    const float4 p = make_float4(transform_row(T, p0.x, p0.y, p0.z), transform_row(T + 4, p0.x, p0.y, p0.z), transform_row(T + 8, p0.x, p0.y, p0.z), p0.w);
+    out[i] = p;
     Nearest1 nn{g.orig, INFINITY, -1};
     // CorrespondenceEstimation::determineCorrespondences keeps a pair iff d2 <= max_dist^2
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) grid_search(g, p.x, p.y, p.z, nextafterf(max_d2, INFINITY), nn, 0, 2);
@@ -51,127 +90,119 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
   }
   block_sum<kIcpAcc, 4>(acc, smem);
   if (threadIdx.x == 0) {
-    double* out = partials + (size_t)blockIdx.x * kIcpAcc;
+    double* o = partials + ((size_t)pair * G + bx) * kIcpPartStride;
 #pragma unroll
-    for (int k = 0; k < kIcpAcc; k++) out[k] = acc[k];
+    for (int k = 0; k < kIcpAcc; k++) o[k] = acc[k];
   }
 }
 
-__global__ void k_icp_reduce(const double* __restrict__ partials, int nblk, double* __restrict__ sums) {
-  const int k = threadIdx.x;
-  if (k >= kIcpAcc) return;
-  double s = 0;
-  for (int b = 0; b < nblk; b++) s += partials[(size_t)b * kIcpAcc + k];  // fixed order: bitwise reproducible
-  sums[k] = s;
+__device__ __forceinline__ int icp_blocks_dev(int n, int G) { return max(1, min(G, (n + kIcpBlock - 1) / kIcpBlock)); }
+
+// One thread per pair: the pair's block partials added in block order (bitwise reproducible), the fit, the convergence criteria.
+__global__ __launch_bounds__(64) void k_icp_advance(IcpPairState* __restrict__ state, const double* __restrict__ partials, IcpConsts c, int G, int S,
+                                                    int* __restrict__ n_active) {
+  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= S) return;
+  IcpPairState& st = state[pair];
+  if (!st.active) return;
+  const int nb = min(G, max(1, (st.n + kIcpBlock - 1) / kIcpBlock));  // blocks past the end of the cloud wrote nothing
+  double sums[kIcpAcc];
+#pragma unroll
+  for (int k = 0; k < kIcpAcc; k++) sums[k] = 0.0;
+  for (int b = 0; b < nb; b++) {
+    const double* row = partials + ((size_t)pair * G + b) * kIcpPartStride;
+#pragma unroll
+    for (int k = 0; k < kIcpAcc; k++) sums[k] += row[k];
+  }
+  icp_advance(st, sums, c);
+  if (n_active && st.active) atomicAdd(n_active, 1);
 }
 
-// least-squares rigid fit q ~ R p + t from the sums (Horn 1987: largest eigenvector of the 4x4 quaternion matrix), fp64
-static bool rigid_from_sums(const double* s, double* T16) {
-  const double n = s[0];
-  if (n < 3) return false;
-  const double mp[3] = {s[1] / n, s[2] / n, s[3] / n}, mq[3] = {s[4] / n, s[5] / n, s[6] / n};
-  double S[3][3];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) S[i][j] = s[7 + 3 * i + j] - n * mp[i] * mq[j];
-  double A[16] = {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0],
-                  S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2],
-                  S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1],
-                  S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]};
-  double V[16];
-  for (int i = 0; i < 16; i++) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 64; sweep++) {  // cyclic Jacobi, symmetric 4x4
-    double off = 0, diag = 0;
-    for (int i = 0; i < 4; i++)
-      for (int j = 0; j < 4; j++) { const double v = A[4 * i + j] * A[4 * i + j]; if (i == j) diag += v; else off += v; }
-    if (off <= 1e-300 || off <= 1e-32 * diag) break;
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 4; q++) {
-        const double apq = A[4 * p + q];
-        if (apq == 0.0) continue;
-        const double tau = (A[4 * q + q] - A[4 * p + p]) / (2.0 * apq);
-        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
-        for (int k = 0; k < 4; k++) { const double a = A[4 * k + p], b = A[4 * k + q]; A[4 * k + p] = c * a - sn * b; A[4 * k + q] = sn * a + c * b; }
-        for (int k = 0; k < 4; k++) { const double a = A[4 * p + k], b = A[4 * q + k]; A[4 * p + k] = c * a - sn * b; A[4 * q + k] = sn * a + c * b; }
-        for (int k = 0; k < 4; k++) { const double a = V[4 * k + p], b = V[4 * k + q]; V[4 * k + p] = c * a - sn * b; V[4 * k + q] = sn * a + c * b; }
-      }
+// src: [S][spitch] points (any order), counts on the device; tgt: the targets' NN voxel hash (built sets); pair p -> target
+// tgt_of_src_host[p] (nullptr: p).  Blocks until every pair is done; the final states stay in the batch (icp_batch_results).
+void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, size_t spitch, const int* d_src_counts, size_t max_count, const CloudSet& tgt,
+                     const int* tgt_of_src_host, const float* guesses_host, const mi355_icp_params& p) {
+  b.S = S;
+  b.h_map.resize((size_t)S);
+  b.h_guess.resize((size_t)S * 16);
+  for (int i = 0; i < S; i++) {
+    const int u = tgt_of_src_host ? tgt_of_src_host[i] : i;
+    if (u < 0 || u >= tgt.B) throw ArgError(MI355_EINVAL, "tgt_of_src entry out of range");
+    b.h_map[(size_t)i] = u;
+    for (int k = 0; k < 16; k++) b.h_guess[(size_t)i * 16 + k] = guesses_host ? guesses_host[(size_t)i * 16 + k] : ((k % 5 == 0) ? 1.f : 0.f);
   }
-  int best = 0;
-  for (int k = 1; k < 4; k++)
-    if (A[5 * k] > A[5 * best]) best = k;
-  double q[4] = {V[best], V[4 + best], V[8 + best], V[12 + best]};
-  const double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (double& v : q) v /= nq;
-  const double w = q[0], x = q[1], y = q[2], z = q[3];
-  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
-                       2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
-                       2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) T16[4 * r + c] = R[3 * r + c];
-    T16[4 * r + 3] = mq[r] - (R[3 * r] * mp[0] + R[3 * r + 1] * mp[1] + R[3 * r + 2] * mp[2]);
-  }
-  T16[12] = T16[13] = T16[14] = 0;
-  T16[15] = 1;
-  return true;
-}
-
-void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4* d_src, size_t n, const mi355_icp_params& p, const float* guess16,
-               mi355_result* out) {
-  const int nblk = std::max(1, std::min(1024, div_up((long)n, kIcpBlock * 4)));
-  sc.cur.ensure(std::max<size_t>(n, 1));
-  sc.partials.ensure((size_t)nblk * kIcpAcc);
-  sc.sums.ensure(kIcpAcc);
-  sc.h_sums.ensure(kIcpAcc);
+  // blocks per pair: ~4 points per thread for a lone pair (the chip is not full anyway), about 8 k blocks over a batch
+  const int Gcap = std::max(2, std::min(1024, 8192 / std::max(S, 1)));
+  b.G = std::max(1, std::min(Gcap, div_up((long)std::max<size_t>(max_count, 1), kIcpBlock * 4)));
+  b.pitch = std::max<size_t>(max_count, 1);
+  b.state.ensure((size_t)S);
+  b.h_state.ensure((size_t)S);
+  b.cur.ensure((size_t)S * b.pitch);
+  b.tgt_of_src.ensure((size_t)S);
+  b.guesses.ensure((size_t)S * 16);
+  b.partials.ensure((size_t)S * b.G * kIcpPartStride);
+  b.n_active.ensure(1);
+  b.h_active.ensure(1);
+  MI_HIP(hipMemcpyAsync(b.tgt_of_src.p, b.h_map.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, s));
+  MI_HIP(hipMemcpyAsync(b.guesses.p, b.h_guess.data(), (size_t)S * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_icp_begin, dim3(div_up(S, 64)), dim3(64), 0, s, b.state.p, (const float*)b.guesses.p, d_src_counts, (const GridMeta*)tgt.meta.p,
+                     (const int*)b.tgt_of_src.p, S);
   const double md2 = p.max_correspondence_distance * p.max_correspondence_distance;
   const float max_d2 = md2 > 3.0e38 ? INFINITY : (float)md2;
-  const double rot_thr = p.rotation_epsilon > 0 ? p.rotation_epsilon : 1.0 - p.transformation_epsilon;
-  Mat4f16 Tinc;
-  memcpy(Tinc.m, guess16, sizeof(Tinc.m));
-  float final_T[16];
-  memcpy(final_T, guess16, sizeof(final_T));
-  int iterations = 0;
-  bool converged = false;
-  double prev_mse = 1.7976931348623157e308, mse = 0;
-  const float4* in = d_src;  // the first step moves the input by the guess, later ones move `cur` in place
-  for (;;) {
-    TimedLaunch tl(KF_CORRESPOND, s);
-    hipLaunchKernelGGL(k_icp_step, dim3(nblk), dim3(kIcpBlock), 0, s, in, sc.cur.p, (int)n, Tinc, (const float4*)tgt.pts.p, (const int*)tgt.orig.p,
-                       (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, max_d2, sc.partials.p);
-    hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(64), 0, s, (const double*)sc.partials.p, nblk, sc.sums.p);
-    MI_HIP(hipMemcpyAsync(sc.h_sums.p, sc.sums.p, kIcpAcc * sizeof(double), hipMemcpyDeviceToHost, s));
-    MI_HIP(hipStreamSynchronize(s));
-    in = sc.cur.p;
-    const double* sm = sc.h_sums.p;
-    double Td[16];
-    if (!rigid_from_sums(sm, Td)) {  // "Not enough correspondences found. Relax your threshold parameters."
-      converged = false;
-      break;
+  IcpConsts c;
+  c.max_iterations = p.max_iterations;
+  c.transformation_epsilon = p.transformation_epsilon;
+  c.euclidean_fitness_epsilon = p.euclidean_fitness_epsilon;
+  c.rot_threshold = p.rotation_epsilon > 0 ? p.rotation_epsilon : 1.0 - p.transformation_epsilon;
+  const int chunk = 8;
+  const dim3 grid(xcd_grid(b.G, S));
+  b.rounds = 0;
+  for (int it = 0; it < std::max(p.max_iterations, 1);) {
+    MI_HIP(hipMemsetAsync(b.n_active.p, 0, sizeof(int), s));
+    for (int k = 0; k < chunk && it < std::max(p.max_iterations, 1); k++, it++) {
+      TimedLaunch tl(KF_CORRESPOND, s);
+      hipLaunchKernelGGL(k_icp_step, grid, dim3(kIcpBlock), 0, s, d_src, spitch, b.cur.p, b.pitch, (const IcpPairState*)b.state.p, (const float4*)tgt.pts.p,
+                         (const int*)tgt.orig.p, (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap,
+                         (const int*)b.tgt_of_src.p, max_d2, b.G, S, b.partials.p);
+      const bool last = k == chunk - 1 || it + 1 >= std::max(p.max_iterations, 1);
+      hipLaunchKernelGGL(k_icp_advance, dim3(div_up(S, 64)), dim3(64), 0, s, b.state.p, (const double*)b.partials.p, c, b.G, S, last ? b.n_active.p : nullptr);
     }
-    for (int k = 0; k < 16; k++) Tinc.m[k] = (float)Td[k];
-    float F[16];  // final_transformation_ = transformation_ * final_transformation_ (Matrix4f)
-    for (int r = 0; r < 4; r++)
-      for (int c = 0; c < 4; c++) {
-        float a = 0.f;
-        for (int k = 0; k < 4; k++) a += Tinc.m[4 * r + k] * final_T[4 * k + c];
-        F[4 * r + c] = a;
-      }
-    memcpy(final_T, F, sizeof(F));
-    iterations++;
-    // DefaultConvergenceCriteria::hasConverged (max_iterations_similar_transforms_ = 0, absolute MSE threshold 1e-12)
-    if (iterations >= p.max_iterations) { converged = true; break; }
-    const double cos_angle = 0.5 * ((double)Tinc.m[0] + (double)Tinc.m[5] + (double)Tinc.m[10] - 1.0);
-    const double tr2 = (double)Tinc.m[3] * Tinc.m[3] + (double)Tinc.m[7] * Tinc.m[7] + (double)Tinc.m[11] * Tinc.m[11];
-    if (cos_angle >= rot_thr && tr2 <= p.transformation_epsilon) { converged = true; break; }
-    mse = sm[16] / sm[0];
-    if (fabs(mse - prev_mse) < 1e-12) { converged = true; break; }
-    if (fabs(mse - prev_mse) / prev_mse < p.euclidean_fitness_epsilon) { converged = true; break; }
-    prev_mse = mse;
+    MI_LAUNCH_CHECK();
+    b.rounds = it;
+    MI_HIP(hipMemcpyAsync(b.h_active.p, b.n_active.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    MI_HIP(hipStreamSynchronize(s));
+    if (*b.h_active.p == 0) break;
   }
-  memset(out, 0, sizeof(*out));
-  memcpy(out->T, final_T, sizeof(final_T));
-  out->converged = converged ? 1 : 0;
-  out->iterations = iterations;
-  out->error = mse;
+  MI_HIP(hipMemcpyAsync(b.h_state.p, b.state.p, (size_t)S * sizeof(IcpPairState), hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+}
+
+void icp_batch_results(IcpBatch& b, mi355_result* out, float* T16_all) {
+  for (int i = 0; i < b.S; i++) {
+    const IcpPairState& st = b.h_state.p[i];
+    if (out) {
+      mi355_result& o = out[i];
+      memset(&o, 0, sizeof(o));
+      memcpy(o.T, st.final_T, sizeof(st.final_T));
+      o.converged = st.converged;
+      o.iterations = st.iterations;
+      o.error = st.mse;
+      o.n_source = st.n;
+      o.n_target = st.n_target;
+    }
+    if (T16_all) memcpy(T16_all + (size_t)i * 16, st.final_T, 16 * sizeof(float));
+  }
+}
+
+// pcl::IterativeClosestPoint::align of ONE pair: a batch of one (source d_src in the caller's order, its count on the device).
+void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4* d_src, const int* d_src_count, size_t n, const mi355_icp_params& p,
+               const float* guess16, mi355_result* out) {
+  if (!sc.batch) sc.batch = icp_batch_create();
+  icp_batch_align(s, *sc.batch, 1, d_src, n, d_src_count, n, tgt, nullptr, guess16, p);
+  icp_batch_results(*sc.batch, out, nullptr);
+}
+IcpScratch::~IcpScratch() {
+  if (batch) icp_batch_destroy(batch);
 }
 
 }  // namespace mi355

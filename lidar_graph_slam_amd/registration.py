@@ -310,8 +310,8 @@ class GeneralizedIterativeClosestPoint(_Registration):
 
 class BatchRegistration:
     """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one registration per pair —
-    FAST_GICP (default) or NDT_OMP, the two engines GraphBasedSLAM::get_registration offers besides ICP
-    (graph_based_slam.cpp:101-152)."""
+    FAST_GICP (default), NDT_OMP or ICP, three of the four engines GraphBasedSLAM::get_registration offers
+    (graph_based_slam.cpp:80-152; ICP is that node's yaml default)."""
 
     def __init__(self, n_sources: int, n_targets: int, capacity: int, ctx: Context | None = None, method: str = "FAST_GICP", **params):
         self.ctx = ctx or default_context()
@@ -319,8 +319,10 @@ class BatchRegistration:
             self.params, code = L.gicp_params(**params), L.METHOD_FAST_GICP
         elif method == "NDT_OMP":
             self.params, code = L.ndt_params(**params), L.METHOD_NDT_OMP
+        elif method == "ICP":
+            self.params, code = L.icp_params(**params), L.METHOD_ICP
         else:
-            raise L.Mi355Error(L.EINVAL, f"batch registration method {method!r} (FAST_GICP or NDT_OMP)")
+            raise L.Mi355Error(L.EINVAL, f"batch registration method {method!r} (FAST_GICP, NDT_OMP or ICP)")
         self.method = method
         self.n_sources, self.n_targets, self.capacity = int(n_sources), int(n_targets), int(capacity)
         self.handle = self.ctx._lib.mi355_batch_create(self.ctx.handle, code, C.byref(self.params), self.n_sources, self.n_targets,

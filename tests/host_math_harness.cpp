@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE: compiles the PRODUCT's shared host/device maths header (lidar_graph_slam_amd/csrc/devmath.hpp)
 // with g++ so that the CPU suite can check it against the oracle / NumPy without a GPU.  Never shipped.
 #include "../lidar_graph_slam_amd/csrc/devmath.hpp"
+#include "../lidar_graph_slam_amd/csrc/icp_fit.hpp"
 #include "../lidar_graph_slam_amd/csrc/ndt_mt.hpp"
 
 using namespace mi355;
@@ -17,6 +18,8 @@ void hm_se3_exp(const double* d, double* T16) {
 }
 int hm_ldlt6(const double* A, const double* rhs, double* x) { return ldlt6_solve(A, rhs, x) ? 1 : 0; }
 void hm_svd6(const double* H, const double* rhs, double* x) { svd6_solve_sym(H, rhs, x); }
+// ICP's rigid fit from the 17 sums of an iteration (Horn's quaternion method); returns 0 when there are fewer than 3 correspondences
+int hm_icp_rigid(const double* sums17, double* T16) { return icp_rigid_from_sums(sums17, T16) ? 1 : 0; }
 // NDT's Newton solve: pivoted LDL^T for a definite, well-conditioned Hessian, the Jacobi SVD solve for everything else
 void hm_ndt_newton(const double* H, const double* rhs, double* x) { ndt_newton_solve(H, rhs, x); }
 void hm_regularize(const double* cov6, int method, double* out6) {

@@ -30,13 +30,13 @@ def _candidates(n_targets=3, n_sources=10):
     return sources, targets, np.asarray(tgt_of_src), truth
 
 
-@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP"])
+@pytest.mark.parametrize("method", ["FAST_GICP", "NDT_OMP", "ICP"])
 def test_sharded_registration_equals_the_single_batch(method):
     from lidar_graph_slam_amd.multi import MultiDevice, shard_by_target
     from lidar_graph_slam_amd.registration import BatchRegistration
 
     sources, targets, tgt_of_src, truth = _candidates()
-    kw = dict(max_iterations=30) if method == "FAST_GICP" else dict(max_iterations=30, resolution=1.0)
+    kw = {"FAST_GICP": dict(max_iterations=30), "NDT_OMP": dict(max_iterations=30, resolution=1.0), "ICP": dict(max_iterations=40)}[method]
     cap = max(len(c) for c in sources + targets)
     S, U = len(sources), len(targets)
     pk = lambda cl: (np.stack([np.pad(c, ((0, cap - len(c)), (0, 0))) for c in cl]), np.array([len(c) for c in cl], np.int32))  # noqa: E731

@@ -60,6 +60,34 @@ def test_ldlt6_and_svd6(hm):
     np.testing.assert_allclose(x, np.linalg.solve(S, b), rtol=1e-8)
 
 
+def test_icp_rigid_fit_is_the_kabsch_fit(hm):
+    """icp_fit.hpp icp_rigid_from_sums (the fit k_icp_advance runs on the device for every pair of a batch): the least-squares rigid
+    transform of the matched pairs, from their 17 sums, equals the SVD (Kabsch / Umeyama) solution."""
+    rng = np.random.default_rng(21)
+    for trial in range(20):
+        n = int(rng.integers(3, 400))
+        P = rng.normal(size=(n, 3)) * rng.uniform(0.5, 30.0, 3) + rng.uniform(-50, 50, 3)
+        ang = rng.uniform(-0.3, 0.3, 3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+        Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+        Rz = np.array([[np.cos(ang[2]), -np.sin(ang[2]), 0], [np.sin(ang[2]), np.cos(ang[2]), 0], [0, 0, 1]])
+        Rt, tt = Rz @ Ry @ Rx, rng.uniform(-2, 2, 3)
+        Q = P @ Rt.T + tt + rng.normal(0, 0.02, (n, 3))
+        sums = np.concatenate([[n], P.sum(0), Q.sum(0), (P[:, :, None] * Q[:, None, :]).sum(0).ravel(), [((Q - P) ** 2).sum()]])
+        T = np.empty(16)
+        assert hm.hm_icp_rigid(_p(np.ascontiguousarray(sums)), _p(T)) == 1
+        T = T.reshape(4, 4)
+        mp, mq = P.mean(0), Q.mean(0)
+        U, _, Vt = np.linalg.svd((Q - mq).T @ (P - mp))
+        D = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+        Rk = U @ D @ Vt
+        np.testing.assert_allclose(T[:3, :3], Rk, atol=1e-9)
+        np.testing.assert_allclose(T[:3, 3], mq - Rk @ mp, atol=1e-8)
+    few = np.zeros(17)
+    few[0] = 2
+    assert hm.hm_icp_rigid(_p(few), _p(np.empty(16))) == 0  # "Not enough correspondences found"
+
+
 def test_ndt_newton_solve_is_the_svd_solve(hm):
     """ndt_mt.hpp ndt_newton_solve: the pivoted-elimination shortcut (well-conditioned Hessians, definite or not) and the Jacobi
     fallback both give JacobiSVD(H).solve(rhs) — the rank-truncating solve for a singular H included."""
