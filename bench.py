@@ -57,23 +57,43 @@ TOL_TRUTH_T, TOL_TRUTH_R = 0.015, 1.0e-3   # vs ground truth on the 2 cm-noise s
 TOL_ORACLE_T, TOL_ORACLE_R = 1.0e-3, 1.0e-4  # vs the oracle on the SAME input, same iteration count
 N_BASE = 32      # distinct ray-cast pairs per rank: own street scene, own sensor pose, own relative motion (synth.bench_pair_spec);
                  # pair p of the batch is pair p % N_BASE under its own world transform (which re-bins every voxel grid)
-N_ORACLE = 8     # pairs of the timed batch that the oracle registers again, from the same world-transformed clouds
+N_ORACLE = 16    # pairs of the timed batch that the oracle registers again, from the same world-transformed clouds (one of them the pair
+                 # with the largest error against the ground truth)
 
 
 def base_pairs(rank: int, n_base: int):
     """The distinct ray-cast pairs of this rank.  Ray casting is single-threaded NumPy (~1.5 s per pair): a pool of SPAWNED
-    workers casts them side by side (fresh interpreters: nothing of this process's GPU state travels)."""
+    workers casts them side by side (fresh interpreters: nothing of this process's GPU state travels).  With several ranks on a node
+    the pairs are cast ONCE, by local rank 0 with every host core, and handed to the other ranks through a file in /dev/shm (8 ranks
+    casting 32 pairs each would queue 512 casts on the host before any GPU does anything); every rank still places them under its
+    own world transforms (main), so no two pairs of the job are the same input."""
     import multiprocessing as mp
 
     from lidar_graph_slam_amd import synth
 
-    specs = [synth.bench_pair_spec(i, rank) for i in range(n_base)]
-    workers = max(1, min(n_base, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    shared = os.path.join("/dev/shm", f"mi355_bench_bases_{os.environ.get('MASTER_PORT', '0')}_{n_base}.npz") if local_world > 1 else None
+    if shared and local_rank != 0:
+        t0 = time.time()
+        while not os.path.exists(shared):
+            if time.time() - t0 > 900:
+                raise SystemExit(f"bench.py: local rank 0 did not deliver {shared}")
+            time.sleep(0.2)
+        z = np.load(shared)
+        return [(z[f"s{i}"], z[f"t{i}"], z[f"g{i}"]) for i in range(n_base)]
+    specs = [synth.bench_pair_spec(i, 0 if shared else rank) for i in range(n_base)]
+    workers = max(1, min(n_base, (os.cpu_count() or 8) - 1))
     if workers == 1:
         pairs = [synth.make_pair_job(sp) for sp in specs]
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             pairs = pool.map(synth.make_pair_job, specs)
+    if shared:
+        tmp = shared + f".{os.getpid()}.tmp.npz"
+        np.savez(tmp, **{f"s{i}": p[0] for i, p in enumerate(pairs)}, **{f"t{i}": p[1] for i, p in enumerate(pairs)},
+                 **{f"g{i}": np.asarray(p[2]) for i, p in enumerate(pairs)})
+        os.replace(tmp, shared)  # (atomic: a reader never sees half a file)
     return [(src, tgt, T_gt) for (src, tgt, T_gt) in pairs]
 
 
@@ -125,6 +145,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        dist.barrier()  # every rank has read the shared base pairs: local rank 0 takes the file out of /dev/shm again
+        if local_rank == 0:
+            try:
+                os.remove(os.path.join("/dev/shm", f"mi355_bench_bases_{os.environ.get('MASTER_PORT', '0')}_{n_base}.npz"))
+            except OSError:
+                pass
 
     from lidar_graph_slam_amd import _lib as L
     from lidar_graph_slam_amd import sharding, synth
@@ -471,7 +497,7 @@ def main():
         # parity on the SAME input: N_ORACLE pairs of the timed batch, spread over the batch and over the distinct scenes, exactly
         # as the GPU saw them (world-transformed), through the oracle
         gp = O.gicp_params(max_iterations=args.iters, force_iterations=1, num_threads=min(16, hw))
-        sample = sorted({((k * P) // N_ORACLE + k) % P for k in range(N_ORACLE)})
+        sample = sorted({((k * P) // (N_ORACLE - 1) + k) % P for k in range(N_ORACLE - 1)} | {int(np.argmax(errs[:, 0]))})
         dts, drs = [], []
         for p_ in sample:
             s0, t0_ = src_d[p_].cpu().numpy(), tgt_d[p_].cpu().numpy()
