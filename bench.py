@@ -7,8 +7,8 @@ One *step* = one pass of the whole hot path over one batch of `--pairs` independ
 inputs already resident in HBM: distance filter + VoxelGrid 0.2 m on both clouds -> voxel-hash build -> k=20
 covariances -> exactly 20 Levenberg-Marquardt GICP iterations -> poses copied back.  Pairs are sharded across ranks with
 no data-path collective (weak scaling); the only collective is the MAX of the elapsed time.  BASELINE.json configs[1].
-Default: ONE batch of 2 048 pairs at a time (90 GB of HBM) — every kernel duration the roofline block reports is then what
-rocprofv3 reports for the same command.  `--inflight 2 --pairs 512` keeps two batch objects in flight on two HIP streams in the same memory
+Default: ONE batch of 4 096 pairs at a time (86 GB of the 288 GB of HBM since round 5: 21 MB per pair, the raw clouds included) —
+every kernel duration the roofline block reports is then what rocprofv3 reports for the same command.  `--inflight 2 --pairs 512` keeps two batch objects in flight on two HIP streams in the same memory
 (while one batch is in its latency- and bandwidth-bound LM iterations the next one is prefiltered and indexed by VALU-bound
 kernels): +8 % pairs/s, `--inflight 3`: +13 %; K steps are then still K whole batches, all finished inside the timed region, but
 HIP-event brackets around kernels of interleaved streams also contain the time a kernel waits for the other stream's.
@@ -102,8 +102,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=2048, help="scan pairs per GPU per step (= per batch): 2 048 pairs = 90 GB of the 288 GB; 1 024 (the default of "
-                    "rounds 1-3, what DESIGN.md quotes per-launch figures at) is 4 %% slower per pair, 128: 33 %%")
+    ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU per step (= per batch): 4 096 pairs = 86 GB of the 288 GB; 2 048 (the default of "
+                    "rounds 3-4) is 5 %% slower per pair, 1 024: 10 %%, 128: 50 %%")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--leaf", type=float, default=0.2)
     ap.add_argument("--cell", type=float, default=0.0, help="voxel-hash cell (m); 0 = library default")
@@ -323,6 +323,9 @@ def main():
                "note": "the same batch from HOST buffers (pageable memory) through mi355_batch_set_targets/_sources: upload + the whole step, one batch at a time; "
                        "not the headline value"}
         del src_h, tgt_h
+
+    hbm_free, hbm_total = torch.cuda.mem_get_info(dev)
+    hbm_in_use = int(hbm_total - hbm_free)  # everything on the device: the raw clouds of the batch, the batch object, its workspaces
 
     # ---- correctness of what was timed: pose error vs ground truth for every pair of this rank ------------------------
     errs = []
@@ -553,6 +556,7 @@ def main():
             "workload": ("BASELINE configs[1]: 64k-pt scan pairs, distance filter 1.0 m + voxel 0.2 m + GICP k=20, exactly 20 LM iterations, batched" if not args.sor else
                          "64k-pt scan pairs through the reference's launch-file prefilter (distance 1.0 m + voxel 0.1 m + SOR 30 / 1.2) + GICP k=20, exactly 20 LM iterations, batched"),
             "pairs_per_gpu_per_step": P,
+            "hbm_bytes_in_use": hbm_in_use,
             "distinct_ray_cast_pairs": n_base,
             "batches_in_flight": len(batches),
             "raw_points_per_cloud": int(cap),

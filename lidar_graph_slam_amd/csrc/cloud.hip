@@ -10,8 +10,12 @@ namespace mi355 {
 void CloudSet::alloc(int B_, size_t cap_) {
   B = B_;
   cap = cap_;
+  // The table of a cloud is sized on the device to 4 x its occupied cells (k_grid_hash_size): ~0.25 entries per point for a voxelised
+  // scan.  Its share of the allocation holds 2 - 4 slots per point of capacity (until round 5: 8 - 16, the worst case of 5 levels
+  // with every point alone in its cell at each of them - 8 MB per 65 536-point slot, half of a batch's footprint, for 0.5 MB used);
+  // a cloud whose cells do not fit (points tens of metres apart) keeps as many of the coarse levels as do.
   size_t s = 16;
-  while (s < 8 * cap) s <<= 1;  // up to 5 levels of cells, load factor <= 0.625 in the worst case
+  while (s < 2 * cap) s <<= 1;
   slots_cap = s;
   pts.ensure((size_t)B * cap);
   orig.ensure((size_t)B * cap);
@@ -132,7 +136,8 @@ __global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __re
   while (top < kMaxLevel && (((max(dx, max(dy, dz)) - 1) >> top) > 0)) top++;
   m.top_level = top;
   m.n_cells = 0;
-  m.pad[0] = m.pad[1] = 0;
+  for (int l = 0; l <= kMaxLevel; l++) m.level_cells[l] = 0;
+  m.pad = 0;
   // the hash size is set by k_grid_hash_size once the occupied cells have been counted (after the sort)
   m.hshift = 28;
   m.hmask = 15;
@@ -172,11 +177,13 @@ __global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pt
 // cloud - a million blocks per 1 024-cloud launch, four fifths of them past the end of their cloud - and took 0.43 ms to read 54 MB.)
 constexpr int kCountBlock = 256, kCountPer = 8;
 __global__ __launch_bounds__(kCountBlock) void k_count_cells(const uint32_t* __restrict__ keys, GridMeta* __restrict__ meta, size_t cap) {
-  __shared__ int wsum[kCountBlock / kWave];
+  __shared__ int wsum[kCountBlock / kWave][kMaxLevel + 1];
   const int c = blockIdx.y;
   const int n = meta[c].n, top = meta[c].top_level;
   const uint32_t* k = keys + (size_t)c * cap;
-  int cnt = 0;
+  int cnt[kMaxLevel + 1];
+#pragma unroll
+  for (int l = 0; l <= kMaxLevel; l++) cnt[l] = 0;
   for (int base = blockIdx.x * kCountBlock * kCountPer; base < n; base += gridDim.x * kCountBlock * kCountPer) {
     const int i0 = base + threadIdx.x * kCountPer;
     uint32_t key[kCountPer + 1];
@@ -186,26 +193,40 @@ __global__ __launch_bounds__(kCountBlock) void k_count_cells(const uint32_t* __r
 #pragma unroll
     for (int u = 0; u < kCountPer; u++) {
       const int i = i0 + u;
-      if (i < n)
-        for (int l = 0; l <= top; l++) cnt += ((i == 0) || ((key[u] >> (3 * l)) != (key[u + 1] >> (3 * l)))) ? 1 : 0;
+      if (i < n) {
+#pragma unroll
+        for (int l = 0; l <= kMaxLevel; l++)
+          if (l <= top) cnt[l] += ((i == 0) || ((key[u] >> (3 * l)) != (key[u + 1] >> (3 * l)))) ? 1 : 0;
+      }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
-  if (lane_id() == 0) wsum[wave_id()] = cnt;
+  for (int l = 0; l <= kMaxLevel; l++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt[l] += __shfl_down(cnt[l], off, kWave);
+    if (lane_id() == 0) wsum[wave_id()][l] = cnt[l];
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x <= kMaxLevel) {
     int total = 0;
-    for (int w = 0; w < kCountBlock / kWave; w++) total += wsum[w];
-    if (total > 0) atomicAdd(&meta[c].n_cells, total);
+    for (int w = 0; w < kCountBlock / kWave; w++) total += wsum[w][threadIdx.x];
+    if (total > 0) atomicAdd(&meta[c].level_cells[threadIdx.x], total);
   }
 }
 
 __global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t slots_cap, uint32_t per_cell) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= B) return;
+  // the levels whose cells fit 0.7 of the cloud's share of the table (level 0 always does: at most one cell per point)
+  int top = meta[c].top_level, cells = 0;
+  for (int l = 0; l <= top; l++) {
+    if (l > 0 && (uint32_t)(cells + meta[c].level_cells[l]) > (slots_cap / 10u) * 7u) { top = l - 1; break; }
+    cells += meta[c].level_cells[l];
+  }
+  meta[c].top_level = top;
+  meta[c].n_cells = cells;
   uint32_t slots = 16, lg = 4;
-  while (slots < per_cell * (uint32_t)max(meta[c].n_cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  while (slots < per_cell * (uint32_t)max(cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
   meta[c].hshift = 32 - lg;
   meta[c].hmask = slots - 1;
 }
@@ -1570,7 +1591,8 @@ __global__ void k_voxel_meta(const uint32_t* __restrict__ bounds, const int* __r
   m.hshift = 0; m.hmask = 0;
   m.top_level = 0;
   m.n_cells = 0;
-  m.pad[0] = m.pad[1] = 0;
+  for (int l = 0; l <= kMaxLevel; l++) m.level_cells[l] = 0;
+  m.pad = 0;
   vmeta[c] = m;
   // voxel indices are below dx dy dz; the points the filter drops carry the all-ones key and must end up behind every real one,
   // so p passes are enough when dx dy dz <= 2^(8p) - 1 (a 100 m x 100 m x 10 m scan at 0.2 m: 12.5 M voxels, 3 passes)

@@ -25,6 +25,8 @@ struct HashSlot {
   int pad;
 };
 
+constexpr int kMaxLevel = 4;
+
 struct GridMeta {
   float ox, oy, oz;   // grid origin (bounding-box minimum)
   float inv_cell, cell;
@@ -35,9 +37,10 @@ struct GridMeta {
   int overflow;       // VoxelGrid index overflow flag (pass-through)
   int top_level;      // coarsest level of the multi-level voxel hash (cell edge = cell * 2^level)
   int n_cells;        // occupied cells over all levels = entries of the hash
-  int pad[2];
+  int level_cells[kMaxLevel + 1];  // ... by level (k_count_cells; k_grid_hash_size drops the coarsest levels of a cloud whose cells
+                                   // would not fit its share of the table: the searches then walk finer cells further, results unchanged)
+  int pad;
 };
-constexpr int kMaxLevel = 4;
 
 struct Workspace {
   DevBuf<uint32_t> keys_a, keys_b;

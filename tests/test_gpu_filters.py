@@ -168,6 +168,26 @@ def test_knn_queries_far_outside(F, small_pair):
     np.testing.assert_array_equal(d2, rd)
 
 
+def test_knn_sparse_cloud_keeps_fewer_hash_levels(F):
+    """Points ~9 m apart: every point is alone in its cell at the 0.5, 1, 2 and 4 m levels of the voxel hash, whose entries then
+    outnumber what the cloud's share of the table holds (2 - 4 slots per point of capacity since round 5) - the build keeps as many
+    of the coarse levels as fit and the searches walk finer cells further: same neighbours, same distances."""
+    rng = np.random.default_rng(77)
+    t = np.zeros((3000, 4), np.float32)
+    t[:, :3] = rng.uniform([-125, -125, -20], [125, 125, 20], (3000, 3))
+    q = t[rng.choice(3000, 300, replace=False)].copy()
+    q[:, :3] += rng.normal(0, 1.0, (300, 3)).astype(np.float32)
+    for k in (1, 8, 20):
+        idx, d2 = F.knn(t, q, k)
+        ri, rd = O.knn(t, q, k)
+        np.testing.assert_array_equal(d2, rd)
+        np.testing.assert_array_equal(idx, ri)
+    covs = F.covariances(t, 20, 0)  # raw covariance (method NONE): the neighbour SETS are what this is about
+    ref = O.covariances(t, 20, 0)
+    scale = np.maximum(np.abs(ref).max(axis=(1, 2), keepdims=True), 1e-12)
+    assert (np.abs(covs.astype(np.float64) - ref) / scale).max() < 2e-6
+
+
 def test_sor(F, medium_pair):
     src, _, _ = medium_pair
     v, _ = O.voxel_grid(O.distance_filter(src, 1.0), 0.1)
