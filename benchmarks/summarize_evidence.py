@@ -12,7 +12,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+PAIRS = 4096
 SRC = os.path.join(ROOT, "gpurun_out", R)
 DST = os.environ.get("EVIDENCE_DST") or os.path.join(ROOT, "profiles")  # on the GPU box: a small directory under gpurun_out/ (the raw traces stay there)
 
@@ -76,8 +77,8 @@ def pmc_sq_table():
     order = sorted(table, key=lambda k: -table[k].get("SQ_BUSY_CYCLES", 0) * launches[k])
     with open(os.path.join(DST, f"{R}_pmc_valu.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel (per-launch averages; python bench.py --steps 1 --warmup 1 --no-cpu-baseline = 1 024 pairs; two rocprofv3 --pmc passes, "
-                    "--kernel-trace only)", "launches"] + cols + ["VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"])
+        w.writerow([f"kernel (per-launch averages; python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d = {PAIRS} pairs per step, {PAIRS // 2} per launch of the "
+                    "per-part kernels; two rocprofv3 --pmc passes, --kernel-trace only)", "launches"] + cols + ["VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"])
         for k in order[:24]:
             t = table[k]
             wc = max(t.get("SQ_WAVE_CYCLES", 0.0), 1.0)
@@ -85,11 +86,12 @@ def pmc_sq_table():
 
 
 def main():
+    global PAIRS
     os.makedirs(DST, exist_ok=True)
     bench = last_json(os.path.join(SRC, "bench_default.json"))
-    pairs = bench["config"]["pairs_per_gpu_per_step"]
-    for name in ("bench_default", "bench_hostinputs", "bench_inflight2", "bench_inflight3", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu", "config5_1gpu_4lanes",
-                 "bench_sor", "bench_1024pairs", "bench_4096pairs", "bench_hostinputs_inflight2"):
+    pairs = PAIRS = bench["config"]["pairs_per_gpu_per_step"]
+    for name in ("bench_default", "bench_hostinputs", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu", "config5_FAST_GICP", "config5_NDT_OMP",
+                 "config5_ICP", "bench_sor", "bench_1024pairs", "bench_2048pairs"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p):
             with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:
@@ -100,6 +102,11 @@ def main():
         if os.path.exists(oc):
             shutil.copy(oc, os.path.join(DST, f"{R}_{txt}.txt"))
     pmc_sq_table()
+    for f in ("ndt_batch.json", "ndt_under_trace.json", "kernel_stats_ndt.csv", "pmc_ndt.csv"):  # benchmarks/ndt_evidence.sh
+        pth = os.path.join(SRC, "ndt", f)
+        if os.path.exists(pth):
+            dst = {"ndt_batch.json": "ndt_batch.json", "ndt_under_trace.json": "ndt_batch_under_trace.json", "kernel_stats_ndt.csv": "kernel_stats_ndt.csv", "pmc_ndt.csv": "pmc_ndt.csv"}[f]
+            shutil.copy(pth, os.path.join(DST, f"{R}_{dst}"))
     fetch = pmc_per_kernel("pmc_fetch", "FETCH_SIZE")
     write = pmc_per_kernel("pmc_write", "WRITE_SIZE")
     rows = []
