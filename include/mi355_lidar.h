@@ -271,11 +271,13 @@ int mi355_cloud_save_pcd(mi355_cloud* cloud, const char* path, int binary);
 /* ---- batch mode: many independent scan pairs per launch (BASELINE configs 2 and 5) --------------------- */
 /* n_sources source clouds and n_targets target clouds, each up to `capacity` points; pair p aligns source p to
  * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates).
- * method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params) or MI355_METHOD_NDT_OMP (params = mi355_ndt_params) — the
- * engines GraphBasedSLAM::get_registration builds (graph_based_slam.cpp:101-141).  With NDT_OMP every pair's Newton /
- * More-Thuente state lives in device memory and all pairs advance together, one derivative launch per evaluation for the
- * whole batch and no read-back in between; mi355_batch_align then BLOCKS until the last pair has converged (FAST_GICP only
- * enqueues).  Results: T, converged, iterations, error (= the NDT score), H, trans_probability; fitness as FAST_GICP. */
+ * method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params), MI355_METHOD_NDT_OMP (mi355_ndt_params) or MI355_METHOD_ICP
+ * (mi355_icp_params; the back end's yaml default) — engines GraphBasedSLAM::get_registration builds (graph_based_slam.cpp:80-152;
+ * pclomp's BFGS GICP, MI355_METHOD_GICP, registers pair by pair only).  With NDT_OMP every pair's Newton / More-Thuente state, with
+ * ICP every pair's fit and convergence criteria live in device memory and all pairs advance together - one pass over the sources of
+ * the whole batch per evaluation, nothing read back in between; mi355_batch_align then BLOCKS until the last pair is done (FAST_GICP
+ * only enqueues).  Results: T, converged, iterations, error (NDT: the score; ICP: the mean squared correspondence distance), H and
+ * trans_probability (NDT); fitness as FAST_GICP. */
 mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity);
 void mi355_batch_destroy(mi355_batch* b);
 /* Device-resident inputs: packed float4 [n_clouds][capacity] + host counts.  prefilter (optional) is applied on device
@@ -300,7 +302,10 @@ int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const float* guesse
 int mi355_batch_results(mi355_batch* b, mi355_result* results, double* fitness);
 /* Use only the first n_sources / n_targets slots of the batch (1 <= live <= what mi355_batch_create was given) until the next call:
  * a caller that keeps ONE batch object for requests of varying size (LoopClosureCore, the lanes of mi355_multi) pays nothing for
- * the slots a request does not fill.  Invalidates the sources, targets and results that were set before. */
+ * the slots a request does not fill.  Invalidates the sources, targets and results that were set before.
+ * The launch geometry (blocks per pair, which search kernel) stays that of the slots the batch was CREATED with, and with it the order
+ * of a pair's fp64 partial sums: a request registered on a larger batch object equals the same request on one created for its size to
+ * summation order (poses to ~1e-6 m), not bit for bit; two requests on the same object are bit-equal. */
 int mi355_batch_set_live(mi355_batch* b, int n_sources, int n_targets);
 /* Parity probe of update_correspondences (fast_gicp F3), after mi355_batch_align of a FAST_GICP batch: the correspondences the
  * INCREMENTAL search holds at the final poses (margins: DESIGN 4.3) against a search of every source point from scratch

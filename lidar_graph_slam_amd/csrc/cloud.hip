@@ -1640,7 +1640,9 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
   const int i0 = base + threadIdx.x * 4;
   int v[4];
   uint32_t prev = (i0 > 0 && i0 - 1 < n) ? k[i0 - 1] : kEmptyKey;
-  if (!m.overflow && i0 + 3 < n) {
+  // (16-byte accesses need a 16-byte aligned address: a capacity that is not a multiple of four shifts the rows of the clouds behind the first)
+  const bool vec = i0 + 3 < n && ((o + (size_t)i0) & 3) == 0;
+  if (!m.overflow && vec) {
     // (the thread's four keys in ONE 16-byte load, its four positions in one store: four 4-byte accesses 16 bytes apart were four
     // quarter-used wave instructions each way - 0.56 ms per 1 024-cloud launch for 0.55 GB)
     const uint4 kq = *reinterpret_cast<const uint4*>(k + i0);
@@ -1669,7 +1671,7 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
   int wbase = 0;
   for (int w = 0; w < wave_id(); w++) wbase += wsum[w];
   int run = wbase + incl - s;
-  if (i0 + 3 < n) {
+  if (vec) {
     *reinterpret_cast<int4*>(lo + i0) = make_int4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
   } else {
 #pragma unroll

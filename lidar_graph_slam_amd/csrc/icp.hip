@@ -22,6 +22,7 @@ struct IcpBatch {
   int S = 0, G = 1;
   DevBuf<IcpPairState> state;
   DevBuf<float4> cur;        // [S][pitch] the sources as moved so far (input_transformed)
+  DevBuf<int> corr;          // [S][pitch] the correspondent of the previous iteration: the seed of the next search
   size_t pitch = 0;
   DevBuf<int> tgt_of_src, n_active;
   DevBuf<float> guesses;
@@ -49,8 +50,11 @@ __global__ void k_icp_begin(IcpPairState* __restrict__ st, const float* __restri
 // PCL estimates the correspondences on the cloud as it stands, fits, THEN moves the cloud — so one launch = [move by the previous
 // iteration's fit] + [correspondences and sums]; the first launch moves the input by the guess.  grid = xcd_grid(G, S): the blocks
 // of a pair share an XCD (its target's points and hash table in ONE L2); blocks of finished pairs leave at once.
+// The search is seeded with the previous iteration's correspondent (the cloud moves by millimetres once the first iterations are
+// over): its distance bounds the walk through the voxel hash from the start, the result is the same exact nearest neighbour under
+// the same tie rule (config 5 with ICP: 36 iterations per pair on average, every one of them a from-scratch walk before).
 __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict__ src, size_t spitch, float4* __restrict__ cur, size_t cpitch,
-                                                        const IcpPairState* __restrict__ state, const float4* __restrict__ tpts,
+                                                        int* __restrict__ corr, const IcpPairState* __restrict__ state, const float4* __restrict__ tpts,
                                                         const int* __restrict__ torig, const HashSlot* __restrict__ ttable,
                                                         const GridMeta* __restrict__ tmeta, size_t tcap, size_t tslots,
                                                         const int* __restrict__ tgt_of_src, float max_d2, int G, int S,
@@ -66,6 +70,8 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
   for (int k = 0; k < 12; k++) T[k] = st.Tinc[k];
   const float4* in = st.moved ? cur + (size_t)pair * cpitch : src + (size_t)pair * spitch;
   float4* out = cur + (size_t)pair * cpitch;
+  int* cr = corr + (size_t)pair * cpitch;
+  const bool seeded = st.moved != 0;
   const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
   double acc[kIcpAcc];
 #pragma unroll
@@ -75,9 +81,20 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
     const float4 p = make_float4(transform_row(T, p0.x, p0.y, p0.z), transform_row(T + 4, p0.x, p0.y, p0.z), transform_row(T + 8, p0.x, p0.y, p0.z), p0.w);
     out[i] = p;
     Nearest1 nn{g.orig, INFINITY, -1};
+    float limit = max_d2;
+    if (seeded) {
+      const int j0 = cr[i];
+      if (j0 >= 0) {
+        const float4 q0 = g.pts[j0];
+        const float d0 = dist2f(p.x, p.y, p.z, q0.x, q0.y, q0.z);
+        if (d0 <= max_d2) { nn.best_d2 = d0; nn.best_j = j0; limit = d0; }
+      }
+    }
     // CorrespondenceEstimation::determineCorrespondences keeps a pair iff d2 <= max_dist^2
-    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) grid_search(g, p.x, p.y, p.z, nextafterf(max_d2, INFINITY), nn, 0, 2);
-    if (nn.best_j >= 0 && nn.best_d2 <= max_d2) {
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) grid_search(g, p.x, p.y, p.z, nextafterf(limit, INFINITY), nn, 0, 2);
+    const bool found = nn.best_j >= 0 && nn.best_d2 <= max_d2;
+    cr[i] = found ? nn.best_j : -1;
+    if (found) {
       const float4 q = g.pts[nn.best_j];
       acc[0] += 1.0;
       acc[1] += (double)p.x; acc[2] += (double)p.y; acc[3] += (double)p.z;
@@ -138,6 +155,7 @@ void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, siz
   b.state.ensure((size_t)S);
   b.h_state.ensure((size_t)S);
   b.cur.ensure((size_t)S * b.pitch);
+  b.corr.ensure((size_t)S * b.pitch);
   b.tgt_of_src.ensure((size_t)S);
   b.guesses.ensure((size_t)S * 16);
   b.partials.ensure((size_t)S * b.G * kIcpPartStride);
@@ -161,7 +179,7 @@ void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, siz
     MI_HIP(hipMemsetAsync(b.n_active.p, 0, sizeof(int), s));
     for (int k = 0; k < chunk && it < std::max(p.max_iterations, 1); k++, it++) {
       TimedLaunch tl(KF_CORRESPOND, s);
-      hipLaunchKernelGGL(k_icp_step, grid, dim3(kIcpBlock), 0, s, d_src, spitch, b.cur.p, b.pitch, (const IcpPairState*)b.state.p, (const float4*)tgt.pts.p,
+      hipLaunchKernelGGL(k_icp_step, grid, dim3(kIcpBlock), 0, s, d_src, spitch, b.cur.p, b.pitch, b.corr.p, (const IcpPairState*)b.state.p, (const float4*)tgt.pts.p,
                          (const int*)tgt.orig.p, (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap,
                          (const int*)b.tgt_of_src.p, max_d2, b.G, S, b.partials.p);
       const bool last = k == chunk - 1 || it + 1 >= std::max(p.max_iterations, 1);
