@@ -271,12 +271,13 @@ int mi355_cloud_save_pcd(mi355_cloud* cloud, const char* path, int binary);
 /* ---- batch mode: many independent scan pairs per launch (BASELINE configs 2 and 5) --------------------- */
 /* n_sources source clouds and n_targets target clouds, each up to `capacity` points; pair p aligns source p to
  * target tgt_of_src[p] (graph_based_slam.cpp:311-322 generalised from 1 candidate per tick to all candidates).
- * method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params), MI355_METHOD_NDT_OMP (mi355_ndt_params) or MI355_METHOD_ICP
- * (mi355_icp_params; the back end's yaml default) — engines GraphBasedSLAM::get_registration builds (graph_based_slam.cpp:80-152;
- * pclomp's BFGS GICP, MI355_METHOD_GICP, registers pair by pair only).  With NDT_OMP every pair's Newton / More-Thuente state, with
- * ICP every pair's fit and convergence criteria live in device memory and all pairs advance together - one pass over the sources of
- * the whole batch per evaluation, nothing read back in between; mi355_batch_align then BLOCKS until the last pair is done (FAST_GICP
- * only enqueues).  Results: T, converged, iterations, error (NDT: the score; ICP: the mean squared correspondence distance), H and
+ * method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params), MI355_METHOD_NDT_OMP (mi355_ndt_params), MI355_METHOD_ICP
+ * (mi355_icp_params; the back end's yaml default) or MI355_METHOD_GICP (mi355_gicp_bfgs_params; pclomp's BFGS GICP) — the four engines
+ * GraphBasedSLAM::get_registration builds (graph_based_slam.cpp:80-152).  With NDT_OMP every pair's Newton / More-Thuente state, with
+ * ICP every pair's fit and convergence criteria, with GICP every pair's line search and BFGS update live in device memory and all pairs
+ * advance together - one pass over the sources of the whole batch per evaluation, nothing read back in between; mi355_batch_align then
+ * BLOCKS until the last pair is done (FAST_GICP only enqueues).  Results: T, converged, iterations, error (NDT: the score; ICP: the
+ * mean squared correspondence distance; GICP: the minimiser's last cost, n_inliers the correspondences of the last evaluation), H and
  * trans_probability (NDT); fitness as FAST_GICP. */
 mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity);
 void mi355_batch_destroy(mi355_batch* b);

@@ -25,9 +25,9 @@ typedef struct mi355_loop_closure_params {
   double max_correspondence_distance;     /* yaml:21 -> 2.0 */
   int correspondence_randomness;          /* yaml:23 -> 20 */
   int registration_method;                /* yaml:9 -> "ICP" = MI355_METHOD_ICP (pcl::IterativeClosestPoint with the values of
-                                             graph_based_slam.cpp:145-149); ICP, MI355_METHOD_FAST_GICP (:80-100) and
-                                             MI355_METHOD_NDT_OMP (:101-119) register all candidates in one batch;
-                                             MI355_METHOD_GICP (:120-141, pclomp's BFGS GICP) runs pair by pair */
+                                             graph_based_slam.cpp:145-149); ICP, MI355_METHOD_FAST_GICP (:80-100),
+                                             MI355_METHOD_NDT_OMP (:101-119) and MI355_METHOD_GICP (:120-141, pclomp's BFGS
+                                             GICP) all register the candidates of a lane in one batch */
   double step_size;                       /* yaml:17 -> 0.1 (NDT_OMP) */
   double ndt_resolution;                  /* yaml:18 -> 1.0 (NDT_OMP) */
   double correspondence_distance;         /* yaml:26 -> 2.0 (GICP) */

@@ -157,6 +157,9 @@ struct mi355_batch {
   mi355_icp_params ip;       // method == MI355_METHOD_ICP
   IcpBatch* icp = nullptr;
   int icp_max_src = 0;       // no source holds more points than this (the counts before the prefilter)
+  mi355_gicp_bfgs_params bp;  // method == MI355_METHOD_GICP
+  BfgsBatch* bfgs = nullptr;
+  int bfgs_max_src = 0;
   NdtTargets* ndt = nullptr;  // every target's voxel Gaussians, built by one launch sequence per mi355_batch_set_targets*
   NdtSolver* ndt_solver = nullptr;
   int ndt_max_src = 0;        // no source holds more points than this (the counts before the prefilter: nothing is read back)
@@ -232,6 +235,7 @@ struct mi355_batch {
     if (ndt) ndt_targets_destroy(ndt);
     if (ndt_solver) ndt_solver_destroy(ndt_solver);
     if (icp) icp_batch_destroy(icp);
+    if (bfgs) bfgs_batch_destroy(bfgs);
     parts.clear();
     for (auto& e : pin_free)
       if (e) (void)hipEventDestroy(e);
@@ -1228,9 +1232,9 @@ static int target_part_of(const mi355_batch* b, int t) {
 }
 
 extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity) {
-  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP) || n_sources <= 0 || n_targets <= 0 ||
-      capacity == 0) {
-    if (ctx) ctx->err = "mi355_batch_create: bad argument (batch mode registers with FAST_GICP, NDT_OMP or ICP)";
+  if (!ctx || (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP && method != MI355_METHOD_GICP) ||
+      n_sources <= 0 || n_targets <= 0 || capacity == 0) {
+    if (ctx) ctx->err = "mi355_batch_create: bad argument (methods: FAST_GICP, NDT_OMP, ICP, GICP)";
     return nullptr;
   }
   auto* b = new mi355_batch();
@@ -1242,6 +1246,17 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
   if (params && method == MI355_METHOD_FAST_GICP) b->gp = *(const mi355_gicp_params*)params;
   if (params && method == MI355_METHOD_NDT_OMP) b->np = *(const mi355_ndt_params*)params;
   if (params && method == MI355_METHOD_ICP) b->ip = *(const mi355_icp_params*)params;
+  mi355_gicp_bfgs_default_params(&b->bp);
+  if (params && method == MI355_METHOD_GICP) b->bp = *(const mi355_gicp_bfgs_params*)params;
+  if (method == MI355_METHOD_GICP) {
+    if (b->bp.ransac_iterations != 0 || b->bp.k_correspondences < 1) {
+      ctx->err = "GICP: only setRANSACIterations(0) is built; k_correspondences must be positive";
+      delete b;
+      return nullptr;
+    }
+    b->gp.k_correspondences = b->bp.k_correspondences;  // the covariance path reads gp (as adopt_bfgs_params)
+    b->gp.regularization_method = MI355_REG_PLANE;
+  }
   if (method == MI355_METHOD_ICP && b->ip.ransac_iterations != 0) {
     ctx->err = "ICP: only setRANSACIterations(0) (graph_based_slam.cpp:150) is built";
     delete b;
@@ -1253,7 +1268,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
   const int rc = guarded(ctx, [&] {
     MI_HIP(hipSetDevice(ctx->device));
     b->tgt.alloc(n_targets, capacity);
-    if (method == MI355_METHOD_FAST_GICP) b->tgt.cov.ensure((size_t)n_targets * capacity);  // (the parts' windows cannot grow it later)
+    if (needs_covariances(method)) b->tgt.cov.ensure((size_t)n_targets * capacity);  // (the parts' windows cannot grow it later)
     if (method == MI355_METHOD_NDT_OMP && !(b->np.resolution > 0)) throw ArgError(MI355_EINVAL, "ndt resolution must be positive");
     const int N = batch_part_count(method, n_sources);
     int prio_lo = 0, prio_hi = 0;
@@ -1282,6 +1297,7 @@ extern "C" mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const voi
       b->ndt_solver = ndt_solver_create();
     }
     if (method == MI355_METHOD_ICP) b->icp = icp_batch_create();
+    if (method == MI355_METHOD_GICP) b->bfgs = bfgs_batch_create();
     for (int k = 0; k < 2; k++) {
       auto& sd = b->side[k];
       create_stream(&sd.stream, prio_lo, N > 1 ? tuning().prep_cus : 1.f, false, ctx->compute_units);
@@ -1376,6 +1392,10 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
         MI_HIP(hipEventRecord(pt.knn_done[k], s));
         pt.knn_pending[k] = true;
       }
+      if (b->method == MI355_METHOD_GICP && !targets) {
+        b->bfgs_max_src = 0;
+        for (int i = 0; i < n; i++) b->bfgs_max_src = std::max(b->bfgs_max_src, pt.h_counts[k][(size_t)i]);
+      }
     }
     MI_HIP(hipEventRecord(pt.prep_done[k], s));
     pt.prep_pending[k] = true;
@@ -1383,7 +1403,7 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
   if (side_streams) sd.pending = true;
   if (targets) {
     b->tgt.built = b->method != MI355_METHOD_NDT_OMP;  // (NDT: the targets' point hash is built when a fitness is asked for)
-    b->tgt.has_cov = b->method == MI355_METHOD_FAST_GICP;
+    b->tgt.has_cov = needs_covariances(b->method);
   }
 }
 
@@ -1588,6 +1608,18 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
         icp_batch_results(*b->icp, nullptr, T.data());
         gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
       }
+    } else if (b->method == MI355_METHOD_GICP) {
+      Part& pt = *b->parts[0];
+      batch_wait_side(b, main, 0);
+      batch_wait_side(b, main, 1);
+      // blocks until every pair is done (the line searches and BFGS updates run on the device; the host polls a counter)
+      gicp_set_map(main, pt.gb, tgt_of_src, b->n_targets);
+      bfgs_batch_align(main, *b->bfgs, b->n_sources, pt.src, b->tgt, (size_t)b->bfgs_max_src, tgt_of_src, guesses16, b->bp);
+      if (b->with_fitness) {
+        std::vector<float> T((size_t)b->n_sources * 16);
+        bfgs_batch_results(*b->bfgs, nullptr, T.data());
+        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
+      }
     } else {
       // every part's LM loop on its stream, behind the chains it needs: its own sources' and those of the targets its pairs name
       const bool forked = b->lm_stream(0) != main;
@@ -1676,6 +1708,7 @@ extern "C" int mi355_batch_results(mi355_batch* b, mi355_result* results, double
     if (b->method != MI355_METHOD_FAST_GICP) {
       Part& pt = *b->parts[0];
       if (b->method == MI355_METHOD_NDT_OMP) ndt_solver_results(*b->ndt_solver, results, nullptr);
+      else if (b->method == MI355_METHOD_GICP) bfgs_batch_results(*b->bfgs, results, nullptr);
       else icp_batch_results(*b->icp, results, nullptr);
       if (fitness) gicp_fitness_values(b->stream(), pt.gb, fitness);
     } else {

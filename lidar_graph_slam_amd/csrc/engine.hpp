@@ -222,11 +222,19 @@ void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4*
                const float* guess16, mi355_result* out);
 
 // ---- gicp_bfgs.hip ---------------------------------------------------------------------------------------------
+// pclomp::GeneralizedIterativeClosestPoint for S pairs at once (every pair's minimiser state in HBM, advanced on the device:
+// bfgs_dev.hpp); a registration object is a batch of one.
+struct BfgsBatch;
+BfgsBatch* bfgs_batch_create();
+void bfgs_batch_destroy(BfgsBatch*);
+// src / tgt: built sets with PLANE covariances; pair p registers source p against target tgt_of_src_host[p] (nullptr: p); no source
+// holds more than max_count points.  Blocks until every pair is done.
+void bfgs_batch_align(hipStream_t s, BfgsBatch& b, int S, const CloudSet& src, const CloudSet& tgt, size_t max_count, const int* tgt_of_src_host,
+                      const float* guesses_host, const mi355_gicp_bfgs_params& p);
+void bfgs_batch_results(BfgsBatch& b, mi355_result* out, float* T16_all);
 struct BfgsScratch {
-  DevBuf<int> corr;          // [n] correspondent (sorted target index) of every sorted source point, -1: none in range
-  DevBuf<double> mahal;      // [n][6] fp64 Mahalanobis matrices of the current outer iteration
-  DevBuf<double> partials, sums;
-  PinnedBuf<double> h_sums;
+  BfgsBatch* batch = nullptr;
+  ~BfgsScratch();
 };
 // pclomp::GeneralizedIterativeClosestPoint::align: built source and target sets with PLANE covariances
 void gicp_bfgs_align(hipStream_t s, BfgsScratch& sc, const CloudSet& src, const CloudSet& tgt, size_t n_src, const mi355_gicp_bfgs_params& p,

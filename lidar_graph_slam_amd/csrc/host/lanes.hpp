@@ -58,6 +58,13 @@ inline bool same_params(const mi355_icp_params& a, const mi355_icp_params& b) {
          a.rotation_epsilon == b.rotation_epsilon && a.ransac_iterations == b.ransac_iterations;
 }
 
+inline bool same_params(const mi355_gicp_bfgs_params& a, const mi355_gicp_bfgs_params& b) {
+  return a.max_correspondence_distance == b.max_correspondence_distance && a.max_iterations == b.max_iterations &&
+         a.max_optimizer_iterations == b.max_optimizer_iterations && a.transformation_epsilon == b.transformation_epsilon &&
+         a.rotation_epsilon == b.rotation_epsilon && a.euclidean_fitness_epsilon == b.euclidean_fitness_epsilon &&
+         a.k_correspondences == b.k_correspondences && a.ransac_iterations == b.ransac_iterations;
+}
+
 // One device's share: its context and a batch object that outlives the calls (tens of GB at 512 candidates: allocated once,
 // grown only when a call needs more sources, sub-maps or capacity).
 class Lane {
@@ -75,7 +82,8 @@ class Lane {
   }
   // Register source s against target tgt_of_src[s], all in one batch launch sequence.  The clouds are either device clouds of THIS
   // lane's context (sources / targets) or host views (src_views / tgt_views: uploaded through the batch's pinned staging).
-  // method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params), MI355_METHOD_NDT_OMP (mi355_ndt_params) or MI355_METHOD_ICP (mi355_icp_params).
+  // method: MI355_METHOD_FAST_GICP (params = mi355_gicp_params), MI355_METHOD_NDT_OMP (mi355_ndt_params), MI355_METHOD_ICP (mi355_icp_params)
+  // or MI355_METHOD_GICP (mi355_gicp_bfgs_params).
   void register_batch(int method, const void* params, size_t params_size, const std::vector<mi355_cloud*>& sources, const std::vector<mi355_cloud*>& targets,
                       const std::vector<int>& tgt_of_src, const float* guesses16, const mi355_prefilter_params* source_prefilter,
                       const mi355_prefilter_params* target_prefilter, bool with_fitness, mi355_result* results, double* fitness) {
@@ -111,6 +119,7 @@ class Lane {
     const bool same = batch_ && method == method_ &&
                       (method == MI355_METHOD_FAST_GICP ? same_params(gp_, *(const mi355_gicp_params*)params)
                        : method == MI355_METHOD_NDT_OMP ? same_params(np_, *(const mi355_ndt_params*)params)
+                       : method == MI355_METHOD_GICP    ? same_params(bp_, *(const mi355_gicp_bfgs_params*)params)
                                                         : same_params(ip_, *(const mi355_icp_params*)params));
     if (!same || S > S_ || U > U_ || cap > cap_) {  // grow-only
       if (batch_) mi355_batch_destroy(batch_);
@@ -120,6 +129,7 @@ class Lane {
       method_ = method;
       if (method == MI355_METHOD_FAST_GICP) gp_ = *(const mi355_gicp_params*)params;
       else if (method == MI355_METHOD_NDT_OMP) np_ = *(const mi355_ndt_params*)params;
+      else if (method == MI355_METHOD_GICP) bp_ = *(const mi355_gicp_bfgs_params*)params;
       else ip_ = *(const mi355_icp_params*)params;
       batch_ = mi355_batch_create(ctx().get(), method, params, S_, U_, cap_);
       allocations_++;
@@ -142,6 +152,7 @@ class Lane {
   mi355_gicp_params gp_{};
   mi355_ndt_params np_{};
   mi355_icp_params ip_{};
+  mi355_gicp_bfgs_params bp_{};
   int allocations_ = 0;
 
  public:

@@ -98,30 +98,7 @@ void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows,
   std::vector<mi355_result> r((size_t)S);
   std::vector<double> f((size_t)S);
   const mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
-  if (params_.registration_method == MI355_METHOD_GICP) {
-    // pclomp's BFGS GICP: one candidate at a time as the reference does (:315-321), everything device-resident
-    if (!ls.pairwise) {
-      auto gicp = std::make_shared<GeneralizedIterativeClosestPoint>(ctx);
-      gicp->setMaxCorrespondenceDistance(params_.correspondence_distance);  // :133-139
-      gicp->setMaximumIterations(params_.max_iteration);
-      gicp->setMaximumOptimizerIterations(params_.max_optimizer_iteration);
-      gicp->setTransformationEpsilon(params_.transformation_epsilon);
-      gicp->setEuclideanFitnessEpsilon(params_.euclidean_fitness_epsilon);
-      gicp->setRANSACIterations(params_.ransac_iteration);  // :131,:139
-      ls.pairwise = gicp;
-    }
-    std::vector<DeviceCloud::Ptr> filtered((size_t)U);
-    for (int u = 0; u < U; u++) filtered[(size_t)u] = submap[(size_t)u]->prefiltered(pf);
-    for (int s = 0; s < S; s++) {
-      const size_t u = (size_t)tgt_of_src[(size_t)s];
-      ls.pairwise->setInputTarget(filtered[u]);
-      ls.pairwise->setInputSource(source[(size_t)s]);
-      ls.pairwise->align(identity4());
-      r[(size_t)s] = ls.pairwise->result();
-      r[(size_t)s].n_target = (int)filtered[u]->size();
-      f[(size_t)s] = ls.pairwise->getFitnessScore();
-    }
-  } else {
+  {
     mi355_gicp_params gp{};
     mi355_gicp_default_params(&gp);  // fast_gicp defaults, then the setters of :92-96
     gp.k_correspondences = params_.correspondence_randomness;
@@ -141,9 +118,20 @@ void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows,
     ip.transformation_epsilon = 1e-8;
     ip.euclidean_fitness_epsilon = 1e-6;
     ip.ransac_iterations = 0;
+    mi355_gicp_bfgs_params bp{};
+    mi355_gicp_bfgs_default_params(&bp);  // pclomp's BFGS GICP, :133-139
+    bp.max_correspondence_distance = params_.correspondence_distance;
+    bp.max_iterations = params_.max_iteration;
+    bp.max_optimizer_iterations = params_.max_optimizer_iteration;
+    bp.transformation_epsilon = params_.transformation_epsilon;
+    bp.euclidean_fitness_epsilon = params_.euclidean_fitness_epsilon;
+    bp.ransac_iterations = params_.ransac_iteration;  // :131,:139 (only 0 is built: mi355_loop_closure_create refuses anything else)
     const int method = params_.registration_method;
-    const void* mp = method == MI355_METHOD_NDT_OMP ? (const void*)&np : (method == MI355_METHOD_ICP ? (const void*)&ip : (const void*)&gp);
-    const size_t mps = method == MI355_METHOD_NDT_OMP ? sizeof(np) : (method == MI355_METHOD_ICP ? sizeof(ip) : sizeof(gp));
+    const void* mp = method == MI355_METHOD_NDT_OMP ? (const void*)&np
+                     : method == MI355_METHOD_ICP   ? (const void*)&ip
+                     : method == MI355_METHOD_GICP  ? (const void*)&bp
+                                                    : (const void*)&gp;
+    const size_t mps = method == MI355_METHOD_NDT_OMP ? sizeof(np) : method == MI355_METHOD_ICP ? sizeof(ip) : method == MI355_METHOD_GICP ? sizeof(bp) : sizeof(gp);
     std::vector<mi355_cloud*> th, sh;
     for (auto& c : submap) th.push_back(c->get());
     for (auto& c : source) sh.push_back(c->get());

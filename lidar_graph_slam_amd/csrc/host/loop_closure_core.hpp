@@ -22,10 +22,9 @@ struct LoopClosureParams {  // graph_based_slam.param.yaml:3-23; sub-map leaf ha
   double transformation_epsilon = 0.01;
   double max_correspondence_distance = 2.0;
   int correspondence_randomness = 20;
-  // get_registration (:74-155): "FAST_GICP" and "NDT_OMP" register all candidates in one batch; "ICP" — the yaml's default
-  // (graph_based_slam.param.yaml:9), pcl::IterativeClosestPoint with the values hard-coded at :145-149 — runs pair by pair
-  // on the device-resident clouds (its Horn fit is a 4x4 eigenproblem on the host per iteration), and so does "GICP"
-  // (pclomp's BFGS GICP, :120-141: the quasi-Newton steps are host logic).
+  // get_registration (:74-155): every engine registers all candidates of a lane in ONE batch - "FAST_GICP", "NDT_OMP", "ICP" (the
+  // yaml's default, graph_based_slam.param.yaml:9: pcl::IterativeClosestPoint with the values hard-coded at :145-149) and "GICP"
+  // (pclomp's BFGS GICP, :120-141); the per-pair optimiser states advance on the device.
   int registration_method = MI355_METHOD_ICP;
   double step_size = 0.1;        // yaml:17 (NDT_OMP)
   double ndt_resolution = 1.0;   // yaml:18
@@ -67,7 +66,6 @@ class LoopClosureCore {
     explicit LaneState(int device) : lane(device) {}
     Lane lane;                                // first member: destroyed last (its context outlives everything below)
     std::vector<DeviceCloud::Ptr> key_frame;  // this lane's copies: one upload per key frame and lane, by the first close() that needs it
-    std::shared_ptr<Registration> pairwise;   // registration_method == ICP or GICP: one candidate at a time
   };
   // one lane's share of a close(): rows of `out` (all with a candidate) -> res / fit at the same positions
   void register_rows(LaneState& ls, const std::vector<int>& rows, const std::vector<LoopResult>& out, std::vector<mi355_result>& res, std::vector<double>& fit);

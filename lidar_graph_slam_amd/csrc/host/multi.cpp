@@ -59,8 +59,8 @@ int multi_register(mi355_multi* m, int method, const void* params, int n_sources
   try {
     if (n_sources <= 0 || n_targets <= 0 || !results) throw mi355::Error(MI355_EINVAL, "mi355_multi_batch_register: NULL / empty argument");
     if (with_fitness && !fitness) throw mi355::Error(MI355_EINVAL, "with_fitness needs a fitness array");
-    if (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP)
-      throw mi355::Error(MI355_EINVAL, "batch mode registers with FAST_GICP, NDT_OMP or ICP");
+    if (method != MI355_METHOD_FAST_GICP && method != MI355_METHOD_NDT_OMP && method != MI355_METHOD_ICP && method != MI355_METHOD_GICP)
+      throw mi355::Error(MI355_EINVAL, "batch mode registers with FAST_GICP, NDT_OMP, ICP or GICP");
     if (!tgt_of_src && n_sources != n_targets) throw mi355::Error(MI355_EINVAL, "tgt_of_src required when n_sources != n_targets");
     mi355_gicp_params gp{};
     mi355_gicp_default_params(&gp);
@@ -71,7 +71,13 @@ int multi_register(mi355_multi* m, int method, const void* params, int n_sources
     mi355_icp_params ip{};
     mi355_icp_default_params(&ip);
     if (params && method == MI355_METHOD_ICP) ip = *(const mi355_icp_params*)params;
-    const void* pp = method == MI355_METHOD_FAST_GICP ? (const void*)&gp : (method == MI355_METHOD_NDT_OMP ? (const void*)&np : (const void*)&ip);
+    mi355_gicp_bfgs_params bp{};
+    mi355_gicp_bfgs_default_params(&bp);
+    if (params && method == MI355_METHOD_GICP) bp = *(const mi355_gicp_bfgs_params*)params;
+    const void* pp = method == MI355_METHOD_FAST_GICP ? (const void*)&gp
+                     : method == MI355_METHOD_NDT_OMP ? (const void*)&np
+                     : method == MI355_METHOD_GICP    ? (const void*)&bp
+                                                      : (const void*)&ip;
     std::vector<int> map((size_t)n_sources);
     for (int p = 0; p < n_sources; p++) {
       map[(size_t)p] = tgt_of_src ? tgt_of_src[p] : p;

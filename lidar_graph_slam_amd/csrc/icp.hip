@@ -13,6 +13,9 @@
 #include "icp_fit.hpp"
 #include "primitives.hpp"
 
+#ifndef ICP_SEEDED
+#define ICP_SEEDED 1  // 0: every iteration searches from scratch (A/B: benchmarks/build_variant.sh)
+#endif
 namespace mi355 {
 
 constexpr int kIcpBlock = 256;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
   const float4* in = st.moved ? cur + (size_t)pair * cpitch : src + (size_t)pair * spitch;
   float4* out = cur + (size_t)pair * cpitch;
   int* cr = corr + (size_t)pair * cpitch;
-  const bool seeded = st.moved != 0;
+  const bool seeded = ICP_SEEDED && st.moved != 0;
   const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
   double acc[kIcpAcc];
 #pragma unroll

@@ -20,8 +20,8 @@ class LoopClosure:
                  registration_method="ICP", step_size=0.1, ndt_resolution=1.0, correspondence_distance=2.0, max_optimizer_iteration=20,
                  ransac_iteration=0, device_id=0, device_ids=None):
         self._lib = L.lib()
-        # graph_based_slam.param.yaml:9 defaults to "ICP"; "ICP" / "FAST_GICP" / "NDT_OMP" go through one batch per lane.
-        # "GICP" (pclomp's BFGS GICP) runs pair by pair.
+        # graph_based_slam.param.yaml:9 defaults to "ICP"; every engine ("ICP" / "FAST_GICP" / "NDT_OMP" / "GICP" = pclomp's BFGS GICP)
+        # goes through one batch per lane.
         methods = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP, "ICP": L.METHOD_ICP, "GICP": L.METHOD_GICP}
         if registration_method not in methods:
             raise L.Mi355Error(L.EINVAL, f"registration_method {registration_method!r}: FAST_GICP, NDT_OMP, ICP or GICP")

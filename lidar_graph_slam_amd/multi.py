@@ -22,6 +22,16 @@ def shard_by_target(tgt_of_src, n_lanes: int) -> np.ndarray:
     return out
 
 
+def _method_and_params(method, params):
+    """(method code, parameter struct) of one of the four engines graph_based_slam.cpp:80-152 builds."""
+    makers = {"FAST_GICP": (L.METHOD_FAST_GICP, L.gicp_params), "NDT_OMP": (L.METHOD_NDT_OMP, L.ndt_params), "ICP": (L.METHOD_ICP, L.icp_params),
+              "GICP": (L.METHOD_GICP, L.gicp_bfgs_params)}
+    if method not in makers:
+        raise L.Mi355Error(L.EINVAL, f"registration method {method!r}: FAST_GICP, NDT_OMP, ICP or GICP")
+    code, make = makers[method]
+    return code, make(**params)
+
+
 class MultiDevice:
     def __init__(self, device_ids=(0,)):
         self._lib = L.lib()
@@ -35,8 +45,7 @@ class MultiDevice:
                        target_prefilter=None, with_fitness=True, raw=False, **params):
         """sources / targets: lists of float32 [n,4] (or [n,8] PointXYZI-shaped) clouds.  Returns (list of result dicts - or, raw=True,
         ONE record array over the C structs -, fitness array or None, lane_of_pair)."""
-        m = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP, "ICP": L.METHOD_ICP}[method]
-        p = L.gicp_params(**params) if m == L.METHOD_FAST_GICP else (L.ndt_params(**params) if m == L.METHOD_NDT_OMP else L.icp_params(**params))
+        m, p = _method_and_params(method, params)
         sv = (L.CloudView * len(sources))()
         tv = (L.CloudView * len(targets))()
         keep = []
@@ -75,8 +84,7 @@ class MultiDevice:
                               target_prefilter=None, with_fitness=True, raw=False, **params):
         """The same for DeviceCloud objects that already live on the lanes: source p and its sub-map on the lane
         shard_by_target deals pair p to (nothing crosses PCIe but the results)."""
-        m = {"FAST_GICP": L.METHOD_FAST_GICP, "NDT_OMP": L.METHOD_NDT_OMP, "ICP": L.METHOD_ICP}[method]
-        p = L.gicp_params(**params) if m == L.METHOD_FAST_GICP else (L.ndt_params(**params) if m == L.METHOD_NDT_OMP else L.icp_params(**params))
+        m, p = _method_and_params(method, params)
         sh = (C.c_void_p * len(sources))(*[c.handle for c in sources])
         th = (C.c_void_p * len(targets))(*[c.handle for c in targets])
         t = None if tgt_of_src is None else np.ascontiguousarray(tgt_of_src, dtype=np.int32)

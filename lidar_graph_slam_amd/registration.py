@@ -310,7 +310,7 @@ class GeneralizedIterativeClosestPoint(_Registration):
 
 class BatchRegistration:
     """Many independent scan pairs per launch (BASELINE configs 2 and 5): device-resident clouds, one registration per pair —
-    FAST_GICP (default), NDT_OMP or ICP, three of the four engines GraphBasedSLAM::get_registration offers
+    FAST_GICP (default), NDT_OMP, ICP or GICP (pclomp's BFGS GICP), the four engines GraphBasedSLAM::get_registration offers
     (graph_based_slam.cpp:80-152; ICP is that node's yaml default)."""
 
     def __init__(self, n_sources: int, n_targets: int, capacity: int, ctx: Context | None = None, method: str = "FAST_GICP", **params):
@@ -321,8 +321,10 @@ class BatchRegistration:
             self.params, code = L.ndt_params(**params), L.METHOD_NDT_OMP
         elif method == "ICP":
             self.params, code = L.icp_params(**params), L.METHOD_ICP
+        elif method == "GICP":
+            self.params, code = L.gicp_bfgs_params(**params), L.METHOD_GICP
         else:
-            raise L.Mi355Error(L.EINVAL, f"batch registration method {method!r} (FAST_GICP, NDT_OMP or ICP)")
+            raise L.Mi355Error(L.EINVAL, f"batch registration method {method!r} (FAST_GICP, NDT_OMP, ICP or GICP)")
         self.method = method
         self.n_sources, self.n_targets, self.capacity = int(n_sources), int(n_targets), int(capacity)
         self.handle = self.ctx._lib.mi355_batch_create(self.ctx.handle, code, C.byref(self.params), self.n_sources, self.n_targets,

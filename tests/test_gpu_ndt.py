@@ -148,4 +148,4 @@ def test_batch_rejects_other_methods(R):
     from lidar_graph_slam_amd import _lib as L
 
     with pytest.raises(L.Mi355Error):
-        R.BatchRegistration(2, 2, 128, method="GICP")  # pclomp's BFGS GICP registers pair by pair only
+        R.BatchRegistration(2, 2, 128, method="VGICP")  # the four engines of graph_based_slam.cpp:80-152 and nothing else

@@ -222,3 +222,81 @@ def test_is_converged(hm):
     T[0, 3] = 0
     T[0, 1], T[1, 0] = -0.0025, 0.0025
     assert hm.hm_is_converged(_p(np.ascontiguousarray(T.reshape(16))), 2e-3, 0.01) == 0
+
+
+@pytest.mark.parametrize("cost_id", [0, 1, 2])
+def test_bfgs_machine_is_pcls_bfgs_class(hm, cost_id):
+    """csrc/bfgs_dev.hpp - PCL's BFGS (GSL vector_bfgs2) as a resumable state machine that RETURNS for every cost evaluation, what the
+    device advances for all pairs of a "GICP" batch - against the same algorithm in upstream's functor-calling shape
+    (tests/bfgs_host_ref.hpp, the product's host code until round 4) on three analytic costs (an anisotropic quadratic, a Rosenbrock
+    chain, quadratic + cosines), from random starts and under every inner-iteration budget: the accepted points, the cost, the number
+    of inner iterations and the status are BIT-EQUAL (a value is a pure function of the step evaluated); the machine evaluates less -
+    one (f, gradient) evaluation per distinct step, where the class calls f() and df() apart."""
+    hm.hm_bfgs_minimize.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(100 + cost_id)
+    fewer = 0
+    for trial in range(12):
+        x = rng.normal(0.0, 1.0 if trial < 8 else 4.0, 6)
+        for budget in (1, 2, 5, 20, 300):
+            a, b = np.zeros(10), np.zeros(10)
+            hm.hm_bfgs_minimize(0, cost_id, _p(x), budget, _p(a))
+            hm.hm_bfgs_minimize(1, cost_id, _p(x), budget, _p(b))
+            np.testing.assert_array_equal(a[:9], b[:9], err_msg=f"trial {trial}, budget {budget}")
+            assert b[9] <= a[9]
+            fewer += int(b[9] < a[9])
+            assert a[8] in (0.0, 3.0, -2.0) and (a[7] == budget or a[8] != -2.0)  # Running only when the budget ran out
+    assert fewer > 30
+    # ... and it minimises: the quadratic's minimum is known in closed form
+    if cost_id == 0:
+        H = np.diag(1.0 + 3.0 * np.arange(6))
+        H[0, 5] = H[5, 0] = 0.2
+        c = (1.0 + 3.0 * np.arange(6)) * 0.3 * (np.arange(6) + 1)
+        out = np.zeros(10)
+        hm.hm_bfgs_minimize(1, 0, _p(np.zeros(6)), 300, _p(out))
+        assert np.abs(H @ out[:6] - c).max() < 1e-2  # testGradient(1e-2) is the stopping rule
+
+
+def test_bfgs_pose_helpers(hm):
+    """applyState (fp32 quaternion product of the three axis rotations onto a 4x4), the start vector of a matrix and the value /
+    gradient from the 14 sums of a cost pass (bfgs_dev.hpp) against NumPy in fp64."""
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        x = np.concatenate([rng.normal(0, 2.0, 3), rng.uniform(-1.2, 1.2, 3)])
+        t = np.eye(4, dtype=np.float32)
+        t[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+        t[:3, 3] = rng.normal(0, 5.0, 3).astype(np.float32)
+        t0 = t.copy()
+        hm.hm_bfgs_apply_state(_p(t), _p(x))
+        cr, sr, cp, sp, cy, sy = np.cos(x[3]), np.sin(x[3]), np.cos(x[4]), np.sin(x[4]), np.cos(x[5]), np.sin(x[5])
+        Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+        Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+        Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+        want = t0.astype(np.float64)
+        want[:3, :3] = Rz @ Ry @ Rx @ want[:3, :3]
+        want[:3, 3] += x[:3]
+        np.testing.assert_allclose(t, want, atol=5e-6)
+        # the parameters of a matrix built by applyState from the identity are the parameters it was built from
+        e = np.eye(4, dtype=np.float32)
+        hm.hm_bfgs_apply_state(_p(e), _p(x))
+        back = np.zeros(6)
+        hm.hm_bfgs_x_from_matrix(_p(e), _p(back))
+        np.testing.assert_allclose(back, x, atol=2e-6)
+        # gradient of the rotation part: g[3 + a] = sum_ij dR/d(angle a)_ij * Racc_ji, against central differences of R
+        h = rng.normal(size=14)
+        h[0] = 50.0
+        f = np.zeros(1)
+        g = np.zeros(6)
+        hm.hm_bfgs_cost_from_sums(_p(h), _p(x), _p(f), _p(g))
+        assert f[0] == h[1] / h[0]
+        np.testing.assert_allclose(g[:3], h[2:5] * 2.0 / h[0], rtol=1e-15)
+        Racc = (h[5:14] * 2.0 / h[0]).reshape(3, 3)
+
+        def rot(a):
+            c, s = np.cos(a), np.sin(a)
+            return (np.array([[c[2], -s[2], 0], [s[2], c[2], 0], [0, 0, 1]]) @ np.array([[c[1], 0, s[1]], [0, 1, 0], [-s[1], 0, c[1]]])
+                    @ np.array([[1, 0, 0], [0, c[0], -s[0]], [0, s[0], c[0]]]))
+        for a in range(3):
+            d = np.zeros(3)
+            d[a] = 1e-6
+            dR = (rot(x[3:] + d) - rot(x[3:] - d)) / 2e-6
+            np.testing.assert_allclose(g[3 + a], np.sum(dR * Racc.T), atol=1e-7 * (1 + np.abs(Racc).sum()))
