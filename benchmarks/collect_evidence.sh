@@ -39,6 +39,10 @@ done
 # with fp32 per-point maths: a kilometre out - the far sub-maps of the 64 - the restated reference itself no longer converges, the
 # oracle exactly like the GPU path: DESIGN 5.)
 timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 8 --method NDT_OMP 2> "$O/config5_NDT_OMP.err" | tail -1 > "$O/config5_NDT_OMP.json"
+# (pclomp's BFGS GICP: the same parametrisation; 1 - 2 cm at <= 40 m from the origin, 0.3 m at 80 m in the oracle itself: 4 sub-maps)
+timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 4 --method GICP 2> "$O/config5_GICP.err" | tail -1 > "$O/config5_GICP.json"
+# k_knn_cov_tile's own counters (the STATS instantiation) for profiles/<round>_knn_tile_counters.txt
+MI355_KNN_STATS=1 timeout 600 python bench.py --pairs 512 --steps 1 --warmup 1 --no-cpu-baseline --no-h2d > /dev/null 2> "$O/knn_stats.err"
 # ---- NDT, the front end's default engine: its own bench line and profile
 bash benchmarks/ndt_evidence.sh $R > "$O/ndt_evidence.log" 2>&1
 # ---- the GPU test suite once, for the parity deltas it logs (tests/parity.py -> gpurun_out/parity_deltas.jsonl)

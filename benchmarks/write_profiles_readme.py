@@ -68,7 +68,9 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 | `{R}_ndt_variants.txt` | `benchmarks/ab_ndt.sh`: the NDT derivative kernel with per-lane loads vs the LDS image of a wave's cells, 3 / 4 / 5 waves per SIMD, one-wave blocks, one box |
 | `{R}_fold_ab.txt` | the margin check of settled pairs folded into `k_gicp_linearize` (+ a fix-up search kernel) against the margin-safe bits: exact, not faster, not kept (DESIGN §3) |
 | `{R}_config5_1gpu.json` | BASELINE config 5 at its stated size — 4 096 candidates × 64 sub-maps — through `mi355_multi_batch_register` on ONE GPU with 2 lanes, host views in (pinned staging), results out: `benchmarks/config5.py --candidates 4096 --submaps 64 --multi-lanes 2` |
-| `{R}_config5_FAST_GICP.json`, `{R}_config5_NDT_OMP.json`, `{R}_config5_ICP.json` | the same list through one `BatchRegistration` per rank (`benchmarks/config5.py --method …`), every engine `GraphBasedSLAM::get_registration` has a batch for — ICP is that node's yaml default |
+| `{R}_config5_FAST_GICP.json`, `{R}_config5_ICP.json`, `{R}_config5_NDT_OMP.json`, `{R}_config5_GICP.json` | the same candidate list through one `BatchRegistration` per rank (`benchmarks/config5.py --method …`: uploads + registration + fitness + read-back, the shorter of two runs on one batch object), every engine `GraphBasedSLAM::get_registration` builds — ICP is that node's yaml default.  NDT_OMP on 8 and BFGS GICP on 4 sub-maps near the map origin: both optimise (translation, Euler angles about the ORIGIN) with fp32 per-point maths, and hundreds of metres out the restated reference itself stops converging (DESIGN §3) |
+| `{R}_icp_seed_ab.txt` | ICP's correspondence search seeded with the previous correspondent against searching from scratch, one box: +20 %, identical results |
+| `{R}_knn_tile_counters.txt` | `k_knn_cov_tile`'s own counters (`MI355_KNN_STATS=1`: candidates gathered / ranked per lane, rounds, phase clocks, hand-over) beside the PMC instruction counts: candidates × instructions per candidate, and what was tried against them |
 | `{R}_parity_deltas.txt` | worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4) |
 | `{R}_bench_sor.json` | `python bench.py --sor --pairs 2048`: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2) — a different workload, never the headline; carries the SOR row |
 | `{R}_bench_hostinputs.json` | `python bench.py --host-inputs --pairs 2048`: HOST buffers (pageable memory) handed to the C-ABI every step — the PCIe-inclusive rate, never the headline |
@@ -175,10 +177,10 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
                 + (f", {c5m4['pairs_per_s_including_uploads']:.0f} with {c5m4['lanes']}" if c5m4 else "")
                 + f" — uploads ({c5m['bytes_uploaded_per_call'] / 1e9:.2f} GB per call), prefilter, indexing, registration (early stop, {c5m['mean_iterations']:.1f} iterations on average) and fitness included; "
                 f"{c5m['within_5cm_of_truth']} of {c5m['candidates']} within 5 cm of the truth, median {c5m['median_pose_err_m'] * 100:.1f} cm |\n")
-    for m in ("FAST_GICP", "NDT_OMP", "ICP"):
+    for m in ("FAST_GICP", "ICP", "NDT_OMP", "GICP"):
         c5e = maybe(f"config5_{m}")
         if c5e and "pairs_per_s_registration" in c5e:
-            out += (f"| config 5 at its stated size through one `BatchRegistration`, engine {m} (`{R}_config5_{m}.json`) | {c5e['pairs_per_s_registration']:.0f} pairs/s of registration "
+            out += (f"| config 5 ({c5e['candidates']} candidates × {c5e['submaps']} sub-maps) through one `BatchRegistration`, engine {m} (`{R}_config5_{m}.json`) | {c5e['pairs_per_s_registration']:.0f} pairs/s of registration "
                     f"({c5e['seconds_register_max_over_ranks'] * 1e3:.0f} ms for {c5e['candidates']} candidates, {c5e['mean_iterations']:.1f} iterations on average); "
                     f"{c5e['accepted(fitness<0.3)']} accepted, median {c5e['median_pose_err_m'] * 100:.1f} cm from the truth |\n")
     hb = b.get("h2d_inclusive")

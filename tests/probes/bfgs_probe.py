@@ -2,6 +2,7 @@
 against the oracle after ONE outer iteration and at convergence, on the shifted pairs of tests/test_gpu_gicp_bfgs_batch.py."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -24,3 +25,14 @@ for mi in (1, 64):
         dt, dr = synth.pose_error(reg.getFinalTransformation(), ref["T"])
         print(f"max_iterations {mi} shift {j}: gpu vs oracle {dt:.6f} m {dr:.2e} rad; iterations {reg._result['iterations']} / {ref['iterations']}; "
               f"cost {reg._result['error']:.9g} / {ref['error']:.9g}")
+
+tj = O.transform(t, shifts[1])
+reg = R.GeneralizedIterativeClosestPoint()
+reg.setInputTarget(tj)
+reg.setInputSource(s)
+ts = []
+for _ in range(7):
+    t0 = time.perf_counter()
+    reg.align()
+    ts.append(time.perf_counter() - t0)
+print(f"align of one pair ({len(s)} x {len(tj)} points, {reg._result['iterations']} outer iterations): median {np.median(ts) * 1e3:.2f} ms, min {np.min(ts) * 1e3:.2f} ms")
