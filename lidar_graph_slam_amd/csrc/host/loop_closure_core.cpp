@@ -94,7 +94,7 @@ void LoopClosureCore::register_rows(LaneState& ls, const std::vector<int>& rows,
     source.push_back(on_device(q)->transformed(geometry_pose_to_matrix(key_frames_[(size_t)q].pose)));
     tgt_of_src.push_back((int)(std::find(uniq.begin(), uniq.end(), out[(size_t)i].candidate_id) - uniq.begin()));
   }
-  const int S = (int)source.size(), U = (int)uniq.size();
+  const int S = (int)source.size();
   std::vector<mi355_result> r((size_t)S);
   std::vector<double> f((size_t)S);
   const mi355_prefilter_params pf{0.0, params_.submap_leaf, 0, 0.0};  // voxel_grid_.filter (:311-313): VoxelGrid only
