@@ -91,7 +91,7 @@ def main():
     bench = last_json(os.path.join(SRC, "bench_default.json"))
     pairs = PAIRS = bench["config"]["pairs_per_gpu_per_step"]
     for name in ("bench_default", "bench_hostinputs", "bench_128pairs", "bench_under_trace", "bench_serial_streams", "config5_1gpu", "config5_FAST_GICP", "config5_NDT_OMP",
-                 "config5_ICP", "bench_sor", "bench_1024pairs", "bench_2048pairs"):
+                 "config5_ICP", "config5_GICP", "bench_sor", "bench_1024pairs", "bench_2048pairs"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p):
             with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:
@@ -102,6 +102,9 @@ def main():
         if os.path.exists(oc):
             shutil.copy(oc, os.path.join(DST, f"{R}_{txt}.txt"))
     pmc_sq_table()
+    if os.path.exists(os.path.join(SRC, "knn_stats.err")):  # k_knn_cov_tile's own counters beside the PMC instruction counts
+        import subprocess
+        subprocess.call([sys.executable, os.path.join(ROOT, "benchmarks", "summarize_knn.py"), R])
     for f in ("ndt_batch.json", "ndt_under_trace.json", "kernel_stats_ndt.csv", "pmc_ndt.csv"):  # benchmarks/ndt_evidence.sh
         pth = os.path.join(SRC, "ndt", f)
         if os.path.exists(pth):
