@@ -15,8 +15,8 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O
 # VALU / LDS / wait counters of the hot kernels at the bench's full batch (two passes: 8 SQ slots each), --kernel-trace only
 G1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY"
 G2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR"
-timeout 600 rocprofv3 --kernel-trace --pmc $G1 --output-format csv -d "$O/pmc_sq1" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d > /dev/null 2> "$O/pmc_sq1.err"
-timeout 600 rocprofv3 --kernel-trace --pmc $G2 --output-format csv -d "$O/pmc_sq2" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d > /dev/null 2> "$O/pmc_sq2.err"
+timeout 1200 rocprofv3 --kernel-trace --pmc $G1 --output-format csv -d "$O/pmc_sq1" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d > /dev/null 2> "$O/pmc_sq1.err"
+timeout 1200 rocprofv3 --kernel-trace --pmc $G2 --output-format csv -d "$O/pmc_sq2" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d > /dev/null 2> "$O/pmc_sq2.err"
 # ---- the same workload at other batch sizes / settings (never the headline)
 for P in 128 1024 2048; do
   timeout 600 python bench.py --pairs $P --no-cpu-baseline --no-h2d > "$O/bench_${P}pairs.json" 2> "$O/bench_${P}pairs.err"
@@ -38,7 +38,7 @@ done
 # (NDT_OMP: 4 096 candidates against 8 sub-maps within 160 m of the map origin.  NDT's pose is (translation, Euler angles about the ORIGIN)
 # with fp32 per-point maths: a kilometre out - the far sub-maps of the 64 - the restated reference itself no longer converges, the
 # oracle exactly like the GPU path: DESIGN 5.)
-timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 8 --method NDT_OMP 2> "$O/config5_NDT_OMP.err" | tail -1 > "$O/config5_NDT_OMP.json"
+timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 8 --method NDT_OMP --min-good 0.8 2> "$O/config5_NDT_OMP.err" | tail -1 > "$O/config5_NDT_OMP.json"
 # (pclomp's BFGS GICP: the same parametrisation; 1 - 2 cm at <= 40 m from the origin, 0.3 m at 80 m in the oracle itself: 4 sub-maps)
 timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 4 --method GICP 2> "$O/config5_GICP.err" | tail -1 > "$O/config5_GICP.json"
 # k_knn_cov_tile's own counters (the STATS instantiation) for profiles/<round>_knn_tile_counters.txt
