@@ -116,3 +116,58 @@ def test_multi_entry_takes_gicp(small_pair):
     for p in range(4):
         assert res["converged"][p] and res["iterations"][p] == one["iterations"][p]
         np.testing.assert_allclose(res["T"][p], one["T"][p], rtol=0, atol=2e-6)
+
+
+def test_batch_gicp_on_loop_closure_pairs_lands_where_the_oracle_lands():
+    """BASELINE config 5's shape with "GICP" (graph_based_slam.cpp:120-141,297-322): candidates at wrong graph poses against 0.5 m
+    voxel-filtered five-key-frame sub-maps, identity guess.  pclomp's GICP optimises (translation, Euler angles about the map ORIGIN):
+    near the origin it recovers the truth to centimetres, tens of metres out it stops short - the restated reference (the oracle)
+    exactly like the batch, which is what this test pins (benchmarks/config5.py --method GICP therefore runs on sub-maps near the
+    origin)."""
+    from lidar_graph_slam_amd import loop_batch
+    from lidar_graph_slam_amd.registration import BatchRegistration
+
+    S = 3  # sub-maps at x = 0, 20, 40 m
+    length = 20.0 * S + 20.0
+
+    def place(c, T):
+        o = c.copy()
+        o[:, :3] = (c[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+        return o
+
+    pre = lambda r: O.voxel_grid(O.distance_filter(r, 1.0), 0.2)[0]  # noqa: E731
+    sub_pose = lambda s: synth.se3(20.0 * s, 0.0, 0.0)  # noqa: E731
+    sources, submaps, expected = [], [], []
+    for s in range(S):
+        true_off = synth.random_perturbation(np.random.default_rng(1000 + s * 64), 1.0, 2.0)
+        wrong = synth.random_perturbation(np.random.default_rng(5 + s), 1.5, 4.0)
+        cand = pre(synth.cast_job((length, sub_pose(s) @ true_off, 9000 + s * 64, 512, 30.0)))
+        kf = [pre(synth.cast_job((length, sub_pose(s) @ synth.se3(1.0 * j, 0, 0), 500 + 10 * s + j, 512, 30.0))) for j in range(-2, 3)]
+        submaps.append(np.concatenate([place(kf[j + 2], sub_pose(s) @ synth.se3(1.0 * j, 0, 0)) for j in range(-2, 3)], axis=0))
+        true_pose = sub_pose(s) @ true_off
+        graph_pose = true_pose @ wrong
+        sources.append(place(cand, graph_pose))
+        expected.append(true_pose @ np.linalg.inv(graph_pose))
+    cap = max(max(len(c) for c in sources), max(len(c) for c in submaps))
+    pk = lambda cl: (np.stack([np.pad(c, ((0, cap - len(c)), (0, 0))) for c in cl]), np.array([len(c) for c in cl], np.int32))  # noqa: E731
+    kw = dict(max_iterations=100, max_correspondence_distance=2.0, max_optimizer_iterations=20, transformation_epsilon=0.01)  # yaml:11-12,24-29
+    b = BatchRegistration(S, S, cap, method="GICP", euclidean_fitness_epsilon=1e-8, **kw)
+    b.set_targets(*pk(submaps), loop_batch.voxel_prefilter(0.5))
+    b.set_sources(*pk(sources))
+    b.align(list(range(S)), with_fitness=True)
+    res, fit = b.results(with_fitness=True)
+    b.close()
+    for s in range(S):
+        t = O.voxel_grid(submaps[s], 0.5)[0]
+        ref = O.gicp_bfgs_align(sources[s], t, O.gicp_bfgs_params(**kw))
+        assert res[s]["n_target"] == len(t) and res[s]["converged"] == ref["converged"]
+        dt, dr = synth.pose_error(res[s]["T"], ref["T"])
+        et, er = synth.pose_error(res[s]["T"], expected[s])
+        ot, orr = synth.pose_error(ref["T"], expected[s])
+        print(f"sub-map at x = {20 * s} m: GPU vs oracle {dt:.4f} m / {dr:.1e} rad, iterations {res[s]['iterations']} / {ref['iterations']}; vs the truth GPU {et:.3f} m, oracle {ot:.3f} m")
+        # two correct executions of this engine stop inside a band of each other (tests/test_gpu_gicp_bfgs.py); what is asserted is that
+        # the GPU is as good as the oracle against the truth, not worse by more than that band (which widens with the distance from the
+        # origin as the engine's own error does: 40 m out both stop ~6 cm from the truth and from each other, an outer iteration apart)
+        assert abs(res[s]["iterations"] - ref["iterations"]) <= 2 and dt <= 0.04 + 0.5 * ot and dr <= 4e-3, (s, dt, dr, ot)
+        assert et <= ot + 0.04 + 0.5 * ot, (s, et, ot)
+        np.testing.assert_allclose(fit[s], O.fitness(sources[s], t, res[s]["T"]), rtol=1e-6)
