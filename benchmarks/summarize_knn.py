@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", R, "knn_stats.err")
 lines = [l.strip() for l in open(src) if l.startswith("[mi355]")]
-blk = lines[-5:]  # the last covariance launch of the run: five lines per launch
+blk = lines[-6:]  # the last covariance launch of the run: six lines per launch
 valu = None
 DST = os.environ.get("EVIDENCE_DST") or os.path.join(ROOT, "profiles")  # (as summarize_evidence.py: on the GPU box a directory under gpurun_out/)
 pmc = os.path.join(DST, f"{R}_pmc_valu.csv")

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
                                                      const int* __restrict__ tile_order = nullptr, unsigned long long* __restrict__ stats = nullptr) {
   int st_tiles = 0, st_segs = 0, st_rounds = 0, st_gathers = 0, st_cands = 0, st_build = 0, st_rank = 0, st_direct = 0;  // STATS only
   int st_fb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // STATS only: lanes handed over, by reason
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // STATS only: shader clocks per phase of the tile loop
+  long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // STATS only: shader clocks per phase of the tile loop (8, 9: the cell lookup / the rest of a gather's set-up apart)
   auto phase = [&](int w) {
     if constexpr (STATS) {
       const long long t = clock64();
@@ -800,7 +800,9 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
         if (Rw > R) {
           if constexpr (STATS) st_gathers++;
           const TileBox nb = grow(bb, Rn);
+          phase(9);
           const TileCells cells = tile_cells(g, nb, kTileMaxLoad);
+          phase(8);
           const int n_new = cells.ok ? tile_gather<KNN_GATHER_DEPTH>(g, cells, nb, ob, has_old, cand, n_ord, kTileMaxCand, gscratch) : -1;
           if constexpr (STATS) { if (!cells.ok) t_fail_cells++; else if (n_new < 0) t_fail_list++; }
           if (n_new < 0) {  // over a budget: split the segment if nothing has been gathered yet, else hand the open lanes over
@@ -1054,6 +1056,7 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
       atomicAdd(&stats[4], (unsigned long long)st_cands); atomicAdd(&stats[5], (unsigned long long)st_build);
       atomicAdd(&stats[6], (unsigned long long)st_rank); atomicAdd(&stats[7], (unsigned long long)st_direct);
       for (int w = 0; w < 8; w++) atomicAdd(&stats[8 + w], (unsigned long long)ph[w]);
+      atomicAdd(&stats[32], (unsigned long long)ph[8]); atomicAdd(&stats[33], (unsigned long long)ph[9]);
       for (int w = 0; w < 4; w++) atomicAdd(&stats[28 + w], (unsigned long long)st_fb[w]);
       atomicAdd(&stats[15], 0ull);
     }
@@ -1331,13 +1334,13 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
   // of a cloud finish together, so more of them shorten the tail each cloud leaves on its XCD).  MI355_TILE_WAVES < 0: that many per cloud.
   const int Gt = tn.tile_waves < 0 ? -tn.tile_waves : max(min(tn.tile_waves / max(set.B, 1), div_up((long)set.cap, kWave)), 16);
   if (tn.knn_stats && !SOR) {
-    set.knn_stats.ensure(32);
-    MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 32 * sizeof(unsigned long long), s));
+    set.knn_stats.ensure(40);
+    MI_HIP(hipMemsetAsync(set.knn_stats.p, 0, 40 * sizeof(unsigned long long), s));
     hipLaunchKernelGGL((k_knn_cov_tile<K, SOR, true>), dim3(xcd_grid(Gt, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                        mean_dist, set.fbq.p, set.fbhint.p, set.fbn.p, set.fbn.p + set.B, set.cap, set.slots_cap, k, method, Gt, set.B, tn.tile_rscale,
                        tile_order ? tn.tile_gather : 1.0f, tile_order, set.knn_stats.p);
     MI_HIP(hipStreamSynchronize(s));
-    unsigned long long st[32];
+    unsigned long long st[40];
     MI_HIP(hipMemcpy(st, set.knn_stats.p, sizeof(st), hipMemcpyDeviceToHost));
     const double tiles = (double)std::max(st[0], 1ull);
     fprintf(stderr, "[mi355] k-NN tiles by segments run (1..7+): %llu %llu %llu %llu %llu %llu %llu; split tiles whose lists fit one list together: %llu, candidates of split tiles %.0f each; "
@@ -1353,6 +1356,8 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
               100 * st[9] / all, st[10] / tiles, 100 * st[10] / all, st[11] / tiles, 100 * st[11] / all, st[12] / tiles, 100 * st[12] / all, st[13] / tiles, 100 * st[13] / all,
               st[14] / tiles, 100 * st[14] / all, st[15] / tiles, 100 * st[15] / all);
     }
+    fprintf(stderr, "[mi355] k-NN gather, shader clocks per tile: cell lookup (64 hash probes) %.0f, before it (radii, box) %.0f, the rest (flat sequence, loads, compaction) %.0f\n",
+            st[32] / tiles, st[33] / tiles, st[10] / tiles);
     fprintf(stderr, "[mi355] k-NN sub-tile lists per tile: %.2f segments, %.2f rounds, %.2f gathers, %.0f candidates gathered, %.1f build trips (x 4 x 16 box tests), "
             "%.1f rank steps per lane (+ %.1f direct)\n", st[1] / tiles, st[2] / tiles, st[3] / tiles, st[4] / tiles, st[5] / tiles, st[6] / tiles, st[7] / tiles);
   } else {
