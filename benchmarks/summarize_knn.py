@@ -25,8 +25,10 @@ out = ["k_knn_cov_tile<20>: candidates per lane and instructions per candidate (
        "Reading: a tile (64 queries, one wave) gathers ~300 candidates into LDS in ~1.8 gathers, files them into four 16-lane sub-lists and every lane",
        "ranks ~185 of them (+ ~12 straight from the tile list in single-sub-tile segments) - 0.6 of the tile's candidates - through the (k + 2)-deep",
        "v_med3 network: 31 VALU instructions per candidate and lane (5 distance, 3 key, 22 + 1 network), ~2.1 rounds per tile.",
-       "Shares of a tile's shader clocks: rank ~31 %, gather ~29 % (a chain of dependent loads: 64 hash probes -> cell ranges -> points), pair +",
-       "covariance ~16 %, fetch ~10 %, sub-list build ~8 %, round end ~5 %.  ~0.55 % of the points are handed to k_knn_hard.", ""]
+       "Shares of a tile's ~133 k shader clocks (the 'gather' of the phase line + the two parts timed apart on the next line): rank ~31 %,",
+       "gather ~31 % - the 64 hash probes of its cell lookup alone 12 % (one dependent random 16-byte load per lane, 1.8 times per tile), radii and",
+       "boxes 2 %, flat sequence + point loads + compaction 16 % -, pair + covariance ~16 %, fetch ~10 %, sub-list build ~8 %, round end ~3 %.",
+       "~0.55 % of the points are handed to k_knn_hard.", ""]
 if valu:
     w, wc = float(valu["SQ_WAVES"]), float(valu["SQ_WAVE_CYCLES"])
     out += [f"PMC (profiles/{R}_pmc_valu.csv, 2 048 clouds per launch): SQ_INSTS_VALU {float(valu['SQ_INSTS_VALU']):.4g} per launch over {w:.0f} waves;",
@@ -42,6 +44,11 @@ out += ["What was tried against candidates x instructions (round 5: analysis and
         "  * 8-lane sub-tiles: 10.9 + 1.8 ms against 10.7 + 1.7 ms per 1 024-cloud launch (r03: the trip count of a wave is its longest sub-list);",
         "  * a third wave per SIMD (needs <= 13.3 KB of LDS and <= 168 VGPRs per wave; today 19 KB and 199): r03 measured 8.0 against 8.3 ms with",
         "    576-entry lists but 0.66 - 2.5 % handed over - the same sum.",
+        "  * (round 5, built and measured, one box) the cell lookups of the NEXT gather issued ahead - after a gather the first hash probe of every",
+        "    cell of the box grown to 1.2 - 2.0 x its radius goes out and comes back under the build + rank; a later round that asks for no more",
+        "    finishes the lookups it finds waiting and gathers that box: exact (51 k-NN / covariance parity tests green), 0.37 of the 0.78 later",
+        "    gathers per tile found their lookups waiting, the cell-lookup clocks fell 15.5 k -> 13.3 k per tile, but the larger box loads and",
+        "    tests more points (the rest of the gather 21.4 k -> 28.3 k): k_knn_cov_tile 50.8 -> 52.3 ms per step at every scale tried - removed.",
         "The product candidates x instructions did not fall this round (DESIGN 8)."]
 dst = os.path.join(DST, f"{R}_knn_tile_counters.txt")
 open(dst, "w").write("\n".join(out) + "\n")
