@@ -49,6 +49,11 @@ out += ["What was tried against candidates x instructions (round 5: analysis and
         "    finishes the lookups it finds waiting and gathers that box: exact (51 k-NN / covariance parity tests green), 0.37 of the 0.78 later",
         "    gathers per tile found their lookups waiting, the cell-lookup clocks fell 15.5 k -> 13.3 k per tile, but the larger box loads and",
         "    tests more points (the rest of the gather 21.4 k -> 28.3 k): k_knn_cov_tile 50.8 -> 52.3 ms per step at every scale tried - removed.",
+        "  * (round 5, built and measured, one box) the cell lookup of the NEXT TILE's first gather issued before the covariance epilogue of the",
+        "    current one (same box, no extra points; 0.94 of the tiles found their lookups waiting): the lookup clocks fell 15.9 k -> 11.7 k per",
+        "    tile and came back in the phases around them (build + 2.5 k, epilogue + 2.4 k, rank + 2 k: 134.6 k against 134.8 k in all) - with two",
+        "    waves filling 0.87 of the SIMD's issue slots a latency that is hidden for one wave is issue time taken from the other; the bench",
+        "    line 148.3 / 146.9 ms per step with it against 145.9 / 146.1 without - removed.  The kernel is bound by its instruction count.",
         "The product candidates x instructions did not fall this round (DESIGN 8)."]
 dst = os.path.join(DST, f"{R}_knn_tile_counters.txt")
 open(dst, "w").write("\n".join(out) + "\n")
