@@ -54,6 +54,10 @@ out += ["What was tried against candidates x instructions (round 5: analysis and
         "    tile and came back in the phases around them (build + 2.5 k, epilogue + 2.4 k, rank + 2 k: 134.6 k against 134.8 k in all) - with two",
         "    waves filling 0.87 of the SIMD's issue slots a latency that is hidden for one wave is issue time taken from the other; the bench",
         "    line 148.3 / 146.9 ms per step with it against 145.9 / 146.1 without - removed.  The kernel is bound by its instruction count.",
+        "  * (round 5, kept) k == K reads the k-th key from its register instead of through a runtime index (K + 2 selects per use, ~150",
+        "    instructions per tile): 145.8 -> 145.0 ms per step over four alternations in one box - made AFTER the evidence of this directory was",
+        "    collected (0.6 %, inside its box-to-box spread).  Splitting the rank loop into steps all lanes have entries for (no end-of-list",
+        "    test: 2 of 31 instructions) and the rest: +0.9 ms; folding k into the covariance epilogue: +29 VGPRs, +-0 - neither kept.",
         "The product candidates x instructions did not fall this round (DESIGN 8)."]
 dst = os.path.join(DST, f"{R}_knn_tile_counters.txt")
 open(dst, "w").write("\n".join(out) + "\n")

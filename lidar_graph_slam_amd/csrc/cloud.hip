@@ -936,7 +936,10 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
         phase(4);
         // ---- which lanes are done?  every point within rsafe of a query of the sub-tile has been seen by its lanes
         const float rsafe = redo ? 0.f : rs * 0.9999f - eps;
-        const uint32_t kk = keys.at(k - 1);
+        // (k == K - the reference's k = 20 - reads the register: a runtime index is K + 2 selects per use, ~150 instructions per tile;
+        // 145.8 -> 145.0 ms per 4 096-pair step over four alternations in one box.  Folding k into the covariance epilogue as well
+        // - the "t < k" guards, the division by k - costs 29 VGPRs and gains nothing: not kept.)
+        const uint32_t kk = (k == K) ? keys.v[K - 1] : keys.at(k - 1);
         const bool full = kk != SmallestKeys<K + 2>::kEmpty;
         const float ub = __uint_as_float(kk | kOrdMask);  // >= the exact k-th squared distance
         if (act && full) hint = sqrtf(ub) * 1.001f + 2.f * eps;
@@ -979,12 +982,13 @@ __global__ __launch_bounds__(64, KNN_TILE_WAVES_PER_SIMD) void k_knn_cov_tile(co
       if constexpr (STATS) { if (!split) t_cands += n_ord; }
       if (!split) {
         // closed lanes: exact unless truncation could have swapped the k-th and (k+1)-th candidates (or they tie exactly)
-        const uint32_t kk = keys.at(k - 1), kn = keys.at(k);
+        const uint32_t kk = (k == K) ? keys.v[K - 1] : keys.at(k - 1), kn = (k == K) ? keys.v[K] : keys.at(k);
         const uint32_t tk = kk >> kOrdBits;
         const bool closed = act && !open && !fb;
         const bool clear = tk < (kn >> kOrdBits);
         // exactly two candidates share the k-th truncated distance: rank the pair exactly (ties: lower caller index)
-        const bool pair = closed && !clear && tk < (keys.at(k + 1) >> kOrdBits) && (k < 2 || (keys.at(k - 2) >> kOrdBits) < tk);
+        const uint32_t kn2 = (k == K) ? keys.v[K + 1] : keys.at(k + 1), kp = (k == K) ? keys.v[K >= 2 ? K - 2 : 0] : keys.at(k - 2);
+        const bool pair = closed && !clear && tk < (kn2 >> kOrdBits) && (k < 2 || (kp >> kOrdBits) < tk);
         if (pair) {
           const float4 a = cand[kk & kOrdMask], b = cand[kn & kOrdMask];
           const float da = dist2f(q.x, q.y, q.z, a.x, a.y, a.z), db = dist2f(q.x, q.y, q.z, b.x, b.y, b.z);
