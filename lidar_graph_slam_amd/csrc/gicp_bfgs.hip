@@ -232,25 +232,21 @@ __global__ __launch_bounds__(64) void k_bfgs_advance(BfgsPairState* __restrict__
   st.evaluations++;
   st.n_inliers = (int)h[0];
   st.searched = 1;
-  bool more;
   if (st.need_corr && h[0] < 4.0) {
     // "Need at least 4 points to estimate a transform": computeTransformation's loop is left, not converged (the first evaluation of
     // an outer iteration also tells how many correspondences there are)
     st.active = 0;
-    more = true;  // (nothing below applies)
-  } else {
-    st.need_corr = 0;
-    double f, g[6];
-    bfgs_cost_from_sums(h, st.m.req_x, &f, g);
-    BfgsParams P;
-    more = bfgs_feed(st.m, f, g, c.max_optimizer_iterations, P);
-    if (more) {
-#pragma unroll
-      for (int k = 0; k < 16; k++) st.T_eval[k] = st.guess[k];
-      bfgs_apply_state(st.T_eval, st.m.req_x);
-    }
+    return;
   }
-  if (!more) {
+  st.need_corr = 0;
+  double f, g[6];
+  bfgs_cost_from_sums(h, st.m.req_x, &f, g);
+  const BfgsParams P;
+  if (bfgs_feed(st.m, f, g, c.max_optimizer_iterations, P)) {  // the search wants the cost at another point: the next round evaluates it
+#pragma unroll
+    for (int k = 0; k < 16; k++) st.T_eval[k] = st.guess[k];
+    bfgs_apply_state(st.T_eval, st.m.req_x);
+  } else {
     // the inner loop is over: estimateRigidTransformationBFGS accepts NoProgress, Success and "out of optimizer iterations"
     const int result = st.m.result;
     if (!(result == BFGS_NOPROGRESS || result == BFGS_SUCCESS || st.m.inner == c.max_optimizer_iterations)) {
