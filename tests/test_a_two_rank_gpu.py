@@ -53,3 +53,21 @@ def test_rccl_with_two_ranks_needs_two_devices():
         assert "RCCL_OK world=2" in r.stdout
     else:
         assert "Duplicate GPU detected" in r.stderr + r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_py_runs_as_two_ranks():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU) - here both ranks on device 0 with gloo
+    for the barrier and the max-over-ranks reduce: the base pairs are cast once and shared through /dev/shm, every rank times its own
+    batches, rank 0 prints ONE line whose value is the whole job's (both ranks' pairs over the slower rank's time)."""
+    env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29300 + (os.getpid() % 250)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "bench.py", "--gpus", "2", "--pairs", "128", "--steps", "2", "--warmup", "1", "--bases", "2", "--no-h2d", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["config"]["pairs_per_gpu_per_step"] == 128
+    assert abs(d["value"] - 2 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]  # whole-job pairs over the max-over-ranks step time
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"mi355_bench_bases_{port}_")]  # the shared file is gone again
