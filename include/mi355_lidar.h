@@ -318,6 +318,12 @@ int mi355_batch_verify_correspondences(mi355_batch* b, long long* n_checked, lon
  * knn_points[2] / knn_handed_over[2] (0 = targets, 1 = sources): the points of each side's last covariance launch and how many
  * of them the wave-cooperative tile search handed over to the one-wave-per-query kernel. */
 int mi355_batch_diagnostics(mi355_batch* b, int* first_converged, long long* knn_points, long long* knn_handed_over);
+/* Parity probe of the batched preparation chain (prefilter -> voxel hash -> k-NN covariances), after mi355_batch_set_targets* /
+ * _sources*: cloud `index` of the targets (targets != 0) or sources AS THE BATCH REGISTERS IT - the points that survived the prefilter, in
+ * the prefilter's output order (pcl::VoxelGrid: ascending voxel index), and, for the engines that use them (FAST_GICP, GICP), their
+ * regularised covariances (6 floats xx xy xz yy yz zz per point; out_cov6 may be NULL).  Synchronises the batch.  *n = the point count;
+ * nothing is copied when it exceeds `capacity` (MI355_ECAPACITY).  Not available for the NDT targets (they are kept as voxel Gaussians). */
+int mi355_batch_get_cloud(mi355_batch* b, int targets, int index, float* out_xyzi, float* out_cov6, size_t capacity, size_t* n);
 /* Per-kernel-family timing for the benchmark's roofline block.  With timing enabled the library records HIP events on the
  * launching stream around every launch of the hot kernels (k_knn_cov_tile, k_gicp_correspond, k_gicp_linearize, ...; short
  * kernels that always run back to back, e.g. the 12 launches of one radix sort, share one bracket).

@@ -132,7 +132,7 @@ EXPORTS = [
     "mi355_batch_set_targets_clouds", "mi355_batch_set_sources_clouds", "mi355_batch_set_targets_views", "mi355_batch_set_sources_views",
     "mi355_cloud_from_pointcloud2", "mi355_cloud_to_pointcloud2", "mi355_pcd_write", "mi355_cloud_save_pcd",
     "mi355_batch_create", "mi355_batch_destroy", "mi355_batch_set_targets_dev", "mi355_batch_set_sources_dev", "mi355_batch_set_targets",
-    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams", "mi355_batch_set_live", "mi355_batch_verify_correspondences", "mi355_batch_diagnostics",
+    "mi355_batch_set_sources", "mi355_batch_set_stream", "mi355_batch_align", "mi355_batch_results", "mi355_batch_set_timing", "mi355_batch_kernel_times", "mi355_batch_set_side_streams", "mi355_batch_set_live", "mi355_batch_verify_correspondences", "mi355_batch_diagnostics", "mi355_batch_get_cloud",
     "mi355_multi_create", "mi355_multi_destroy", "mi355_multi_last_error", "mi355_multi_device_count", "mi355_multi_context",
     "mi355_multi_shard_by_target", "mi355_multi_batch_register", "mi355_multi_batch_register_clouds", "mi355_multi_lane_allocations",
 ]
@@ -309,6 +309,7 @@ def lib():
         L.mi355_batch_set_live.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mi355_batch_verify_correspondences.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.mi355_batch_diagnostics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mi355_batch_get_cloud.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355_multi_create.restype = C.c_void_p
         L.mi355_multi_create.argtypes = [C.c_void_p, C.c_int]
         L.mi355_multi_destroy.argtypes = [C.c_void_p]

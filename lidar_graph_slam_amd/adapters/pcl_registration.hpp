@@ -167,6 +167,9 @@ class FastGICP : public RegistrationBase<MI355_METHOD_FAST_GICP, mi355_gicp_para
   void setNumThreads(int n) { p_.num_threads = n; dirty_ = true; }
 };
 
+// the values of pclomp::NeighborSearchMethod (ndt_omp.h), for callers that do not have ndt_omp's header at hand
+enum NeighborSearchMethod { KDTREE = 0, DIRECT26 = 1, DIRECT7 = 2, DIRECT1 = 3 };
+
 // replaces `new pclomp::NormalDistributionsTransform<PointType, PointType>` (lidar_scan_matcher.cpp:56-57)
 class NormalDistributionsTransform : public RegistrationBase<MI355_METHOD_NDT_OMP, mi355_ndt_params> {
  public:
@@ -176,7 +179,12 @@ class NormalDistributionsTransform : public RegistrationBase<MI355_METHOD_NDT_OM
   void setStepSize(double s) { p_.step_size = s; dirty_ = true; }
   void setResolution(float r) { p_.resolution = r; dirty_ = true; }
   void setMaximumIterations(int n) { p_.max_iterations = n; max_iterations_ = n; dirty_ = true; }
-  template <typename T> void setNeighborhoodSearchMethod(T) {}  // DIRECT7 is the only mode (lidar_scan_matcher.cpp:69)
+  // pclomp::NeighborSearchMethod is {KDTREE, DIRECT26, DIRECT7, DIRECT1}; the node asks for DIRECT7 (lidar_scan_matcher.cpp:69) and
+  // DIRECT7 is the only search the device path has: anything else is refused, never silently replaced (host/pcl_like.hpp does the same)
+  template <typename T> void setNeighborhoodSearchMethod(T method) {
+    if (static_cast<int>(method) != static_cast<int>(DIRECT7))
+      throw std::invalid_argument("mi355::NDT: only pclomp::DIRECT7 (lidar_scan_matcher.cpp:69) is built");
+  }
   void setNumThreads(int n) { p_.num_threads = n; dirty_ = true; }
   double getTransformationProbability() const { return trans_probability_; }
  protected:

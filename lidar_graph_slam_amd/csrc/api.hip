@@ -1760,6 +1760,42 @@ extern "C" int mi355_batch_diagnostics(mi355_batch* b, int* first_converged, lon
   });
 }
 
+extern "C" int mi355_batch_get_cloud(mi355_batch* b, int targets, int index, float* out_xyzi, float* out_cov6, size_t capacity, size_t* n) {
+  if (!b || !n) return MI355_EINVAL;
+  return guarded(b->ctx, [&] {
+    if (index < 0 || index >= (targets ? b->n_targets : b->n_sources)) throw ArgError(MI355_EINVAL, "mi355_batch_get_cloud: index");
+    if (!(targets ? b->has_tgt : b->has_src)) throw ArgError(MI355_ESTATE, "mi355_batch_get_cloud: after mi355_batch_set_targets* / _sources*");
+    MI_HIP(hipSetDevice(b->ctx->device));
+    b->quiesce();
+    for (auto& ptp : b->parts) {
+      Part& pt = *ptp;
+      const int c0 = targets ? pt.t0 : pt.s0, nc = targets ? pt.nt : pt.ns;
+      if (index < c0 || index >= c0 + nc) continue;
+      const CloudSet& set = targets ? pt.tgt : pt.src;
+      if (!set.built) throw ArgError(MI355_ESTATE, "mi355_batch_get_cloud: this side holds no indexed clouds (NDT targets are voxel Gaussians)");
+      const int c = index - c0;
+      int cnt = 0;
+      MI_HIP(hipMemcpy(&cnt, set.count.p + c, sizeof(int), hipMemcpyDeviceToHost));
+      *n = (size_t)cnt;
+      if ((size_t)cnt > capacity) throw ArgError(MI355_ECAPACITY, "mi355_batch_get_cloud: capacity");
+      if (cnt == 0 || !out_xyzi) return;
+      std::vector<float4> p((size_t)cnt);
+      std::vector<int> orig((size_t)cnt);
+      MI_HIP(hipMemcpy(p.data(), set.pts.p + (size_t)c * set.cap, sizeof(float4) * (size_t)cnt, hipMemcpyDeviceToHost));
+      MI_HIP(hipMemcpy(orig.data(), set.orig.p + (size_t)c * set.cap, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; i++) memcpy(out_xyzi + 4 * (size_t)orig[(size_t)i], &p[(size_t)i], sizeof(float4));
+      if (out_cov6) {
+        if (!set.has_cov || !set.cov.p) throw ArgError(MI355_ESTATE, "mi355_batch_get_cloud: this engine computes no covariances");
+        std::vector<Cov6> cv((size_t)cnt);
+        MI_HIP(hipMemcpy(cv.data(), set.cov.p + (size_t)c * set.cap, sizeof(Cov6) * (size_t)cnt, hipMemcpyDeviceToHost));
+        for (int i = 0; i < cnt; i++) memcpy(out_cov6 + 6 * (size_t)orig[(size_t)i], &cv[(size_t)i], sizeof(Cov6));
+      }
+      return;
+    }
+    throw ArgError(MI355_EINVAL, "mi355_batch_get_cloud: index outside every part");
+  });
+}
+
 extern "C" int mi355_batch_set_side_streams(mi355_batch* b, int mode) {
   if (!b || mode < -1 || mode > 1) return MI355_EINVAL;
   return guarded(b->ctx, [&] {

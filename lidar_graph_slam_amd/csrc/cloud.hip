@@ -137,10 +137,10 @@ __global__ void k_grid_meta(const uint32_t* __restrict__ bounds, const int* __re
   m.top_level = top;
   m.n_cells = 0;
   for (int l = 0; l <= kMaxLevel; l++) m.level_cells[l] = 0;
-  m.pad = 0;
-  // the hash size is set by k_grid_hash_size once the occupied cells have been counted (after the sort)
+  // the hash size is set by k_grid_hash_size / k_hash_build once the occupied cells have been counted (after the sort)
   m.hshift = 28;
   m.hmask = 15;
+  m.pmask = 15;
   meta[c] = m;
   // Morton keys of this cloud are below 2^(3 bits), bits = those of the largest cell coordinate (top_level is capped, this is not):
   // every point has a key, so ceil(3 bits / 8) radix passes order them (the sort's own padding follows the real elements and stays
@@ -214,21 +214,31 @@ __global__ __launch_bounds__(kCountBlock) void k_count_cells(const uint32_t* __r
   }
 }
 
+// The table of one cloud from its occupied cells per level: which levels it keeps, how many slots it gets.
+struct HashSize {
+  int top, cells;
+  uint32_t hshift, hmask, pmask;
+};
+__device__ __forceinline__ HashSize grid_hash_size(int top_level, const int* level_cells, uint32_t slots_cap, uint32_t per_cell) {
+  // the levels whose cells fit 0.7 of the cloud's share of the table (level 0 always does: at most one cell per point)
+  int top = top_level, cells = 0;
+  for (int l = 0; l <= top; l++) {
+    if (l > 0 && (uint32_t)(cells + level_cells[l]) > (slots_cap / 10u) * 7u) { top = l - 1; break; }
+    cells += level_cells[l];
+  }
+  uint32_t slots = 16, lg = 4;
+  while (slots < per_cell * (uint32_t)max(cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
+  return HashSize{top, cells, 32 - lg, slots - 1, min(slots, kProbeBlock) - 1};
+}
 __global__ void k_grid_hash_size(GridMeta* __restrict__ meta, int B, uint32_t slots_cap, uint32_t per_cell) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= B) return;
-  // the levels whose cells fit 0.7 of the cloud's share of the table (level 0 always does: at most one cell per point)
-  int top = meta[c].top_level, cells = 0;
-  for (int l = 0; l <= top; l++) {
-    if (l > 0 && (uint32_t)(cells + meta[c].level_cells[l]) > (slots_cap / 10u) * 7u) { top = l - 1; break; }
-    cells += meta[c].level_cells[l];
-  }
-  meta[c].top_level = top;
-  meta[c].n_cells = cells;
-  uint32_t slots = 16, lg = 4;
-  while (slots < per_cell * (uint32_t)max(cells, 1) && slots < slots_cap) { slots <<= 1; lg++; }
-  meta[c].hshift = 32 - lg;
-  meta[c].hmask = slots - 1;
+  const HashSize hs = grid_hash_size(meta[c].top_level, meta[c].level_cells, slots_cap, per_cell);
+  meta[c].top_level = hs.top;
+  meta[c].n_cells = hs.cells;
+  meta[c].hshift = hs.hshift;
+  meta[c].hmask = hs.hmask;
+  meta[c].pmask = hs.pmask;
 }
 
 // (clear and insert of a cloud run on the XCD that searches it later — xcd_item_chunk: the table of a scan, 0.5 MB, is filled in ONE
@@ -248,7 +258,7 @@ __device__ __forceinline__ HashSlot* table_insert(HashSlot* t, const GridMeta& m
   for (;;) {
     const uint32_t prev = atomicCAS(&t[h].key, kEmptyKey, key);
     if (prev == kEmptyKey || prev == key) return &t[h];
-    h = (h + 1) & m.hmask;
+    h = next_probe(h, m.pmask);
   }
 }
 
@@ -387,6 +397,157 @@ __global__ __launch_bounds__(256) void k_gather_insert(const float4* __restrict_
   }
 }
 
+// ---- the voxel hash of a batch of scan-sized clouds: one workgroup per cloud, the table built in LDS (round 6) -----------------------
+// k_gather_insert above enters every cell with a CAS and scattered 4- / 16-byte stores into a table in HBM: per 2 048-cloud launch 2.5 GB
+// written for 0.9 GB of points, indices and slots, 1.66 ms (+ 0.17 ms clearing the tables first, + the cell count and its atomics).
+// Here ONE block owns a cloud from the sorted (cell key, index) pairs to the finished table:
+//   pass A  gathers the points into Morton order (and leaves the keys of build_tile_order's sort), counting the occupied cells per level
+//           on the way; thread 0 sizes the table (grid_hash_size);
+//   then, per probe block of the table (kProbeBlock = 8 192 slots = 128 KB of LDS; a voxelised scan's table is four of them): clear the
+//   LDS image, walk the sorted keys once more - a run of equal (key >> 3l) is a cell of level l: its first element enters `start`, its
+//   last `end` - inserting with LDS atomics only the cells whose first slot lies in this probe block (probe sequences wrap inside their
+//   block: next_probe), and write the image out with coalesced 16-byte stores.  HBM sees every slot written exactly once.
+// A cloud costs (probe blocks) x (its points) key tests, so this is the path of BATCHES of scan-sized clouds (hash_build_in_blocks);
+// lone and large clouds keep k_gather_insert.
+constexpr int kHbThreads = 1024, kHbKeep = 16;  // a cloud of <= kHbKeep x 1 024 points keeps its keys in registers between the passes
+__global__ __launch_bounds__(kHbThreads) void k_hash_build(const float4* __restrict__ in, const uint32_t* __restrict__ keys, const int* __restrict__ vals,
+                                                           GridMeta* __restrict__ meta, float4* __restrict__ pts, int* __restrict__ orig,
+                                                           HashSlot* __restrict__ table, size_t cap, size_t slots_cap, uint32_t per_cell,
+                                                           uint32_t* __restrict__ order_keys, int* __restrict__ order_vals) {
+  __shared__ int4 image[kProbeBlock];
+  __shared__ int wcnt[kHbThreads / kWave][kMaxLevel + 1];
+  __shared__ HashSize s_hs;
+  const int c = blockIdx.x;
+  const GridMeta m = meta[c];
+  const int n = m.n;
+  const size_t o = (size_t)c * cap;
+  const uint32_t* k = keys + o;
+  const int tid = threadIdx.x;
+  // levels at which an element starts / ends a run of equal (key >> 3l), from the keys of its neighbours: all l <= msb(difference) / 3
+  auto run_level = [](uint32_t diff) { return diff ? min((31 - __clz((int)diff)) / 3, kMaxLevel) : -1; };
+  // ---- pass A: gather + occupied cells per level
+  int cnt[kMaxLevel + 1];
+#pragma unroll
+  for (int l = 0; l <= kMaxLevel; l++) cnt[l] = 0;
+  const bool keep = n <= kHbKeep * kHbThreads;
+  uint32_t key_[kHbKeep];  // keep: element tid + 1 024 j -> its key and (head level + 1) | (tail level + 1) << 4
+  uint32_t lev_[kHbKeep];
+#pragma unroll
+  for (int j = 0; j < kHbKeep; j++) { key_[j] = 0u; lev_[j] = 0u; }
+  constexpr int kU = 4;  // elements per thread and trip: their index loads, then their point gathers, in flight together
+  auto pass_a = [&](int i0, auto&& remember) {
+    int v[kU];
+    uint32_t kc[kU], kp[kU], kn[kU];
+    float4 pv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const int i = i0 + u * kHbThreads;
+      const bool valid = i < n;
+      v[u] = valid ? vals[o + i] : 0;
+      kc[u] = valid ? k[i] : 0u;
+      kp[u] = (valid && i > 0) ? k[i - 1] : 0u;
+      kn[u] = (valid && i < n - 1) ? k[i + 1] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; u++) pv[u] = (i0 + u * kHbThreads < n) ? in[o + v[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const int i = i0 + u * kHbThreads;
+      if (i >= n) continue;
+      pts[o + i] = pv[u];
+      orig[o + i] = v[u];
+      if (order_keys) {
+        order_keys[o + i] = tile_order_key(m, pv[u]);
+        order_vals[o + i] = i;
+      }
+      const int lh = (i > 0) ? run_level(kp[u] ^ kc[u]) : kMaxLevel, lt = (i < n - 1) ? run_level(kn[u] ^ kc[u]) : kMaxLevel;
+#pragma unroll
+      for (int l = 0; l <= kMaxLevel; l++)
+        if (l <= m.top_level) cnt[l] += (l <= lh) ? 1 : 0;
+      remember(u, kc[u], (uint32_t)(lh + 1) | ((uint32_t)(lt + 1) << 4));
+    }
+  };
+  if (keep) {
+#pragma unroll
+    for (int jb = 0; jb < kHbKeep / kU; jb++)
+      if (tid + jb * kU * kHbThreads < n)
+        pass_a(tid + jb * kU * kHbThreads, [&](int u, uint32_t key, uint32_t lev) {
+#pragma unroll
+          for (int uu = 0; uu < kU; uu++)
+            if (uu == u) { key_[jb * kU + uu] = key; lev_[jb * kU + uu] = lev; }
+        });
+  } else {
+    for (int i0 = tid; i0 < n; i0 += kU * kHbThreads) pass_a(i0, [](int, uint32_t, uint32_t) {});
+  }
+#pragma unroll
+  for (int l = 0; l <= kMaxLevel; l++) {
+    const int t = wave_reduce64(cnt[l], [](int a, int b) { return a + b; });
+    if (lane_id() == 0) wcnt[wave_id()][l] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int level_cells[kMaxLevel + 1];
+    for (int l = 0; l <= kMaxLevel; l++) {
+      int t = 0;
+      for (int w = 0; w < kHbThreads / kWave; w++) t += wcnt[w][l];
+      level_cells[l] = t;
+      meta[c].level_cells[l] = t;
+    }
+    const HashSize hs = grid_hash_size(m.top_level, level_cells, (uint32_t)slots_cap, per_cell);
+    meta[c].top_level = hs.top;
+    meta[c].n_cells = hs.cells;
+    meta[c].hshift = hs.hshift;
+    meta[c].hmask = hs.hmask;
+    meta[c].pmask = hs.pmask;
+    s_hs = hs;
+  }
+  __syncthreads();
+  const HashSize hs = s_hs;
+  // ---- the table, one probe block at a time
+  const uint32_t slots = hs.hmask + 1u, psize = hs.pmask + 1u, pieces = slots / psize;
+  int4* tab = reinterpret_cast<int4*>(table + (size_t)c * slots_cap);
+  // element i: key, run levels lh / lt (-1: none; capped at the levels the table keeps) -> its cells of probe block q
+  auto enter = [&](uint32_t q, int i, uint32_t key, int lh, int lt) {
+    lh = min(lh, hs.top); lt = min(lt, hs.top);
+    for (int l = 0; l <= max(lh, lt); l++) {
+      const uint32_t K = level_key(key, l);
+      uint32_t h = hash_slot(K, hs.hshift);
+      if ((h >> kProbeBlockLog) != q) continue;
+      h &= hs.pmask;
+      for (;;) {
+        const uint32_t prev = atomicCAS(reinterpret_cast<uint32_t*>(&image[h].x), kEmptyKey, K);
+        if (prev == kEmptyKey || prev == K) break;
+        h = (h + 1u) & hs.pmask;
+      }
+      if (l <= lh) image[h].y = i;
+      if (l <= lt) image[h].z = i + 1;
+    }
+  };
+  for (uint32_t q = 0; q < pieces; q++) {
+    for (uint32_t z = tid; z < psize; z += kHbThreads) image[z] = make_int4((int)kEmptyKey, 0, 0, 0);
+    __syncthreads();
+    if (keep) {
+#pragma unroll
+      for (int j = 0; j < kHbKeep; j++)
+        if (lev_[j]) enter(q, tid + j * kHbThreads, key_[j], (int)(lev_[j] & 15u) - 1, (int)(lev_[j] >> 4) - 1);
+    } else {
+      for (int i = tid; i < n; i += kHbThreads) {
+        const uint32_t key = k[i];
+        enter(q, i, key, (i > 0) ? run_level(k[i - 1] ^ key) : kMaxLevel, (i < n - 1) ? run_level(k[i + 1] ^ key) : kMaxLevel);
+      }
+    }
+    __syncthreads();
+    for (uint32_t z = tid; z < psize; z += kHbThreads) tab[(size_t)q * psize + z] = image[z];
+    __syncthreads();
+  }
+}
+// which batches take k_hash_build: many clouds (a block per cloud must fill the chip) of at most 2^16 points (<= 16 probe blocks)
+static bool hash_build_in_blocks(int B, size_t cap) {
+  static const int mode = [] { const char* e = getenv("MI355_HASH_BLOCKS"); return e ? atoi(e) : -1; }();  // A/B aid: 0 = never, 1 = always
+  if (mode >= 0) return mode != 0 && cap <= 65536;
+  return B >= 64 && cap <= 65536;
+}
+
 __global__ void k_copy_counts(const int* in, int* out, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) out[i] = in[i];
@@ -407,13 +568,19 @@ void build_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
   hipLaunchKernelGGL(k_copy_counts, dim3(div_up(B, 256)), dim3(256), 0, s, cnt_in, out.count.p, B);
   sort_pairs(s, ws, B, cap, cnt_in, 4, ws.sort_passes.p);
   TimedLaunch tl(KF_HASH_BUILD, s);
-  hipLaunchKernelGGL(k_count_cells, dim3(std::max(1, std::min(std::max(8, 1024 / std::max(B, 1)), div_up((long)cap, kCountBlock * kCountPer))), B), dim3(kCountBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
-  hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap, (uint32_t)std::max(1, tuning().hash_slots_per_cell));
-  const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = std::max(1, std::min(std::max(64, 8192 / std::max(B, 1)), div_up((long)cap, kHashBlock * kGiGroups)));  // (a lone big cloud: thousands of blocks)
-  hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
   const bool okeys = tile_order_keys && tuning().knn_tiles == 1 && tuning().tile_order;
-  hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(kHashBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
-                     out.table.p, cap, out.slots_cap, Gi, B, okeys ? ws.keys_b.p : (uint32_t*)nullptr, okeys ? ws.vals_b.p : (int*)nullptr);
+  if (hash_build_in_blocks(B, cap)) {
+    hipLaunchKernelGGL(k_hash_build, dim3(B), dim3(kHbThreads), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p, out.table.p, cap,
+                       out.slots_cap, (uint32_t)std::max(1, tuning().hash_slots_per_cell), okeys ? ws.keys_b.p : (uint32_t*)nullptr,
+                       okeys ? ws.vals_b.p : (int*)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_count_cells, dim3(std::max(1, std::min(std::max(8, 1024 / std::max(B, 1)), div_up((long)cap, kCountBlock * kCountPer))), B), dim3(kCountBlock), 0, s, ws.keys_a.p, out.meta.p, cap);
+    hipLaunchKernelGGL(k_grid_hash_size, dim3(div_up(B, 64)), dim3(64), 0, s, out.meta.p, B, (uint32_t)out.slots_cap, (uint32_t)std::max(1, tuning().hash_slots_per_cell));
+    const int Gc = std::max(1, std::min(32, (int)(out.slots_cap / 8192))), Gi = std::max(1, std::min(std::max(64, 8192 / std::max(B, 1)), div_up((long)cap, kHashBlock * kGiGroups)));  // (a lone big cloud: thousands of blocks)
+    hipLaunchKernelGGL(k_table_clear, dim3(xcd_grid(Gc, B)), dim3(256), 0, s, out.table.p, out.meta.p, out.slots_cap, Gc, B);
+    hipLaunchKernelGGL(k_gather_insert, dim3(xcd_grid(Gi, B)), dim3(kHashBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, out.meta.p, out.pts.p, out.orig.p,
+                       out.table.p, cap, out.slots_cap, Gi, B, okeys ? ws.keys_b.p : (uint32_t*)nullptr, okeys ? ws.vals_b.p : (int*)nullptr);
+  }
   MI_LAUNCH_CHECK();
   if (okeys) {  // sort_pairs reads the *_a buffers
     std::swap(ws.keys_a.p, ws.keys_b.p); std::swap(ws.keys_a.n, ws.keys_b.n);
@@ -1597,11 +1764,10 @@ __global__ void k_voxel_meta(const uint32_t* __restrict__ bounds, const int* __r
   m.dz = (int)floorf(mx[2] * inv) - mb2 + 1;
   m.inv_cell = inv;
   m.cell = leaf;
-  m.hshift = 0; m.hmask = 0;
+  m.hshift = 0; m.hmask = 0; m.pmask = 0;
   m.top_level = 0;
   m.n_cells = 0;
   for (int l = 0; l <= kMaxLevel; l++) m.level_cells[l] = 0;
-  m.pad = 0;
   vmeta[c] = m;
   // voxel indices are below dx dy dz; the points the filter drops carry the all-ones key and must end up behind every real one,
   // so p passes are enough when dx dy dz <= 2^(8p) - 1 (a 100 m x 100 m x 10 m scan at 0.2 m: 12.5 M voxels, 3 passes)
@@ -1692,19 +1858,19 @@ __global__ __launch_bounds__(256) void k_voxel_scan_heads(const uint32_t* __rest
   if (threadIdx.x == 255) blocksum[(size_t)c * nblk + blockIdx.x] = wbase + incl;
 }
 
-// One thread per sorted point; the thread at the head of a voxel's run adds the run in ascending point-index order (the
-// stable sort's order — the same as the oracle's, so the fp32 sums are bit-equal).  History, per 1 024-cloud launch: 1 024-point
-// tiles staged through LDS behind a block barrier 5.7 ms; head threads walking their runs from memory, four gathers in flight,
-// 2.6 ms (a run is ~4 points on average, up to ~100 next to the sensor; 3 lanes of 4 idle); now one gather per lane and the run
-// handed to its head by lane shuffles.
-// Round 4: a wave takes kVcGroups x 64 consecutive sorted elements, not 64.  With one element per lane a wave lived ~11 us - a chain of
-// four dependent memory operations (meta, keys / indices, the gather, the output position) around ~500 instructions - and 8 192
-// resident waves of that shape moved 4.3 GB in 3.9 ms (PMC: 73 % of the wave cycles waiting).  Now the loads of all groups are
-// issued together (four gathers per lane in flight), then every group is folded and written as before.
-#ifndef VC_GROUPS
-#define VC_GROUPS 4
-#endif
-constexpr int kVcGroups = VC_GROUPS;
+// The centroid of every voxel: the points of a run of equal keys added in ascending point-index order (the stable sort's order - the
+// same as the oracle's, so the fp32 sums are bit-equal) and divided by their number.
+// History, per 1 024-cloud launch: 1 024-point tiles staged through LDS behind a block barrier 5.7 ms; head threads walking their runs
+// from memory 2.6 ms; one sorted element per lane, a run handed to its head lane by lane shifts, 1.7 ms (round 4: four groups of 64 per
+// wave, their loads in flight together: 2.1 ms per 2 048 clouds).  That version was bound by its own instruction stream: ~1 660 VALU +
+// 1 490 SALU instructions per 256 elements at 6.8 resident waves per SIMD (round 5 counters: 0.67 of the SIMDs' issue slots) - every lane
+// of a group ran the shift loop for as many steps as the LONGEST run in the group is long (8 on average, 18 at the 90th percentile) while
+// a run averages 3.5 points.
+// Round 6: a LANE takes kVcLane = 4 CONSECUTIVE sorted elements (one 16-byte load each of keys, indices and output positions, four
+// point gathers in flight), folds the runs that lie inside its four elements in registers, and only the one run that is still open at the
+// end of its elements goes on through lane shifts - four elements of the next lane per step, so a wave of 256 elements takes
+// (longest continuation) / 4 steps.  A block of one cloud that had a wave per 256 elements keeps that geometry.
+constexpr int kVcLane = 4, kVcWaveElems = kWave * kVcLane;
 __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* __restrict__ in, const uint32_t* __restrict__ keys,
                                                          const int* __restrict__ vals, const GridMeta* __restrict__ vmeta,
                                                          const int* __restrict__ local,
@@ -1712,13 +1878,15 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
                                                          float4* __restrict__ out, int* __restrict__ cnt_out, size_t cap, int nblk, int G, int B,
                                                          double min_distance, const GridMeta* __restrict__ next_meta, uint32_t* __restrict__ next_keys,
                                                          int* __restrict__ next_vals) {
+  static_assert(kScanTile % kVcWaveElems == 0, "a wave's elements share one scan tile");
   int c, bx;
   if (!xcd_item_chunk(G, B, c, bx)) return;
   const GridMeta m = vmeta[c];
+  const int n = m.n;
   const int lane = lane_id();
-  const int i0 = bx * (kWave * kVcGroups) + lane;
-  if (i0 == 0) cnt_out[c] = (m.n > 0) ? totals[c] : 0;
-  if (bx * (kWave * kVcGroups) >= m.n) return;  // whole block past the end of the cloud
+  const int w0 = bx * kVcWaveElems;
+  if (w0 == 0 && lane == 0) cnt_out[c] = (n > 0) ? totals[c] : 0;
+  if (w0 >= n) return;  // whole block past the end of the cloud
   const size_t o = (size_t)c * cap;
   // next_meta: the voxel hash that indexes this filter's output next (voxel_grid's `index_next`) - the output point's cell key is
   // written while the point is in a register, so build_grid needs neither a bounds pass nor a key pass over the output
@@ -1731,75 +1899,118 @@ __global__ __launch_bounds__(kPointBlock) void k_voxel_centroids(const float4* _
       next_vals[o + pos] = pos;
     }
   };
+  const int i0 = w0 + lane * kVcLane;
+  const int boff = blockoff[(size_t)c * nblk + w0 / kScanTile];
+  // ---- this lane's four elements: keys, indices, output positions (16-byte accesses where the row of the cloud is 16-byte aligned)
+  uint32_t k[kVcLane];
+  int v[kVcLane], pos[kVcLane];
+  const bool vec = ((o & 3) == 0) && i0 + kVcLane <= n;
+  if (vec) {
+    const uint4 kq = *reinterpret_cast<const uint4*>(keys + o + i0);
+    const int4 vq = *reinterpret_cast<const int4*>(vals + o + i0);
+    const int4 lq = *reinterpret_cast<const int4*>(local + o + i0);
+    k[0] = kq.x; k[1] = kq.y; k[2] = kq.z; k[3] = kq.w;
+    v[0] = vq.x; v[1] = vq.y; v[2] = vq.z; v[3] = vq.w;
+    pos[0] = lq.x; pos[1] = lq.y; pos[2] = lq.z; pos[3] = lq.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < kVcLane; e++) {
+      const bool valid = i0 + e < n;
+      k[e] = valid ? keys[o + i0 + e] : 0xFFFFFFFEu;  // (no voxel index is that large: the overflow test bounds it by INT_MAX)
+      v[e] = valid ? vals[o + i0 + e] : 0;
+      pos[e] = valid ? local[o + i0 + e] : 0;
+    }
+  }
+  const uint32_t kprev = (i0 > 0 && i0 <= n) ? keys[o + i0 - 1] : kEmptyKey;
+  float4 p[kVcLane];
+#pragma unroll
+  for (int e = 0; e < kVcLane; e++) p[e] = (i0 + e < n) ? in[o + v[e]] : make_float4(0.f, 0.f, 0.f, 0.f);
   if (m.overflow) {  // "Leaf size is too small for the input dataset" -> output = input (what the fused distance filter keeps)
 #pragma unroll
-    for (int g = 0; g < kVcGroups; g++) {
-      const int i = i0 + g * kWave;
-      if (i < m.n && voxel_head(m, keys + o, in + o, i, kEmptyKey, min_distance)) emit(local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile], in[o + i]);
-    }
+    for (int e = 0; e < kVcLane; e++)
+      if (i0 + e < n && passes_distance(p[e], min_distance)) emit(pos[e] + boff, p[e]);  // (all keys are empty: the stable sort left the points in order)
     return;
   }
-  // EVERY lane fetches the points at its sorted positions (one gather per lane and group, all in flight together); a head then adds
-  // the points of the lanes behind it in ascending order, passed along by lane shuffles.  The loop runs as long as any head of the
-  // group still has run left inside the group (a run is ~4 points); a run that leaves the group is finished from memory.
-  uint32_t kk_[kVcGroups], kprev_[kVcGroups];
-  float4 a_[kVcGroups];
-  int pos_[kVcGroups];
-  bool valid_[kVcGroups];
+  // ---- heads, and the runs inside the lane: head e takes the elements behind it while their key is its own, in order
+  bool head[kVcLane];
+  int cnt[kVcLane];
 #pragma unroll
-  for (int g = 0; g < kVcGroups; g++) {
-    const int i = i0 + g * kWave;
-    valid_[g] = i < m.n;
-    kk_[g] = valid_[g] ? keys[o + i] : 0xFFFFFFFEu;  // (no voxel index is that large: the overflow test bounds it by INT_MAX)
-    kprev_[g] = (valid_[g] && i > 0) ? keys[o + i - 1] : kEmptyKey;
-    a_[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid_[g]) a_[g] = in[o + vals[o + i]];
-    pos_[g] = valid_[g] ? local[o + i] + blockoff[(size_t)c * nblk + i / kScanTile] : 0;
+  for (int e = 0; e < kVcLane; e++) {
+    head[e] = i0 + e < n && k[e] != kEmptyKey && (i0 + e == 0 || k[e] != (e == 0 ? kprev : k[e - 1]));
+    cnt[e] = 1;
   }
+  float4 a[kVcLane];
 #pragma unroll
-  for (int g = 0; g < kVcGroups; g++) {
-    const int i = i0 + g * kWave;
-    const uint32_t k = kk_[g];
-    const bool head = valid_[g] && k != kEmptyKey && (i == 0 || k != kprev_[g]);
-    float4 a = a_[g];
-    const float4 mine = a;
-    int cnt = 1;
-    bool open = head;  // still collecting
-    // the key and point of lane + d reach this lane one lane per step: a DPP whole-wave shift in the VALU (v_mov_b32_dpp wave_shl:1), where
-    // __shfl_down(x, d) was a ds_bpermute round trip per value and step that the next step's `take` waited for
-    uint32_t kk = k;
-    float px = mine.x, py = mine.y, pz = mine.z, pw = mine.w;
-    for (int d = 1; d < kWave; d++) {
-      kk = wave_shl1(kk);
-      px = wave_shl1(px); py = wave_shl1(py); pz = wave_shl1(pz); pw = wave_shl1(pw);
-      const bool in_wave = lane + d < kWave;
-      const bool take = open && in_wave && kk == k;
-      if (take) { a.x += px; a.y += py; a.z += pz; a.w += pw; cnt++; }
-      open = take || (open && !in_wave);  // a run that reaches the end of the group stays open for the memory walk below
-      if (!__any(open && in_wave)) break;
+  for (int e = 0; e < kVcLane; e++) a[e] = p[e];
+#pragma unroll
+  for (int e = 0; e + 1 < kVcLane; e++) {
+    bool open = head[e];
+#pragma unroll
+    for (int f = e + 1; f < kVcLane; f++) {
+      open = open && k[f] == k[e];
+      if (open) { a[e].x += p[f].x; a[e].y += p[f].y; a[e].z += p[f].z; a[e].w += p[f].w; cnt[e]++; }
     }
-    if (!head) continue;
-    if (open) {  // the run continues past this group's 64 points
-      for (int j = i + (kWave - lane); j < m.n; j += 4) {
+  }
+  // ---- the run that reaches the end of the lane's elements goes on in the next lanes: their elements arrive four per step
+  // (one whole-wave DPP shift per register and step), and are added while their key is the run's
+  int te = -1;  // which of the lane's heads owns that run
+#pragma unroll
+  for (int e = 0; e < kVcLane; e++)
+    if (head[e] && k[kVcLane - 1] == k[e]) te = e;
+  bool cont = te >= 0;
+  const uint32_t kt = k[kVcLane - 1];
+  float4 ta = make_float4(0.f, 0.f, 0.f, 0.f);
+  int tc = 0;
+#pragma unroll
+  for (int e = 0; e < kVcLane; e++)
+    if (e == te) { ta = a[e]; tc = cnt[e]; }
+  if (__any(cont)) {
+    uint32_t nk[kVcLane];
+    float nx[kVcLane], ny[kVcLane], nz[kVcLane], nw[kVcLane];
+#pragma unroll
+    for (int e = 0; e < kVcLane; e++) { nk[e] = k[e]; nx[e] = p[e].x; ny[e] = p[e].y; nz[e] = p[e].z; nw[e] = p[e].w; }
+    for (int d = 1; d < kWave; d++) {
+#pragma unroll
+      for (int e = 0; e < kVcLane; e++) {
+        nk[e] = wave_shl1(nk[e]);
+        nx[e] = wave_shl1(nx[e]); ny[e] = wave_shl1(ny[e]); nz[e] = wave_shl1(nz[e]); nw[e] = wave_shl1(nw[e]);
+      }
+      const bool in_wave = lane + d < kWave;
+      bool take = cont && in_wave;
+#pragma unroll
+      for (int e = 0; e < kVcLane; e++) {
+        take = take && nk[e] == kt;
+        if (take) { ta.x += nx[e]; ta.y += ny[e]; ta.z += nz[e]; ta.w += nw[e]; tc++; }
+      }
+      cont = take || (cont && !in_wave);  // a run that reaches the end of the wave stays open for the memory walk below
+      if (!__any(cont && in_wave)) break;
+    }
+    if (cont) {  // the run continues past this wave's 256 elements
+      for (int j = w0 + kVcWaveElems; j < n; j += 4) {
         uint32_t kq[4];
-        float4 p[4];
+        float4 q[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int jj = min(j + u, m.n - 1);
-          kq[u] = (j + u < m.n) ? keys[o + jj] : ~k;
-          p[u] = in[o + vals[o + jj]];
+          const int jj = min(j + u, n - 1);
+          kq[u] = (j + u < n) ? keys[o + jj] : ~kt;
+          q[u] = in[o + vals[o + jj]];
         }
         bool more = true;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          more = more && (kq[u] == k);
-          if (more) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; cnt++; }
+          more = more && (kq[u] == kt);
+          if (more) { ta.x += q[u].x; ta.y += q[u].y; ta.z += q[u].z; ta.w += q[u].w; tc++; }
         }
         if (!more) break;
       }
     }
-    const float fc = (float)cnt;
-    emit(pos_[g], make_float4(a.x / fc, a.y / fc, a.z / fc, a.w / fc));
+  }
+#pragma unroll
+  for (int e = 0; e < kVcLane; e++) {
+    if (!head[e]) continue;
+    const float4 s = (e == te) ? ta : a[e];
+    const float fc = (float)((e == te) ? tc : cnt[e]);
+    emit(pos[e] + boff, make_float4(s.x / fc, s.y / fc, s.z / fc, s.w / fc));
   }
 }
 
@@ -1828,7 +2039,7 @@ void voxel_grid(hipStream_t s, Workspace& ws, const float4* in, const int* cnt_i
     if (index_next->B != B || index_next->cap != cap) throw ArgError(MI355_EINVAL, "voxel_grid: index_next has another shape");
     hipLaunchKernelGGL(k_grid_meta, dim3(div_up(B, 64)), dim3(64), 0, s, ws.bounds.p, ws.totals.p, index_next->meta.p, B, index_cell, ws.sort_passes.p);
   }
-  const int Gv = div_up((long)cap, kPointBlock * kVcGroups);
+  const int Gv = div_up((long)cap, kVcWaveElems);
   TimedLaunch tl(KF_VOXEL_CENTROIDS, s);
   hipLaunchKernelGGL(k_voxel_centroids, dim3(xcd_grid(Gv, B)), dim3(kPointBlock), 0, s, in, ws.keys_a.p, ws.vals_a.p, ws.vmeta.p, ws.scan_local.p,
                      ws.scan_block.p, ws.totals.p, out, cnt_out, cap, nblk, Gv, B, min_distance,

@@ -39,8 +39,13 @@ struct GridMeta {
   int n_cells;        // occupied cells over all levels = entries of the hash
   int level_cells[kMaxLevel + 1];  // ... by level (k_count_cells; k_grid_hash_size drops the coarsest levels of a cloud whose cells
                                    // would not fit its share of the table: the searches then walk finer cells further, results unchanged)
-  int pad;
+  uint32_t pmask;     // probe-block mask: a probe sequence wraps inside the aligned block of pmask + 1 slots its first slot lies in (grid.hpp next_probe)
 };
+static_assert(sizeof(GridMeta) == 80, "GridMeta layout");
+
+// Linear probing wraps inside aligned blocks of kProbeBlock slots (128 KB): a block of the table can then be BUILT IN LDS by one workgroup
+// and written out with coalesced stores (k_hash_build) - no entry of it lies outside, whatever the collisions.
+constexpr uint32_t kProbeBlockLog = 13, kProbeBlock = 1u << kProbeBlockLog;
 
 struct Workspace {
   DevBuf<uint32_t> keys_a, keys_b;

@@ -69,13 +69,16 @@ __host__ __device__ __forceinline__ uint32_t level_key(uint32_t m27, int l) { re
 
 __device__ __forceinline__ uint32_t hash_slot(uint32_t key, uint32_t hshift) { return (key * 0x9E3779B1u) >> hshift; }
 
+// next slot of a probe sequence: linear, wrapping inside the probe block (engine.hpp kProbeBlock) of the first slot
+__device__ __forceinline__ uint32_t next_probe(uint32_t h, uint32_t pmask) { return (h & ~pmask) | ((h + 1u) & pmask); }
+
 __device__ __forceinline__ bool cell_range(const GridView& g, uint32_t key, int& s, int& e) {
   uint32_t h = hash_slot(key, g.m.hshift);
   for (;;) {
     const int4 sl = *reinterpret_cast<const int4*>(&g.table[h]);
     if ((uint32_t)sl.x == key) { s = sl.y; e = sl.z; return true; }
     if ((uint32_t)sl.x == kEmptyKey) return false;
-    h = (h + 1) & g.m.hmask;
+    h = next_probe(h, g.m.pmask);
   }
 }
 
@@ -115,7 +118,7 @@ __device__ __forceinline__ bool resolve_range(const GridView& g, uint32_t key, i
   for (;;) {
     if ((uint32_t)sl.x == key) { s = sl.y; e = sl.z; return true; }
     if ((uint32_t)sl.x == kEmptyKey) return false;
-    h = (h + 1) & g.m.hmask;
+    h = next_probe(h, g.m.pmask);
     sl = *reinterpret_cast<const int4*>(&g.table[h]);
   }
 }

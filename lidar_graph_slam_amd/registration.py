@@ -410,6 +410,16 @@ class BatchRegistration:
         self.ctx.check(self.ctx._lib.mi355_batch_diagnostics(self.handle, fc.ctypes.data, pts.ctypes.data, fb.ctypes.data))
         return {"first_converged": fc, "knn_points": pts, "knn_handed_over": fb}
 
+    def get_cloud(self, targets: bool, index: int, with_cov: bool = False):
+        """Parity probe (synchronises): cloud `index` of the targets / sources as the batch registers it - the points the prefilter left,
+        in its output order, float32 [n, 4]; with_cov: also their regularised covariances, float32 [n, 6] (xx xy xz yy yz zz)."""
+        n = C.c_size_t(0)
+        pts = np.zeros((self.capacity, 4), dtype=np.float32)
+        cov = np.zeros((self.capacity, 6), dtype=np.float32) if with_cov else None
+        self.ctx.check(self.ctx._lib.mi355_batch_get_cloud(self.handle, 1 if targets else 0, int(index), pts.ctypes.data,
+                                                           cov.ctypes.data if with_cov else None, self.capacity, C.byref(n)))
+        return (pts[: n.value].copy(), cov[: n.value].copy()) if with_cov else pts[: n.value].copy()
+
     def set_side_streams(self, on: bool | None):
         """Prepare targets and sources on two overlapping side streams (True, the default), or one after the other on the batch's
         own stream (False: what a profiler wants); None = the library default."""

@@ -28,7 +28,7 @@ double use(pcl::PointCloud<PointType>::Ptr target, pcl::PointCloud<PointType>::P
     ndt->setStepSize(0.1);
     ndt->setResolution(2.0f);
     ndt->setMaximumIterations(64);
-    ndt->setNeighborhoodSearchMethod(0);
+    ndt->setNeighborhoodSearchMethod(mi355_pcl::DIRECT7);  // (pclomp::DIRECT7 in the node: the same value)
     ndt->setNumThreads(4);
     (void)ndt->getTransformationProbability();
   }
