@@ -7,7 +7,8 @@ One *step* = one pass of the whole hot path over one batch of `--pairs` independ
 inputs already resident in HBM: distance filter + VoxelGrid 0.2 m on both clouds -> voxel-hash build -> k=20
 covariances -> exactly 20 Levenberg-Marquardt GICP iterations -> poses copied back.  Pairs are sharded across ranks with
 no data-path collective (weak scaling); the only collective is the MAX of the elapsed time.  BASELINE.json configs[1].
-Default: ONE batch of 4 096 pairs at a time (86 GB of the 288 GB of HBM since round 5: 21 MB per pair, the raw clouds included) —
+Default: ONE batch of 4 096 pairs at a time (~113 GB of the 288 GB of HBM in use, as `config.hbm_bytes_in_use` of the line measures it:
+27.5 MB per pair with the raw clouds, the batch object and its workspaces) —
 every kernel duration the roofline block reports is then what rocprofv3 reports for the same command.  `--inflight 2 --pairs 512` keeps two batch objects in flight on two HIP streams in the same memory
 (while one batch is in its latency- and bandwidth-bound LM iterations the next one is prefiltered and indexed by VALU-bound
 kernels): +8 % pairs/s, `--inflight 3`: +13 %; K steps are then still K whole batches, all finished inside the timed region, but
@@ -48,7 +49,7 @@ ALG_BYTES = {
     "k_knn_cov_tile": ("cloud point", 40),       # read 16 + write 24 (neighbour gathers are implementation traffic)
     "k_voxel_centroids": ("raw point", 32),      # read 16 + write <= 16
     "sort_pairs(k_sort_*)": ("sorted element", 64),  # 4 passes x (8 B read + 8 B written) of (key, index) pairs
-    "hash_build(k_count_cells,k_table_clear,k_gather_insert)": ("cloud point", 36),  # read pt 16 + write sorted pt 16 + index 4
+    "hash_build(k_hash_build|k_gather_insert)": ("cloud point", 36),  # read pt 16 + write sorted pt 16 + index 4
     # --sor only: StatisticalOutlierRemoval, SURVEY 8d: read 16 + mask 1 + compacted 16 per point (priced on the points that SURVIVE
     # it — the count the batch reports — so a lower bound of the bytes)
     "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)": ("surviving point", 33),
@@ -59,6 +60,13 @@ N_BASE = 32      # distinct ray-cast pairs per rank: own street scene, own senso
                  # pair p of the batch is pair p % N_BASE under its own world transform (which re-bins every voxel grid)
 N_ORACLE = 16    # pairs of the timed batch that the oracle registers again, from the same world-transformed clouds (one of them the pair
                  # with the largest error against the ground truth)
+
+
+def shared_bases_path(n_base: int) -> str:
+    """The /dev/shm file local rank 0 hands the base pairs to the node's other ranks through.  Keyed by THIS launch - the rendezvous port,
+    torchrun's run id and the pid of the launcher every local rank is a child of - so that a file an earlier, crashed run left behind on
+    the same port is never picked up."""
+    return os.path.join("/dev/shm", f"mi355_bench_bases_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}_{n_base}.npz")
 
 
 def base_pairs(rank: int, n_base: int):
@@ -73,7 +81,7 @@ def base_pairs(rank: int, n_base: int):
 
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    shared = os.path.join("/dev/shm", f"mi355_bench_bases_{os.environ.get('MASTER_PORT', '0')}_{n_base}.npz") if local_world > 1 else None
+    shared = shared_bases_path(n_base) if local_world > 1 else None
     if shared and local_rank != 0:
         t0 = time.time()
         while not os.path.exists(shared):
@@ -82,7 +90,9 @@ def base_pairs(rank: int, n_base: int):
             time.sleep(0.2)
         z = np.load(shared)
         return [(z[f"s{i}"], z[f"t{i}"], z[f"g{i}"]) for i in range(n_base)]
-    specs = [synth.bench_pair_spec(i, 0 if shared else rank) for i in range(n_base)]
+    # (shared: the node's ranks hold the same scenes - seeded by the NODE's rank, so that several nodes still cast different ones - and
+    # differ by their world transforms; alone: seeded by the rank)
+    specs = [synth.bench_pair_spec(i, int(os.environ.get("GROUP_RANK", "0")) if shared else rank) for i in range(n_base)]
     workers = max(1, min(n_base, (os.cpu_count() or 8) - 1))
     if workers == 1:
         pairs = [synth.make_pair_job(sp) for sp in specs]
@@ -102,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU per step (= per batch): 4 096 pairs = 86 GB of the 288 GB; 2 048 (the default of "
+    ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU per step (= per batch): 4 096 pairs = ~113 GB of the 288 GB in use (config.hbm_bytes_in_use); 2 048 (the default of "
                     "rounds 3-4) is 5 %% slower per pair, 1 024: 10 %%, 128: 50 %%")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--leaf", type=float, default=0.2)
@@ -131,13 +141,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
+    # BENCH_BOOTSTRAP_ONLY: the rank bootstrap alone - base pairs handed over, process group up, barrier, the shared file gone,
+    # one max-over-ranks reduce, rank 0's line - with the GPU section stubbed out: tests/test_bench_host.py runs it with 8 local ranks
+    # on a machine without a GPU (the pool has no multi-GPU box: the host side of `--gpus 8` is what can be shown)
+    bootstrap_only = bool(os.environ.get("BENCH_BOOTSTRAP_ONLY"))
+    if not bootstrap_only and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     # BENCH_DEVICE / BENCH_BACKEND exist so that the multi-rank code path can be exercised on a box with ONE GPU (every rank
     # on device 0, gloo for the two tiny collectives); the driver's runs use neither.
     dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    dev = None
+    if not bootstrap_only:
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm
@@ -148,9 +164,25 @@ def main():
         dist.barrier()  # every rank has read the shared base pairs: local rank 0 takes the file out of /dev/shm again
         if local_rank == 0:
             try:
-                os.remove(os.path.join("/dev/shm", f"mi355_bench_bases_{os.environ.get('MASTER_PORT', '0')}_{n_base}.npz"))
+                os.remove(shared_bases_path(n_base))
             except OSError:
                 pass
+    if bootstrap_only:
+        from lidar_graph_slam_amd import sharding
+
+        slowest = sharding.max_over_ranks(1.0 + 0.001 * rank)  # (the reduce the timed region ends with)
+        checksum = float(sum(np.asarray(b[0], np.float64).sum() + np.asarray(b[1], np.float64).sum() for b in base))
+        sums = [None] * world
+        if world > 1:
+            dist.all_gather_object(sums, checksum)
+        else:
+            sums = [checksum]
+        if rank == 0:
+            print(json.dumps({"bootstrap_only": True, "n_gpus": world, "max_over_ranks": slowest, "base_pairs_identical_on_every_rank": len(set(sums)) == 1,
+                              "shared_file_left_behind": os.path.exists(shared_bases_path(n_base)), "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from lidar_graph_slam_amd import _lib as L
     from lidar_graph_slam_amd import sharding, synth
@@ -351,7 +383,7 @@ def main():
         "k_gicp_linearize": float(n_src.sum()) * args.iters, "k_gicp_correspond": float(n_src.sum()) * args.iters,
         "k_gicp_correspond_tile": float(n_src.sum()) * ktimes.get("k_gicp_correspond_tile", [0, 0])[1] / max(args.steps, 1),
         "k_knn_cov_tile": n_pts, "k_voxel_centroids": n_raw,
-        "sort_pairs(k_sort_*)": n_raw + n_pts, "hash_build(k_count_cells,k_table_clear,k_gather_insert)": n_pts,
+        "sort_pairs(k_sort_*)": n_raw + n_pts, "hash_build(k_hash_build|k_gather_insert)": n_pts,
         "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)": n_pts,
     }
     gpu_ms_total = sum(v[0] for v in ktimes.values())
@@ -423,6 +455,22 @@ def main():
             roofline["traffic"] = tj["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tj.get("source", "profiles/" + tname)
             break
+
+    # ... and the share of the chip's VALU issue slots the kernels fill (SQ counters of the same command: profiles/<round>_issue.json):
+    # the search kernels are bound by their instruction stream, and the HBM fraction alone would not say so
+    for iname in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_issue.json") and "ndt" not in f), reverse=True):
+        ij = json.load(open(os.path.join(ROOT, "profiles", iname)))
+        if ij.get("pairs") != P:
+            continue
+        for fam_name, e in by_kernel.items():
+            hit = ij["kernels"].get(fam_name.split("(")[0])
+            if hit:
+                e["valu_issue_frac"] = hit["valu_issue_frac"]
+        hit = ij["kernels"].get(dom.split("(")[0])
+        if hit:
+            roofline["valu_issue_frac"] = hit["valu_issue_frac"]
+            roofline["valu_issue_frac_source"] = f"profiles/{iname}: {ij.get('unit', '')}"
+        break
 
     # ---- accuracy gate: a fast kernel whose results differ from the reference's is not done -------------------------------
     if errs[:, 0].max() > TOL_TRUTH_T or errs[:, 1].max() > TOL_TRUTH_R:
@@ -548,7 +596,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32 per-point maths, f64 accumulation",  # (distances, transforms, Mahalanobis matrices in fp32 on 24-byte covariances; every sum - covariances,
+                                                          # normal equations, trial costs - in fp64: the 16 oracle-checked pairs agree with the all-fp64 oracle to ~1e-7 m)
         "data": "synthetic",
         "inputs": "host buffers (PCIe-inclusive; NOT the headline)" if args.host_inputs else "resident in HBM",
         **({"not_the_headline": "--sor: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2), not BASELINE configs[1]"} if args.sor else {}),

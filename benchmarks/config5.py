@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=2, help="uploads + registration + read-back this many times on the same batch object, the shortest reported "
                     "(the first call of a process pays the library's workspace allocations)")
     ap.add_argument("--min-good", type=float, default=0.9, help="fail unless this fraction of the pairs lands within 5 cm / 5 mrad of the truth")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip timing the oracle on four of the candidates")
     ap.add_argument("--multi-lanes", type=int, default=0, help="ONE process, this many lanes on device 0 through mi355_multi_batch_register (host views in, "
                     "results out: uploads included in the rate) instead of one rank per GPU")
     args = ap.parse_args()
@@ -197,6 +198,36 @@ def main():
         accepted = out["converged"] & (out["fitness"] < 0.3)  # graph_based_slam.cpp:321-328
         # NDT with 1 m cells lands within decimetres (the oracle does the same, tests/test_gpu_fullsize.py): a wider gate for it
         good = (errs[:, 0] < 0.05) & (errs[:, 1] < 5e-3) if args.method in ("FAST_GICP", "GICP") else (errs[:, 0] < 0.30) & (errs[:, 1] < 2e-2)
+        cpu = None
+        if not args.no_cpu_baseline:
+            # the CPU path beside it: the oracle - the restated reference engine - on a handful of the SAME candidates, one
+            # after the other with the reference's 4 OpenMP threads (graph_based_slam registers one candidate per tick): per candidate
+            # setInputTarget (kd-tree / covariances / leaves of the voxel-filtered sub-map) + setInputSource + align + getFitnessScore
+            from oracle import oracle_py as O
+
+            sample = sorted({(k * n) // 4 for k in range(4)})
+            threads = min(4, O.max_threads())
+            tc = 0.0
+            worst = 0.0
+            for p_ in sample:
+                src_c = load_source(p_)
+                tgt_c = O.voxel_grid(load_target(int(tgt_of_src[p_])), 0.5)[0]
+                tc0 = time.perf_counter()
+                if args.method == "FAST_GICP":
+                    r_ = O.gicp_align(src_c, tgt_c, O.gicp_params(max_iterations=args.max_iterations, num_threads=threads))
+                elif args.method == "NDT_OMP":
+                    r_ = O.ndt_align(src_c, tgt_c, O.ndt_params(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01, num_threads=threads))
+                elif args.method == "ICP":
+                    r_ = O.icp_align(src_c, tgt_c, O.icp_params(max_iterations=100, max_correspondence_distance=30.0, transformation_epsilon=1e-8, euclidean_fitness_epsilon=1e-6, num_threads=threads))
+                else:
+                    r_ = O.gicp_bfgs_align(src_c, tgt_c, O.gicp_bfgs_params(max_iterations=100, max_correspondence_distance=2.0, max_optimizer_iterations=20,
+                                                                             transformation_epsilon=0.01, euclidean_fitness_epsilon=1e-8, num_threads=threads))
+                O.fitness(src_c, tgt_c, r_["T"])
+                tc += time.perf_counter() - tc0
+                worst = max(worst, float(S_.pose_error(out["T"][p_], r_["T"])[0]))
+            cpu = {"value": round(len(sample) / tc, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+                   "sample": f"candidates {sample} of this list through oracle/liboracle.so ({args.method}: target set-up + align + fitness per candidate, {threads} OpenMP threads - the reference's "
+                             f"configuration) in {tc:.1f} s", "gpu_vs_cpu_pose_dt_m_max": round(worst, 6)}
         line = {
             "config": "BASELINE configs[4]: loop-closure batch, candidates sharded by sub-map over the ranks, results all-gathered",
             "n_gpus": world, "backend": backend if world > 1 else "single process", "collective_ranks": dist.get_world_size() if world > 1 else 1,
@@ -207,6 +238,7 @@ def main():
             "accepted(fitness<0.3)": int(accepted.sum()), "within_5cm_of_truth" if args.method in ("FAST_GICP", "GICP") else "within_30cm_of_truth": int(good.sum()),
             "median_pose_err_m": round(float(np.median(errs[:, 0])), 4), "max_pose_err_m_of_accepted": round(float(errs[accepted, 0].max()), 4) if accepted.any() else None,
             "mean_iterations": round(float(out["iterations"].mean()), 1),
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line))
         if not out["reported"].all() or good.sum() < args.min_good * n:

@@ -220,8 +220,24 @@ def main():
 
     by = []
     name, ms, nl, mt = fam("k_ndt_derivatives")
-    bytes_deriv = 268.0 * float((evals * n_src).sum())
-    by.append(row(name, nl, ms, mt, bytes_deriv, "268 B per source point and evaluation (16 + 7 cells x 36); evaluations per pair: mean %.2f" % float(evals.mean())))
+    # COMPULSORY bytes of the derivative pass: the 16-byte source point per evaluation + every leaf of a launch's targets ONCE per launch (a
+    # leaf holds >= 6 target points - min_points_per_voxel - so at most 48 B per 6 target points; neighbouring points share their leaves
+    # and find them in L2).  SURVEY 8d's 268 B per point and evaluation (16 + 7 cells x 36) prices every leaf as if it came from HBM for
+    # every point: by that figure the kernel "achieves" more than the HBM peak - kept below as `survey_pricing`, never as the fraction.
+    bytes_deriv = 16.0 * float((evals * n_src).sum()) + nl * 48.0 / 6.0 * float(n_tgt.sum())
+    by.append(row(name, nl, ms, mt, bytes_deriv, "16 B per source point and evaluation + <= 48 B per 6 target points and launch (the leaves, once per launch); "
+                                                   "evaluations per pair: mean %.2f" % float(evals.mean())))
+    survey_bytes = 268.0 * float((evals * n_src).sum())
+    by[0]["survey_pricing"] = {"bytes_per_unit": "268 B per source point and evaluation (16 + 7 cells x 36: SURVEY 8d)", "algorithmic_bytes_per_step": int(survey_bytes),
+                               "achieved_GBs_if_all_of_it_came_from_hbm": round(survey_bytes / (ms * 1e-3) / 1e9, 1) if ms else None,
+                               "note": "above the HBM peak when it is: the 7 leaves of a point come from L2 (counter traffic of a launch = the source points alone); not a roofline fraction"}
+    issue = None
+    prof = os.path.join(ROOT, "profiles")
+    for iname in sorted((f for f in os.listdir(prof) if f.endswith("_ndt_issue.json")), reverse=True):
+        hit = json.load(open(os.path.join(prof, iname)))["kernels"].get("k_ndt_derivatives")
+        if hit:
+            issue = dict(hit, source=f"profiles/{iname} (SQ counters of this command: SQ_ACTIVE_INST_VALU / (8 SQ_BUSY_CYCLES), benchmarks/summarize_evidence.py ISSUE_NOTE)")
+        break
     bytes_tgt = 16.0 * float(n_tgt.sum())
     name, ms, nl, mt = fam("ndt_target_sort")
     by.append(row(name, nl, ms, mt, 4.0 * bytes_tgt, "64 B per target point: 4 passes x (8 B read + 8 B written) of (voxel index, point index)"))
@@ -232,7 +248,7 @@ def main():
     for name in sorted(iso):
         if not name.startswith(("k_ndt_derivatives", "ndt_target", "k_ndt_leaves")):
             by.append(row(name, iso[name][1] / 2, iso[name][0] / 2, ktimes.get(name, (0.0, 0))[0] / args.steps, 0, ""))
-    total_bytes = bytes_deriv + bytes_tgt + 32.0 * float(counts_s.sum())
+    total_bytes = survey_bytes + bytes_tgt + 32.0 * float(counts_s.sum())
     line = {
         "metric": "NDT_OMP scan-vs-sub-map pairs/sec (64k-pt scans, 5-key-frame sub-maps, 2.0 m cells) on 1 MI355X", "not_the_headline": True,
         "value": round(P / (ms_step * 1e-3), 1), "unit": "pairs/s", "ms_per_step": round(ms_step, 3), "steps": args.steps, "warmup": args.warmup,
@@ -247,7 +263,9 @@ def main():
         "gpu_vs_oracle": oracle,
         "roofline": {"bound": "hbm", "kernel": by[0]["kernel"], "achieved": by[0].get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": by[0].get("frac_of_hbm_peak"),
-                     "end_to_end_frac": round(total_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "valu_issue_frac": issue["valu_issue_frac"] if issue else None, "valu_issue": issue,
+                     "note": "the derivative pass is bound by VALU issue, not by bytes: frac prices its COMPULSORY bytes (by_kernel[0].bytes_per_unit)",
+                     "end_to_end_frac_by_survey_pricing": round(total_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "by_kernel": by, "seconds_ray_casting_on_host": round(t_cast, 1),
     }
     b.close()

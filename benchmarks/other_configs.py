@@ -7,7 +7,7 @@ go into DESIGN.md / profiles, not into bench.py's JSON):
   config 4  KITTI-shaped stream through ScanMatcherCore (scan-to-keyframe), scans/s and end-point drift
 (config 5 - the loop-closure batch at its stated size - is benchmarks/config5.py.)
 
-usage: python benchmarks/other_configs.py [--scans 40] [--cpu]
+usage: python benchmarks/other_configs.py [--scans 40] [--no-cpu]
 """
 import argparse
 import json
@@ -40,7 +40,7 @@ def timed(f, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=40)
-    ap.add_argument("--cpu", action="store_true", help="also time the oracle (CPU) where it is cheap enough")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the oracle timings (cpu_baseline blocks)")
     args = ap.parse_args()
     out = {}
     scene = synth.Scene(1234)
@@ -86,12 +86,17 @@ def main():
                                     "set_target_ms(first call: allocations and the 17 MB upload from pageable memory included; benchmarks/ndt_batch.py --config3 times it warm)": t_build * 1e3,
                                     "align_ms_median": med * 1e3,
                                     "iterations": ndt.result["iterations"], "pose_err_vs_truth": synth.pose_error(ndt.getFinalTransformation(), T_true)}
-    if args.cpu:
+    if not args.no_cpu:
+        # the CPU path beside it: the oracle's ndt_omp restatement on the same scan and sub-map - target leaves + align,
+        # what the node pays per key frame -, 4 OpenMP threads (lidar_scan_matcher.param.yaml:10)
         from oracle import oracle_py as O
+        threads = min(4, O.max_threads())
         t0 = time.perf_counter()
-        r = O.ndt_align(scan, sub, O.ndt_params(resolution=1.0), guess=guess)
-        out["config3_ndt_1M_submap"]["cpu_ms"] = (time.perf_counter() - t0) * 1e3
-        out["config3_ndt_1M_submap"]["gpu_vs_cpu"] = synth.pose_error(ndt.getFinalTransformation(), r["T"])
+        r = O.ndt_align(scan, sub, O.ndt_params(resolution=1.0, num_threads=threads), guess=guess)
+        tc = time.perf_counter() - t0
+        out["config3_ndt_1M_submap"]["cpu_baseline"] = {"value": round(tc * 1e3, 2), "unit": "ms per setInputTarget + align", "cores": threads, "kind": "port",
+                                                        "sample": "this scan against this sub-map through oracle/liboracle.so, once",
+                                                        "gpu_vs_cpu_pose": synth.pose_error(ndt.getFinalTransformation(), r["T"])}
 
     # ---- config 4: stream through ScanMatcherCore (street scene: objects along the whole path; ground returns to 20 m —
     # the flat corridor of round 1 traps NDT at the identity, tests/test_oracle_ndt.py)
@@ -115,6 +120,19 @@ def main():
                                           "target_points_end": last["target_points"] if last else 0,
                                           "end_pose_err_vs_truth": synth.pose_error(last["pose"], gt) if last else None}
 
+    if not args.no_cpu:
+        # config 4 on the CPU: the oracle's fast_gicp restatement registering the stream's LAST scan against a sub-map of the 20 scans
+        # before it (the reference's window; every key frame rebuilds the target's kd-tree and covariances) - one registration, 4 threads
+        from oracle import oracle_py as O
+        threads = min(4, O.max_threads())
+        k0 = max(0, n - 21)
+        submap = np.concatenate([synth_transform(scans[i], np.linalg.inv(traj[n - 2]) @ traj[i]) for i in range(k0, n - 1)], axis=0)
+        t0 = time.perf_counter()
+        r = O.gicp_align(scans[n - 1], submap, O.gicp_params(num_threads=threads), guess=(np.linalg.inv(traj[n - 2]) @ traj[n - 1]).astype(np.float32))
+        tc = time.perf_counter() - t0
+        out["config4_stream_cpu_baseline"] = {"value": round(tc * 1e3, 1), "unit": "ms per key-frame scan (setInputTarget + setInputSource + align)", "cores": threads, "kind": "port",
+                                              "sample": f"the stream's last scan against the {n - 1 - k0} scans before it ({len(submap)} points) through oracle/liboracle.so, once",
+                                              "iterations": int(r["iterations"]), "converged": bool(r["converged"])}
     print(json.dumps(out, indent=1, default=lambda o: list(o) if isinstance(o, tuple) else float(o)))
 
 

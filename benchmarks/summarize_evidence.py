@@ -49,6 +49,17 @@ def pmc_per_kernel(counter_dir, counter):
     return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
 
 
+ISSUE_NOTE = ("valu_issue_frac = the share of the chip's VALU issue slots a kernel fills while it runs: SQ_ACTIVE_INST_VALU (summed over the waves, in "
+              "quad-cycles) x 4 clocks / (1 024 SIMDs x the kernel's clocks), the clocks taken as SQ_BUSY_CYCLES / 32 (it sums the busy clocks of the 32 shader "
+              "engines) = SQ_ACTIVE_INST_VALU / (8 SQ_BUSY_CYCLES).  Checked on k_knn_cov_tile: SQ_WAVE_CYCLES / (8 SQ_BUSY_CYCLES) = 1.9 resident waves per "
+              "SIMD where its 19 KB of LDS per wave allow 2.")
+
+
+def issue_fractions(t):
+    busy = max(t.get("SQ_BUSY_CYCLES", 0.0), 1.0)
+    return t.get("SQ_WAVE_CYCLES", 0.0) / (8.0 * busy), t.get("SQ_ACTIVE_INST_VALU", 0.0) / (8.0 * busy)
+
+
 def pmc_sq_table():
     """<round>_pmc_valu.csv: SQ counters per launch and kernel from the two --pmc passes of `python bench.py --steps 1 --warmup 1
     --no-cpu-baseline` (the bench's full batch), plus the derived instructions per point-lane and issue share."""
@@ -78,11 +89,21 @@ def pmc_sq_table():
     with open(os.path.join(DST, f"{R}_pmc_valu.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow([f"kernel (per-launch averages; python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d = {PAIRS} pairs per step, {PAIRS // 2} per launch of the "
-                    "per-part kernels; two rocprofv3 --pmc passes, --kernel-trace only)", "launches"] + cols + ["VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"])
+                    "per-part kernels; two rocprofv3 --pmc passes, --kernel-trace only)", "launches"] + cols + ["VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
+                    "resident_waves_per_SIMD = SQ_WAVE_CYCLES / (8 SQ_BUSY_CYCLES)", "valu_issue_frac = SQ_ACTIVE_INST_VALU / (8 SQ_BUSY_CYCLES)"])
+        issue = {}
         for k in order[:24]:
             t = table[k]
             wc = max(t.get("SQ_WAVE_CYCLES", 0.0), 1.0)
-            w.writerow([k[:90], launches[k]] + [round(t.get(c, 0.0), 1) for c in cols] + [round(t.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4), round(t.get("SQ_WAIT_ANY", 0.0) / wc, 4)])
+            occ, vfrac = issue_fractions(t)
+            issue.setdefault(k.split("(")[0].split("<")[0].replace("void ", "").replace("mi355::", "").strip(), {"valu_issue_frac": round(vfrac, 4), "resident_waves_per_simd": round(occ, 3),
+                                                                                "valu_issue_share_per_wave": round(t.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
+                                                                                "wait_share_per_wave": round(t.get("SQ_WAIT_ANY", 0.0) / wc, 4)})
+            w.writerow([k[:90], launches[k]] + [round(t.get(c, 0.0), 1) for c in cols] + [round(t.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4), round(t.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+                                                                                         round(occ, 3), round(vfrac, 4)])
+    with open(os.path.join(DST, f"{R}_issue.json"), "w") as f:
+        json.dump({"pairs": PAIRS, "source": f"profiles/{R}_pmc_valu.csv", "unit": ISSUE_NOTE, "kernels": issue}, f, indent=1)
+        f.write("\n")
 
 
 def main():
@@ -105,10 +126,10 @@ def main():
     if os.path.exists(os.path.join(SRC, "knn_stats.err")):  # k_knn_cov_tile's own counters beside the PMC instruction counts
         import subprocess
         subprocess.call([sys.executable, os.path.join(ROOT, "benchmarks", "summarize_knn.py"), R])
-    for f in ("ndt_batch.json", "ndt_under_trace.json", "kernel_stats_ndt.csv", "pmc_ndt.csv"):  # benchmarks/ndt_evidence.sh
+    for f in ("ndt_batch.json", "ndt_under_trace.json", "kernel_stats_ndt.csv", "pmc_ndt.csv", "ndt_issue.json"):  # benchmarks/ndt_evidence.sh
         pth = os.path.join(SRC, "ndt", f)
         if os.path.exists(pth):
-            dst = {"ndt_batch.json": "ndt_batch.json", "ndt_under_trace.json": "ndt_batch_under_trace.json", "kernel_stats_ndt.csv": "kernel_stats_ndt.csv", "pmc_ndt.csv": "pmc_ndt.csv"}[f]
+            dst = {"ndt_batch.json": "ndt_batch.json", "ndt_under_trace.json": "ndt_batch_under_trace.json", "kernel_stats_ndt.csv": "kernel_stats_ndt.csv", "pmc_ndt.csv": "pmc_ndt.csv", "ndt_issue.json": "ndt_issue.json"}[f]
             shutil.copy(pth, os.path.join(DST, f"{R}_{dst}"))
     fetch = pmc_per_kernel("pmc_fetch", "FETCH_SIZE")
     write = pmc_per_kernel("pmc_write", "WRITE_SIZE")

@@ -58,13 +58,23 @@ def main():
         w = csv.writer(f)
         w.writerow(["kernel (per-launch means; python benchmarks/ndt_batch.py --steps 1|2 --warmup 1 --no-oracle; separate rocprofv3 --pmc passes, --kernel-trace only; "
                     "FETCH_SIZE / WRITE_SIZE in KB, FETCH raw: x2 for 16-B/lane streaming reads)", "launches"] + cols +
-                   ["HBM_bytes_FETCHx2_plus_WRITE", "VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"])
+                   ["HBM_bytes_FETCHx2_plus_WRITE", "VALU_issue_share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES", "WAIT_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES",
+                    "resident_waves_per_SIMD = SQ_WAVE_CYCLES / (8 SQ_BUSY_CYCLES)", "valu_issue_frac = SQ_ACTIVE_INST_VALU / (8 SQ_BUSY_CYCLES)"])
+        issue = {}
         for k in order[:30]:
             t = table[k]
             wc = max(t.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+            busy = max(t.get("SQ_BUSY_CYCLES", 0.0), 1.0)  # (sums the busy clocks of the 32 shader engines; benchmarks/summarize_evidence.py ISSUE_NOTE)
+            occ, vfrac = t.get("SQ_WAVE_CYCLES", 0.0) / (8.0 * busy), t.get("SQ_ACTIVE_INST_VALU", 0.0) / (8.0 * busy)
+            issue.setdefault(k.split("(")[0].split("<")[0].replace("void ", "").replace("mi355::", "").strip(), {"valu_issue_frac": round(vfrac, 4), "resident_waves_per_simd": round(occ, 3),
+                                                                                "hbm_bytes_per_launch_FETCHx2_plus_WRITE": int(2048 * t.get("FETCH_SIZE", 0.0) + 1024 * t.get("WRITE_SIZE", 0.0))})
             w.writerow([k[:100], launches[k]] + [round(t.get(c, 0.0), 1) for c in cols] +
                        [int(2048 * t.get("FETCH_SIZE", 0.0) + 1024 * t.get("WRITE_SIZE", 0.0)), round(t.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
-                        round(t.get("SQ_WAIT_ANY", 0.0) / wc, 4)])
+                        round(t.get("SQ_WAIT_ANY", 0.0) / wc, 4), round(occ, 3), round(vfrac, 4)])
+    import json
+    with open(os.path.join(SRC, "ndt_issue.json"), "w") as f:
+        json.dump({"source": "pmc_ndt.csv of the same directory", "kernels": issue}, f, indent=1)
+        f.write("\n")
     print(open(os.path.join(SRC, "pmc_ndt.csv")).read()[:6000])
 
 

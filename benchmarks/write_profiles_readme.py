@@ -20,7 +20,7 @@ NOTES = {
     "sort_pairs(k_sort_*)": "per cloud three sorts - voxel index, Morton code of the hash, 2-D Hilbert index of the tile order: in-LDS tile sort (24 576 elements per block, all radix passes on chip) + merge-path merges for the raw 64 k-point clouds",
     "k_voxel_centroids": "fp32 centroid sums per voxel in ascending point order (the oracle's order): one gather per lane, runs handed to their head lane by shuffles",
     "k_gicp_linearize": "F4 + the sums F5 needs, streaming: 80 algorithmic B per source point; 72 model sums (8 x 8 outer products on fp64 MFMA + 20 registers) from which k_gicp_step forms H, b and every LM trial cost",
-    "hash_build(k_count_cells,k_table_clear,k_gather_insert)": "multi-level voxel hash sized to the occupied cells",
+    "hash_build(k_hash_build|k_gather_insert)": "multi-level voxel hash sized to the occupied cells",
     "k_gicp_step": "partials -> model -> H, b -> all LM trial poses and their costs; accept / reject walk (F5-F9)",
 }
 

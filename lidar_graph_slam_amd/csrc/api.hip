@@ -12,7 +12,7 @@ namespace mi355 {
 thread_local KernelTimers* g_timers = nullptr;
 thread_local int g_family_override = -1;
 const char* const kKernelFamilyName[KF_COUNT] = {"k_knn_cov_tile", "k_knn_hard", "k_voxel_centroids", "sort_pairs(k_sort_*)",
-                                                 "hash_build(k_count_cells,k_table_clear,k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
+                                                 "hash_build(k_hash_build|k_gather_insert)", "k_gicp_correspond", "k_gicp_correspond_tile", "k_gicp_linearize",
                                                  "k_gicp_step", "k_fitness",
                                                  "sor(sort,hash,k_knn_cov_tile<SOR>,k_knn_hard<SOR>,threshold,compact)",
                                                  "ndt_target_prep(k_ndt_bounds,keys,heads,scan,size,clear)", "ndt_target_sort(k_sort_tile,k_sort_merge)", "k_ndt_leaves(k_ndt_leaf_sums,k_ndt_leaf_finalize)", "k_ndt_derivatives", "k_ndt_advance"};
@@ -1359,6 +1359,14 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
       // targets' points is what getFitnessScore searches: built at align time, and only when a fitness is asked for.  The sources are
       // points in the voxel hash's Morton order (neighbouring lanes of the derivative pass read the same leaves).
       if (targets) {
+        if (pts == in && d_points != b->host_stage_tgt.p && d_points != b->cloud_stage_tgt.p) {
+          // no prefilter ran (and the points are not in the batch's own staging already): `pts` is the CALLER's buffer, and the targets' point hash (getFitnessScore) is built from it only at align
+          // time - a later enqueue than this call, by when the caller may have reused the memory (the *_dev contract is "read by work
+          // enqueued during the call").  The batch keeps its own copy.
+          ws.stage_a.ensure((size_t)n * b->cap);
+          MI_HIP(hipMemcpyAsync(ws.stage_a.p, in, (size_t)n * b->cap * sizeof(float4), hipMemcpyDeviceToDevice, s));
+          pts = ws.stage_a.p;
+        }
         ndt_build_targets(s, ws, *b->ndt, pts, b->cap, cnt, pt.h_counts[k].data(), n, b->cap, b->np, b->np.legacy_mt_skip == 0);
         b->ndt_tgt_pts = pts;
         b->ndt_tgt_cnt = cnt;
@@ -1371,8 +1379,9 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
     } else if (b->method == MI355_METHOD_ICP) {
       // point-to-point ICP: the targets' NN voxel hash is all it needs; the sources are points in that hash's Morton order
       // (neighbouring lanes of k_icp_step walk the same cells of the target)
-      build_grid(s, ws, pts, cnt, set, ctx->grid_cell, false);
+      build_grid(s, ws, pts, cnt, set, ctx->grid_cell, !targets);
       if (!targets) {
+        build_tile_order(s, ws, set);  // the sources' compact 64-point patches: what k_icp_correspond_tile's waves take
         b->icp_max_src = 0;
         for (int i = 0; i < n; i++) b->icp_max_src = std::max(b->icp_max_src, pt.h_counts[k][(size_t)i]);
       }
@@ -1602,7 +1611,8 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
       batch_wait_side(b, main, 1);
       // blocks until every pair is done (the fits and PCL's convergence criteria run on the device; the host polls a counter)
       gicp_set_map(main, pt.gb, tgt_of_src, b->n_targets);
-      icp_batch_align(main, *b->icp, b->n_sources, pt.src.pts.p, b->cap, pt.src.count.p, (size_t)b->icp_max_src, b->tgt, tgt_of_src, guesses16, b->ip);
+      icp_batch_align(main, *b->icp, b->n_sources, pt.src.pts.p, b->cap, pt.src.count.p, (size_t)b->icp_max_src, b->tgt, tgt_of_src, guesses16, b->ip,
+                      pt.src.has_order ? (const int*)pt.src.tile_order.p : (const int*)nullptr);
       if (b->with_fitness) {
         std::vector<float> T((size_t)b->n_sources * 16);
         icp_batch_results(*b->icp, nullptr, T.data());

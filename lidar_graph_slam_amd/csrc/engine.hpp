@@ -207,6 +207,13 @@ void gicp_linearize_once(hipStream_t s, GicpBatch& gb, const CloudSet& src, cons
 void gicp_trial_cost_probe(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, const double* T_lin16,
                            const double* T_trial16, double* model_cost, double* direct_cost);
 
+// gicp.hip: pcl::IterativeClosestPoint's correspondences by FAST_GICP's wave-cooperative tiles (k_icp_correspond_tile): cur = [S][cpitch] the
+// sources as moved so far, corr / qsearch the rows k_icp_step reads; pairs whose last fit moved them less than min_move are skipped
+struct IcpPairState;
+// tile_order (optional): [S][opitch] the sources' points in the order of their compact 64-point patches (cloud.hip build_tile_order)
+void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
+                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch);
+
 // ---- icp.hip -------------------------------------------------------------------------------------------------
 // pcl::IterativeClosestPoint for S pairs at once (every pair's state in HBM, advanced on the device); a registration object is a
 // batch of one.
@@ -216,7 +223,7 @@ void icp_batch_destroy(IcpBatch*);
 // src: [S][spitch] points in any order, counts on the device, none above max_count; tgt: built sets (the NN voxel hash is all
 // point-to-point ICP needs); pair p registers against target tgt_of_src_host[p] (nullptr: p).  Blocks until every pair is done.
 void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, size_t spitch, const int* d_src_counts, size_t max_count, const CloudSet& tgt,
-                     const int* tgt_of_src_host, const float* guesses_host, const mi355_icp_params& p);
+                     const int* tgt_of_src_host, const float* guesses_host, const mi355_icp_params& p, const int* src_tile_order = nullptr);
 void icp_batch_results(IcpBatch& b, mi355_result* out, float* T16_all);
 struct IcpScratch {
   IcpBatch* batch = nullptr;

@@ -12,6 +12,7 @@
 //                     lambda update, convergence test, iteration bookkeeping — no host round trip, no pass over the points.
 // Algorithmic HBM bytes of k_gicp_linearize per source point: src pt 16 + src cov 24 + tgt pt 16 + tgt cov 24 = 80 B.
 #include "engine.hpp"
+#include "icp_fit.hpp"
 #include "grid.hpp"
 #include "primitives.hpp"
 #include "tile.hpp"
@@ -1121,6 +1122,74 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
   if (act2) { best = b; explored2 = reach2; }
 }
 
+// The tiles of ONE pair (block bx of the pair's G): sp = the pair's source points, Tf the pose they are searched at (row-major 3 x 4),
+// corr_p / qs_p the pair's rows of the correspondence and last-search arrays.  Shared by FAST_GICP's update_correspondences and by ICP's
+// correspondence estimation (k_icp_correspond_tile below).
+__device__ __forceinline__ void correspond_tiles_of_pair(const GridView& g, const float4* __restrict__ sp, int n, const float* Tf, int* __restrict__ corr_p,
+                                                         float4* __restrict__ qs_p, float max_corr_d2, float r1, int G, int bx,
+                                                         unsigned long long* __restrict__ stats, const int* __restrict__ order_p, float4* cand, int* scratch) {
+  const int lane = lane_id();
+  const float reach2 = search_reach2(g, max_corr_d2, true);
+  const float reach = sqrtf(reach2);
+  const bool one_round = !(r1 < reach);
+  const float R1 = one_round ? reach : r1, R1_2 = one_round ? reach2 : r1 * r1;
+  constexpr int kWavesPerBlock = kGicpBlock / kWave;
+  for (int tile = bx * kWavesPerBlock + wave_id(); tile * kWave < n; tile += G * kWavesPerBlock) {
+    int i = tile * kWave + lane;
+    const bool valid = i < n;
+    // the source's tiles in the order its k-NN search took them (cloud.hip, build_tile_order): compact patches, not runs of the Morton curve
+    if (order_p && valid) i = order_p[i];
+    const float4 p = sp[valid ? i : tile * kWave];
+    const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
+    const bool finite_q = valid && isfinite(qx) && isfinite(qy) && isfinite(qz);
+    if (valid && !finite_q) corr_p[i] = -1;
+    // a point whose last search left a margin it has not used up keeps its correspondence (far-field points mostly: nothing
+    // within reach, and that stays so while the pose moves by decimetres)
+    const float4 qs = qs_p[valid ? i : tile * kWave];
+    const bool act = finite_q && !(sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z)) < qs.w);
+    if (!__ballot(act)) continue;
+    CorrBest best{kCorrEmpty, kCorrEmpty, -1};
+    float explored2 = 0.f;
+    {
+      // a patch across a jump of the Morton curve is mostly empty space between compact parts: its quarters go through the
+      // rounds one after the other
+      const TileBox box = tile_bounds(act, qx, qy, qz);
+      const TileCells probe = tile_cells(g, grow(box, R1 + tile_eps(box, reach)), kCorrSplitPoints);
+      const int parts = probe.ok ? 1 : 4;
+      for (int part = 0; part < parts; part++) {
+        const bool pact = act && (parts == 1 || (lane >> 4) == part);
+        if (!__ballot(pact)) continue;
+        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats, scratch);
+      }
+    }
+    // what the keys could not decide (a tie or near-tie of the two smallest, a box that could not be scanned) is left to the
+    // per-lane search of k_gicp_correspond, which runs next: NaN margin = "not searched"
+    const bool near_tie = best.k2 != kCorrEmpty && ((best.k2 >> kCorrOrdBits) - (best.k1 >> kCorrOrdBits)) <= 1u;
+    const bool left = act && (explored2 == 0.f || near_tie);
+    if (stats) {
+      const unsigned long long mleft = __ballot(left);
+      if (lane == 0) atomicAdd(&stats[7], (unsigned long long)__popcll(mleft));
+    }
+    if (left) {
+      corr_p[i] = -1;
+      qs_p[i] = make_float4(qx, qy, qz, __uint_as_float(0x7fc00000u));
+    } else if (act) {
+      NnState stt{INFINITY, -1, INFINITY, explored2, true};
+      if (best.k1 != kCorrEmpty) {
+        const float4 w = g.pts[best.j1];
+        stt.d1 = dist2f(qx, qy, qz, w.x, w.y, w.z);
+        stt.j1 = best.j1;
+        if (best.k2 != kCorrEmpty) stt.d2nd = __uint_as_float(((best.k2 >> kCorrOrdBits) - 1u) << kCorrOrdBits);  // lower edge, one bucket of slack
+      }
+      int j;
+      float margin;
+      finish_search(stt, max_corr_d2, true, j, margin);
+      corr_p[i] = j;
+      qs_p[i] = make_float4(qx, qy, qz, margin);
+    }
+  }
+}
+
 // (4 waves per SIMD = 126 VGPRs, no spills: 4.05 ms per launch at 1 024 pairs; unconstrained 135 VGPRs = 3 waves: 4.53 ms;
 // 5 waves = 96 VGPRs + 48 B of scratch: 4.6 ms)
 __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const float4* __restrict__ spts, const int* __restrict__ scount, size_t scap,
@@ -1149,67 +1218,46 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_gicp_correspond_tile(const fl
     Tf[4 * r + 3] = (float)x0.t[r];
   }
   const size_t so = (size_t)pair * scap;
-  const int lane = lane_id();
-  float4* cand = cand_all[wave_id()];
-  const float reach2 = search_reach2(g, max_corr_d2, true);
-  const float reach = sqrtf(reach2);
-  const bool one_round = !(r1 < reach);
-  const float R1 = one_round ? reach : r1, R1_2 = one_round ? reach2 : r1 * r1;
-  constexpr int kWavesPerBlock = kGicpBlock / kWave;
-  for (int tile = bx * kWavesPerBlock + wave_id(); tile * kWave < n; tile += G * kWavesPerBlock) {
-    int i = tile * kWave + lane;
-    const bool valid = i < n;
-    // the source's tiles in the order its k-NN search took them (cloud.hip, build_tile_order): compact patches, not runs of the Morton curve
-    if (tile_order && valid) i = tile_order[so + i];
-    const float4 p = spts[so + (valid ? i : tile * kWave)];
-    const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
-    const bool finite_q = valid && isfinite(qx) && isfinite(qy) && isfinite(qz);
-    if (valid && !finite_q) corr[so + i] = -1;
-    // a point whose last search left a margin it has not used up keeps its correspondence (far-field points mostly: nothing
-    // within reach, and that stays so while the pose moves by decimetres)
-    const float4 qs = qsearch[so + (valid ? i : tile * kWave)];
-    const bool act = finite_q && !(sqrtf(dist2f(qx, qy, qz, qs.x, qs.y, qs.z)) < qs.w);
-    if (!__ballot(act)) continue;
-    CorrBest best{kCorrEmpty, kCorrEmpty, -1};
-    float explored2 = 0.f;
-    {
-      // a patch across a jump of the Morton curve is mostly empty space between compact parts: its quarters go through the
-      // rounds one after the other
-      const TileBox box = tile_bounds(act, qx, qy, qz);
-      const TileCells probe = tile_cells(g, grow(box, R1 + tile_eps(box, reach)), kCorrSplitPoints);
-      const int parts = probe.ok ? 1 : 4;
-      for (int part = 0; part < parts; part++) {
-        const bool pact = act && (parts == 1 || (lane >> 4) == part);
-        if (!__ballot(pact)) continue;
-        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats, gscratch[wave_id()]);
-      }
-    }
-    // what the keys could not decide (a tie or near-tie of the two smallest, a box that could not be scanned) is left to the
-    // per-lane search of k_gicp_correspond, which runs next: NaN margin = "not searched"
-    const bool near_tie = best.k2 != kCorrEmpty && ((best.k2 >> kCorrOrdBits) - (best.k1 >> kCorrOrdBits)) <= 1u;
-    const bool left = act && (explored2 == 0.f || near_tie);
-    if (stats) {
-      const unsigned long long mleft = __ballot(left);
-      if (lane == 0) atomicAdd(&stats[7], (unsigned long long)__popcll(mleft));
-    }
-    if (left) {
-      corr[so + i] = -1;
-      qsearch[so + i] = make_float4(qx, qy, qz, __uint_as_float(0x7fc00000u));
-    } else if (act) {
-      NnState stt{INFINITY, -1, INFINITY, explored2, true};
-      if (best.k1 != kCorrEmpty) {
-        const float4 w = g.pts[best.j1];
-        stt.d1 = dist2f(qx, qy, qz, w.x, w.y, w.z);
-        stt.j1 = best.j1;
-        if (best.k2 != kCorrEmpty) stt.d2nd = __uint_as_float(((best.k2 >> kCorrOrdBits) - 1u) << kCorrOrdBits);  // lower edge, one bucket of slack
-      }
-      int j;
-      float margin;
-      finish_search(stt, max_corr_d2, true, j, margin);
-      corr[so + i] = j;
-      qsearch[so + i] = make_float4(qx, qy, qz, margin);
-    }
+  correspond_tiles_of_pair(g, spts + so, n, Tf, corr + so, qsearch + so, max_corr_d2, r1, G, bx, stats, tile_order ? tile_order + so : nullptr,
+                           cand_all[wave_id()], gscratch[wave_id()]);
+}
+
+// pcl::IterativeClosestPoint's correspondence estimation by the same tiles (round 6).  `cur` holds the sources AS MOVED SO FAR, so the
+// pose is the identity; a pair is searched by tiles while its last incremental fit still moved it by more than `min_move` (metres at a
+// 50 m lever arm - every point then needs a new search anyway); afterwards the margins the searches left carry the correspondences
+// (k_icp_step) and this kernel leaves at once.  What the tiles cannot decide (near-ties of their keys, patches whose box they cannot scan,
+// points with nothing within r1 and a reach of tens of metres) is marked "not searched" and goes through k_icp_step's per-lane search.
+__global__ __launch_bounds__(kGicpBlock, 4) void k_icp_correspond_tile(const float4* __restrict__ cur, size_t cpitch, const IcpPairState* __restrict__ state,
+                                                                    const float4* __restrict__ tpts, const int* __restrict__ torig,
+                                                                    const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
+                                                                    size_t tslots, const int* __restrict__ tgt_of_src, int* __restrict__ corr,
+                                                                    float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S, float min_move,
+                                                                    const int* __restrict__ tile_order, size_t opitch) {
+  __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand + 8];
+  __shared__ int gscratch[kGicpBlock / kWave][2 * kWave];
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
+  const IcpPairState& st = state[pair];
+  if (!st.active) return;
+  if (st.iterations > 0) {  // (the first search of a pair is always by tiles)
+    const float tr = sqrtf(st.Tinc[3] * st.Tinc[3] + st.Tinc[7] * st.Tinc[7] + st.Tinc[11] * st.Tinc[11]);
+    const float c = 0.5f * (st.Tinc[0] + st.Tinc[5] + st.Tinc[10] - 1.f);
+    const float ang = sqrtf(fmaxf(2.f * (1.f - c), 0.f));  // ~ the rotation angle of the last fit
+    if (!(tr + 50.f * ang >= min_move)) return;
   }
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
+  const float I[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  const size_t so = (size_t)pair * cpitch;
+  correspond_tiles_of_pair(g, cur + so, st.n, I, corr + so, qsearch + so, max_corr_d2, r1, G, bx, nullptr,
+                           tile_order ? tile_order + (size_t)pair * opitch : nullptr, cand_all[wave_id()], gscratch[wave_id()]);
+}
+void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
+                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch) {
+  const int G = std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cpitch, kGicpBlock)));
+  TimedLaunch tl(KF_CORRESPOND_TILE, s);
+  hipLaunchKernelGGL(k_icp_correspond_tile, dim3(xcd_grid(G, S)), dim3(kGicpBlock), 0, s, cur, cpitch, state, (const float4*)tgt.pts.p, (const int*)tgt.orig.p,
+                     (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, tgt_of_src, corr, qsearch, max_corr_d2, r1, G, S, min_move, tile_order, opitch);
+  MI_LAUNCH_CHECK();
 }
 
 // F4 linearize given the correspondences: Mahalanobis + normal equations, a pure streaming pass — per source point it

@@ -126,6 +126,7 @@ MI_HD void icp_advance(IcpPairState& st, const double* sums, const IcpConsts& c)
     }
   for (int k = 0; k < 16; k++) st.final_T[k] = F[k];
   st.iterations++;
+  st.mse = sums[16] / sums[0];  // (always: `error` of the result describes the correspondences of the LAST iteration, however it ended)
   // DefaultConvergenceCriteria::hasConverged (max_iterations_similar_transforms_ = 0, absolute MSE threshold 1e-12)
   bool done = false;
   if (st.iterations >= c.max_iterations) done = true;
@@ -135,7 +136,6 @@ MI_HD void icp_advance(IcpPairState& st, const double* sums, const IcpConsts& c)
     if (cos_angle >= c.rot_threshold && tr2 <= c.transformation_epsilon) done = true;
   }
   if (!done) {
-    st.mse = sums[16] / sums[0];
     if (fabs(st.mse - st.prev_mse) < 1e-12) done = true;
     else if (fabs(st.mse - st.prev_mse) / st.prev_mse < c.euclidean_fitness_epsilon) done = true;
     else st.prev_mse = st.mse;

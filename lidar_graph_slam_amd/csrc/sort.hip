@@ -142,10 +142,15 @@ __device__ __forceinline__ void tile_geometry(int n, int& nt, int& tl) {
 
 // A cloud of ONE tile is written straight to (keys_final, vals_final) — where the merge rounds would deliver it — and the merge
 // kernels skip it: a voxelised scan costs one launch's worth of traffic, not three.
+// The LAST tile of a cloud with an odd number of tiles (the third of a raw 64 k-point scan) has no partner in the first merge round,
+// which used to copy it: it is written straight to (keys_r1, vals_r1), where that round delivers, and the round skips it (round 6: a third
+// of the first round's traffic).  That may be the buffer the tile's own keys were read from: every thread holds its elements in
+// registers by then, and no other block reads that range.
 // VOXEL: the keys are the voxel indices of the points vpts (VoxelKeySource), computed here - keys_in is not read.
 template <bool VOXEL>
-__global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
+__global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* keys_in, uint32_t* keys_out, int* vals_out,
                                                           uint32_t* __restrict__ keys_final, int* __restrict__ vals_final,
+                                                          uint32_t* keys_r1, int* vals_r1,
                                                           const int* __restrict__ counts, size_t cap, int passes_max,
                                                           const int* __restrict__ seg_passes, const float4* __restrict__ vpts,
                                                           const GridMeta* __restrict__ vmeta, double min_distance) {
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* __rest
   tile_geometry(n, nt, tl);
   if ((int)blockIdx.x >= nt) return;
   if (nt == 1) { keys_out = keys_final; vals_out = vals_final; }
+  else if ((nt & 1) && (int)blockIdx.x == nt - 1) { keys_out = keys_r1; vals_out = vals_r1; }
   const int passes = seg_passes ? min(passes_max, max(1, seg_passes[c])) : passes_max;
   const int base = blockIdx.x * tl;
   const int len = max(0, min(tl, n - base));
@@ -305,6 +311,7 @@ constexpr int kMergeMaxChunks = 8;
 __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out, int* __restrict__ vals_out,
                                                               const int* __restrict__ counts, size_t cap, int run) {
+  // (run == 1: a last tile without a partner is in its place already - k_sort_tile wrote it to this round's output)
   __shared__ uint32_t sk[kMergeChunk + 1];
   __shared__ int sv[kMergeChunk + 1];
   __shared__ int s_a0[kMergeMaxChunks], s_b0[kMergeMaxChunks], s_b1[kMergeMaxChunks], s_d[kMergeMaxChunks][2], s_i[kMergeMaxChunks][2];
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_sort_merge(const uint32_t* __
     bool found = false;
     for (long pa = 0; pa < n; pa += 2 * L) {
       const int len = (int)min((long)n - pa, 2 * L);
-      const long nch = (len + kMergeChunk - 1) / kMergeChunk;
+      const long nch = (run == 1 && pa + L >= n) ? 0 : (len + kMergeChunk - 1) / kMergeChunk;
       if (g < nch) {
         a0 = (int)pa;
         b0 = (int)min((long)n, pa + L);
@@ -418,11 +425,11 @@ void sort_pairs(hipStream_t s, Workspace& ws, int B, size_t cap, const int* d_co
     // after `hops` hops (a -> b -> a ...) the result sits in b when hops is odd
     if (voxel)
       hipLaunchKernelGGL(k_sort_tile<true>, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
-                         (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes, d_passes, voxel->pts,
-                         voxel->vmeta, voxel->min_distance);
+                         (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, ws.keys_a.p, ws.vals_a.p, d_counts, cap, passes, d_passes,
+                         voxel->pts, voxel->vmeta, voxel->min_distance);
     else
       hipLaunchKernelGGL(k_sort_tile<false>, dim3(max_tiles, B), dim3(kTsThreads), 0, s, ws.keys_a.p, ws.keys_b.p, ws.vals_b.p,
-                         (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, d_counts, cap, passes, d_passes,
+                         (hops & 1) ? ws.keys_b.p : ws.keys_a.p, (hops & 1) ? ws.vals_b.p : ws.vals_a.p, ws.keys_a.p, ws.vals_a.p, d_counts, cap, passes, d_passes,
                          (const float4*)nullptr, (const GridMeta*)nullptr, -1.0);
     hops = 1;
     uint32_t* ki = ws.keys_b.p; uint32_t* ko = ws.keys_a.p;

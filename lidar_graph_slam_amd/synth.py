@@ -217,7 +217,7 @@ def cast_job(spec):
 
 def cast_jobs_in_child(jobs, workers: int | None = None):
     """[cast_job(j) for j in jobs], computed by ONE child interpreter that owns the worker pool.  For callers whose own process may
-    have initialised the GPU already (a pytest session): the caller starts a single plain child (python -m ...synth), which never
+    have initialised the GPU already (a pytest session): the caller starts a single plain child (python -m lidar_graph_slam_amd._cast_child), which never
     touches the GPU and is the one that spawns workers; jobs and scans travel through a temporary directory."""
     import pickle
     import subprocess
@@ -229,26 +229,10 @@ def cast_jobs_in_child(jobs, workers: int | None = None):
         with open(os.path.join(d, "jobs.pkl"), "wb") as f:
             pickle.dump(list(jobs), f)
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-        subprocess.run([sys.executable, "-m", "lidar_graph_slam_amd.synth", "--cast-jobs", d] + ([str(workers)] if workers else []),
+        subprocess.run([sys.executable, "-m", "lidar_graph_slam_amd._cast_child", d] + ([str(workers)] if workers else []),
                        check=True, env=env, cwd=root)
         z = np.load(os.path.join(d, "scans.npz"))
         return [z[f"s{i}"] for i in range(len(z.files))]
-
-
-def _cast_jobs_main(argv):
-    import multiprocessing as mp
-    import pickle
-
-    d = argv[0]
-    workers = int(argv[1]) if len(argv) > 1 else max(1, min(64, (os.cpu_count() or 8) - 2))
-    with open(os.path.join(d, "jobs.pkl"), "rb") as f:
-        jobs = pickle.load(f)
-    if workers <= 1:
-        scans = [cast_job(j) for j in jobs]
-    else:
-        with mp.get_context("spawn").Pool(workers) as pool:
-            scans = pool.map(cast_job, jobs, chunksize=4)
-    np.savez(os.path.join(d, "scans.npz"), **{f"s{i}": s for i, s in enumerate(scans)})
 
 
 def trajectory(n: int, *, speed: float = 8.0, hz: float = 10.0, seed: int = 3) -> np.ndarray:
@@ -278,9 +262,3 @@ def random_perturbation(rng: np.random.Generator, max_t: float = 2.0, max_deg: f
     ang = np.deg2rad(rng.uniform(-max_deg, max_deg))
     return se3(t[0], t[1], t[2], 0.0, 0.0, ang)
 
-
-if __name__ == "__main__":
-    import sys
-
-    if len(sys.argv) >= 3 and sys.argv[1] == "--cast-jobs":
-        _cast_jobs_main(sys.argv[2:])

@@ -4,9 +4,7 @@ list) through mi355_multi_batch_register - two and four lanes, all on device 0 (
 per-lane host threads, the per-lane uploads through pinned staging and the gather are those of an 8-GPU node).  Results must be
 those of ONE BatchRegistration on a 256-pair sample, inside the convergence band of the oracle on four pairs, and the acceptance
 rule of graph_based_slam.cpp:321-328 (converged and fitness < score_threshold) must accept what lies near the truth.
-The 832 scans behind the list (64 x 8 candidate scans, 64 x 5 key frames) are ray-cast by a pool of spawned CPU workers."""
-import multiprocessing as mp
-import os
+The 832 scans behind the list (64 x 8 candidate scans, 64 x 5 key frames) are ray-cast by a pool of CPU workers under a child interpreter."""
 import time
 
 import numpy as np
@@ -29,13 +27,6 @@ def _place(c, T):
 
 @pytest.fixture(scope="module")
 def config5():
-    import torch  # torch's ROCm runtime before the library's (INTEGRATION.md): a module-scoped fixture is built BEFORE the
-                  # function-scoped autouse fixture of conftest.py that sees to it, and this one prefilters on the GPU
-
-    if torch.cuda.is_available():
-        torch.cuda.init()
-    from lidar_graph_slam_amd.filters import PointsPreFiltering
-
     length = 20.0 * S + 20.0
     sub_pose = lambda s: synth.se3(20.0 * s, 0.0, 0.0)  # noqa: E731
     true_off = [synth.random_perturbation(np.random.default_rng(1000 + s * 64 + c), 1.0, 2.0) for s in range(S) for c in range(CASTS)]
@@ -45,8 +36,16 @@ def config5():
     cast_of = (np.arange(N) // S) % CASTS
     jobs = [(length, sub_pose(s) @ true_off[s * CASTS + c], 9000 + s * 64 + c, 1024, 30.0) for s in range(S) for c in range(CASTS)]
     jobs += [(length, sub_pose(s) @ synth.se3(1.0 * j, 0.0, 0.0), 500 + 10 * s + j, 1024, 30.0) for s in range(S) for j in range(-2, 3)]
-    with mp.get_context("spawn").Pool(max(1, min(64, (os.cpu_count() or 8) - 2))) as pool:
-        raw = pool.map(synth.cast_job, jobs, chunksize=4)
+    # the 832 scans are cast by ONE plain child interpreter that owns the worker pool and never touches the GPU; this process - which
+    # other tests of the session may have put on the GPU already - starts nothing but that child
+    raw = synth.cast_jobs_in_child(jobs)
+    import torch  # torch's ROCm runtime before the library's (INTEGRATION.md): a module-scoped fixture is built BEFORE the
+                  # function-scoped autouse fixture of conftest.py that sees to it, and this one prefilters on the GPU
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    from lidar_graph_slam_amd.filters import PointsPreFiltering
+
     pre = PointsPreFiltering(leaf_size=0.2, mean_k=0, min_distance_cloud=1.0)
     scans = [pre.callback_sensor_points(r) for r in raw]
     cand = {(s, c): scans[s * CASTS + c] for s in range(S) for c in range(CASTS)}

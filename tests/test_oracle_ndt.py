@@ -161,3 +161,35 @@ def test_ring_trap_is_a_property_of_the_scene_not_of_the_optimiser():
     assert int(np.argmax(prof)) <= 1  # the objective peaks within 0.1 m of the identity
     g = O.gicp_align(s, t, O.gicp_params(), guess=np.eye(4, dtype=np.float32))
     assert synth.pose_error(g["T"], T_gt)[0] < 0.03
+
+
+def test_far_from_the_map_origin_the_fp32_placements_cost_the_pose_an_all_fp64_ndt_keeps_it():
+    """VERDICT r5 item 7 (the claim behind timing config 5 with NDT_OMP on sub-maps near the origin): NDT's pose is (translation, Euler
+    angles about the map ORIGIN) and ndt_omp evaluates the transformed cloud, the point gradients and the per-cell terms in fp32 -
+    the placements oracle_ndt.cpp restates.  The SAME street pair that registers to 4 cm at the origin, placed 1.2 km and 2.4 km out,
+    is left with a residual rotation of ~5e-4 rad by the oracle - 0.6 m and 1.2 m at those lever arms - while the independent
+    all-fp64 NumPy NDT (finite-difference derivatives of its own score, no code shared) still lands within 5 cm: the loss comes
+    with the arithmetic upstream chose, it is not a property of the restated algorithm.  (The HIP path lands where the oracle lands:
+    tests/test_gpu_fullsize.py, tests/test_gpu_loop_closure.py.)"""
+    from oracle import numpy_ref as N
+
+    s, t, T_gt = _ndt_pair(synth.street(60.0), 192, 20.0)
+    P = O.ndt_params(resolution=2.0)
+    got = {}
+    for D in (0.0, 1200.0, 2400.0):
+        W = synth.se3(D, 3.0, 0, 0, 0, 0.3)
+        s2, t2 = O.transform(s, W.astype(np.float32)), O.transform(t, W.astype(np.float32))
+        T_exp = W @ T_gt @ np.linalg.inv(W)
+        r = O.ndt_align(s2, t2, P, guess=np.eye(4, dtype=np.float32))
+        p, _, conv = N.NdtModel(t2, 2.0).align(s2, np.zeros(6))
+        Tn = np.eye(4)
+        Tn[:3, :3] = N.rot_xyz(*p[3:])
+        Tn[:3, 3] = p[:3]
+        assert r["converged"] and conv
+        got[D] = (synth.pose_error(r["T"], T_exp), synth.pose_error(Tn, T_exp))
+    assert got[0.0][0][0] < 0.08 and got[0.0][1][0] < 0.08, got[0.0]  # at the origin both land (NDT's cell-size accuracy)
+    for D in (1200.0, 2400.0):
+        (dt32, dr32), (dt64, dr64) = got[D]
+        assert dt64 < 0.08 and dr64 < 2e-4, (D, dt64, dr64)                   # all-fp64: still there
+        assert dt32 > 0.25 and 2e-4 < dr32 < 2e-3, (D, dt32, dr32)           # fp32 placements: a rotation left over ...
+        assert abs(dt32 - dr32 * D) < 0.35 * dt32, (D, dt32, dr32)            # ... that IS the translation error at this lever arm
