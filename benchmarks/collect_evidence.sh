@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash benchmarks/collect_evidence.sh r05'): everything profiles/README.md cites, written
 # under gpurun_out/<round>/; benchmarks/summarize_evidence.py then distils it into profiles/.
 # rocprofv3 is given the program directly (no env/bash hop) and PMC passes carry --kernel-trace only.
-R=${1:-r05}
+R=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
@@ -41,6 +41,12 @@ done
 timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 8 --method NDT_OMP --min-good 0.8 2> "$O/config5_NDT_OMP.err" | tail -1 > "$O/config5_NDT_OMP.json"
 # (pclomp's BFGS GICP: the same parametrisation; 1 - 2 cm at <= 40 m from the origin, 0.3 m at 80 m in the oracle itself: 4 sub-maps)
 timeout 900 python benchmarks/config5.py --candidates 4096 --submaps 4 --method GICP 2> "$O/config5_GICP.err" | tail -1 > "$O/config5_GICP.json"
+# kernel-level rows of the two engines batched in round 5 (missing 1): rocprofv3 kernel stats of the same commands, and the
+# search kernel's launches in launch order
+bash benchmarks/config5_trace.sh $R/c5trace_ICP ICP --candidates 4096 --submaps 64 --repeats 1 --no-cpu-baseline > "$O/c5trace_ICP.log" 2>&1
+bash benchmarks/config5_trace.sh $R/c5trace_GICP GICP --candidates 4096 --submaps 4 --repeats 1 --no-cpu-baseline > "$O/c5trace_GICP.log" 2>&1
+# every kernel of the bench step BY ITSELF (one part, chains serialised): the per-kernel own durations of the prefilter / index chain
+bash benchmarks/serial_trace.sh $R/serial > "$O/serial.log" 2>&1
 # k_knn_cov_tile's own counters (the STATS instantiation) for profiles/<round>_knn_tile_counters.txt
 MI355_KNN_STATS=1 timeout 600 python bench.py --pairs 512 --steps 1 --warmup 1 --no-cpu-baseline --no-h2d > /dev/null 2> "$O/knn_stats.err"
 # ---- NDT, the front end's default engine: its own bench line and profile

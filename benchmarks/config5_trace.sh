@@ -3,7 +3,7 @@
 # Usage: bash benchmarks/config5_trace.sh <out-name> <METHOD> [config5 args]
 NAME=$1; METHOD=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out; rm -rf /tmp/c5_$NAME
+mkdir -p gpurun_out "$(dirname gpurun_out/$NAME)" "$(dirname /tmp/c5_$NAME)"; rm -rf /tmp/c5_$NAME
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c5_$NAME -- python3 benchmarks/config5.py --method $METHOD "$@" 2> gpurun_out/${NAME}.err | tail -1 > gpurun_out/${NAME}.json
 f=$(ls /tmp/c5_$NAME/*/*_kernel_stats.csv | tail -1)
 cp "$f" gpurun_out/${NAME}_kernel_stats.csv

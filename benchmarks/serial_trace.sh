@@ -4,7 +4,7 @@
 # Usage: bash benchmarks/serial_trace.sh [out-name] [bench args]   (MI355_LIB=<variant .so> selects a library build)
 NAME=${1:-serial}; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out
+mkdir -p gpurun_out "$(dirname gpurun_out/$NAME)" "$(dirname /tmp/st_$NAME)"
 export MI355_BATCH_SIDE_STREAMS=0 MI355_BATCH_PARTS=1
 rm -rf /tmp/st_$NAME
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$NAME -- python3 bench.py --pairs 2048 --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-kernel-timing "$@" > gpurun_out/${NAME}_bench.json 2> gpurun_out/${NAME}_trace.err

@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 PAIRS = 4096
 SRC = os.path.join(ROOT, "gpurun_out", R)
 DST = os.environ.get("EVIDENCE_DST") or os.path.join(ROOT, "profiles")  # on the GPU box: a small directory under gpurun_out/ (the raw traces stay there)
@@ -118,6 +118,13 @@ def main():
             with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:
                 f.write(json.dumps(last_json(p)) + "\n")
     shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(DST, f"{R}_kernel_stats_bench_default.csv"))
+    for src_name, dst_name in (("c5trace_ICP_kernel_stats.csv", "kernel_stats_icp.csv"), ("c5trace_GICP_kernel_stats.csv", "kernel_stats_bfgs.csv"),
+                               ("c5trace_ICP_launches.txt", "icp_launches.txt"), ("c5trace_GICP_launches.txt", "bfgs_launches.txt"),
+                               ("c5trace_ICP.json", "config5_ICP_under_trace.json"), ("c5trace_GICP.json", "config5_GICP_under_trace.json"),
+                               ("serial_kernel_stats.csv", "kernel_stats_serial_2048pairs.csv"), ("serial_bench.json", "bench_serial_one_part_under_trace.json")):
+        pth = os.path.join(SRC, src_name)
+        if os.path.exists(pth):
+            shutil.copy(pth, os.path.join(DST, f"{R}_{dst_name}"))
     for txt in ("other_configs", "single_pair", "stream_profile"):
         oc = os.path.join(SRC, txt + ".txt")
         if os.path.exists(oc):

@@ -37,6 +37,7 @@ const Tuning& tuning() {
     geti("MI355_KNN_TILES", v.knn_tiles);
     geti("MI355_KNN_NEED_DIV", v.knn_need_div);
     geti("MI355_TILE_WAVES", v.tile_waves);
+    geti("MI355_HARD_WAVES", v.hard_waves);
     getf("MI355_TILE_RSCALE", v.tile_rscale);
     geti("MI355_TILE_ORDER", v.tile_order);
     getf("MI355_TILE_GATHER", v.tile_gather);

@@ -1571,7 +1571,7 @@ static void launch_covariances(hipStream_t s, CloudSet& set, int k, int method, 
                        tile_order ? tn.tile_gather : 1.0f, tile_order);
   }
   // the points the tile kernel handed over: one wave per point, covariance included
-  const int Gh = std::max(64, std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
+  const int Gh = std::max(std::max(1, tn.hard_waves), std::min(4096 / std::max(set.B, 1), div_up((long)set.cap, kWave)));  // a lone big cloud gets thousands of waves
   TimedLaunch tl(KF_KNN_HARD, s);
   hipLaunchKernelGGL((k_knn_hard<K, SOR>), dim3(xcd_grid(Gh, set.B)), dim3(kWave), 0, s, set.pts.p, set.orig.p, set.table.p, set.meta.p, set.cov.p,
                      mean_dist, (const int*)set.fbq.p, (const float*)set.fbhint.p, (const int*)set.fbn.p, set.cap, set.slots_cap, k, method, Gh, set.B);

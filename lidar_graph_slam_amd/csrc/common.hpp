@@ -98,6 +98,7 @@ struct Tuning {
                               //                         every point (k_knn_self).  (Round 3's LDS cell bricks, measured slower, live in git history only.)
   int knn_need_div = 2;       // MI355_KNN_NEED_DIV      start level heuristic of the per-lane search
   int tile_waves = 8192;      // MI355_TILE_WAVES        resident one-wave blocks of k_knn_cov_tile over the batch
+  int hard_waves = 64;        // MI355_HARD_WAVES        one-wave blocks of k_knn_hard per cloud of a batch (a lone big cloud gets thousands)
   int tile_order = 1;         // MI355_TILE_ORDER        1 = batches take the tiles of k_knn_cov_tile along a Hilbert curve (one more sort per cloud), 0 = along the voxel hash's Morton order, 2 = single clouds too (tests)
   float tile_rscale = 1.0f;   // MI355_TILE_RSCALE       first radius of a tile as a multiple of its density estimate
   float tile_gather = 1.25f;  // MI355_TILE_GATHER       first gather radius of a k-NN tile as a multiple of what its sub-tiles ask for, when the tiles follow build_tile_order (along the Morton order a wider gather was measured slower: 1.0)

@@ -141,6 +141,23 @@ MI_HD bool smallest_eigenvector_sym3(const Sym3<double>& cv, double n[3]) {
   const double pm = ((third - 1.0) * third + m) * third - d;
   const bool small_sep = pm > 0.0;
   double l = small_sep ? 0.0 : 1.0;
+  {
+    // Warm start (round 6): the first Newton steps in fp32 - an fp64 step costs ~35 instructions, most of them the division, and the
+    // covariance epilogue of k_knn_cov_tile ran 6 - 10 of them per point.  From outside the spectrum the iteration is monotone (p is
+    // concave below 1/3 and convex above: the tangent's root lies on the starting side of the polynomial's), so in exact arithmetic it
+    // never passes the root; fp32 rounding may, by ~1e-7 relative, and the result is moved back OUT by 1e-5 relative before the fp64
+    // iteration takes over - still monotone, now within 1e-5 of the root it converges to as before (|step| <= 2e-17).
+    const float mf = (float)m, df = (float)d;
+    float lf = small_sep ? 0.f : 1.f;
+    for (int it = 0; it < 6; it++) {
+      const float p = ((lf - 1.f) * lf + mf) * lf - df;
+      const float dp = (3.f * lf - 2.f) * lf + mf;
+      if (dp == 0.f) break;
+      lf -= p / dp;
+    }
+    const float back = small_sep ? lf * (1.f - 1e-5f) : lf * (1.f + 1e-5f);
+    if (back >= 0.f && back <= 1.f) l = (double)back;  // (NaN or an escape from [0, 1]: the cold start)
+  }
   for (int it = 0; it < 24; it++) {
     const double p = ((l - 1.0) * l + m) * l - d;
     const double dp = (3.0 * l - 2.0) * l + m;
