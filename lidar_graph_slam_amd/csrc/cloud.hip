@@ -523,46 +523,13 @@ __global__ __launch_bounds__(kHbThreads) void k_hash_build(const float4* __restr
       if (l <= lt) image[h].z = i + 1;
     }
   };
-  // (keep) which probe block each cell of an element lives in, 4 bits per level, once: the walk of a probe block then tests bits and
-  // computes a hash only for the cells it enters (hashing every cell again for every probe block was a third of the kernel)
-  uint32_t blk_[kHbKeep];
-  if (keep) {
-#pragma unroll
-    for (int j = 0; j < kHbKeep; j++) {
-      uint32_t b = 0;
-#pragma unroll
-      for (int l = 0; l <= kMaxLevel; l++) b |= (hash_slot(level_key(key_[j], l), hs.hshift) >> kProbeBlockLog) << (4 * l);
-      blk_[j] = b;
-      // levels above the table's top are not entered
-      const int lh = min((int)(lev_[j] & 15u) - 1, hs.top), lt = min((int)(lev_[j] >> 4) - 1, hs.top);
-      lev_[j] = (uint32_t)(lh + 1) | ((uint32_t)(lt + 1) << 4);
-    }
-  }
-  static_assert(65536 * 2 / kProbeBlock <= 16, "4 bits per level hold the probe block of a cell (hash_build_in_blocks: cap <= 65536)");
   for (uint32_t q = 0; q < pieces; q++) {
     for (uint32_t z = tid; z < psize; z += kHbThreads) image[z] = make_int4((int)kEmptyKey, 0, 0, 0);
     __syncthreads();
     if (keep) {
 #pragma unroll
-      for (int j = 0; j < kHbKeep; j++) {
-        const int lh = (int)(lev_[j] & 15u) - 1, lt = (int)(lev_[j] >> 4) - 1;
-        uint32_t todo = 0;  // the levels of element j whose cell lies in probe block q
-#pragma unroll
-        for (int l = 0; l <= kMaxLevel; l++) todo |= (l <= max(lh, lt) && ((blk_[j] >> (4 * l)) & 15u) == q) ? (1u << l) : 0u;
-        while (todo) {
-          const int l = __ffs(todo) - 1;
-          todo &= todo - 1;
-          const uint32_t K = level_key(key_[j], l);
-          uint32_t h = hash_slot(K, hs.hshift) & hs.pmask;
-          for (;;) {
-            const uint32_t prev = atomicCAS(reinterpret_cast<uint32_t*>(&image[h].x), kEmptyKey, K);
-            if (prev == kEmptyKey || prev == K) break;
-            h = (h + 1u) & hs.pmask;
-          }
-          if (l <= lh) image[h].y = tid + j * kHbThreads;
-          if (l <= lt) image[h].z = tid + j * kHbThreads + 1;
-        }
-      }
+      for (int j = 0; j < kHbKeep; j++)
+        if (lev_[j]) enter(q, tid + j * kHbThreads, key_[j], (int)(lev_[j] & 15u) - 1, (int)(lev_[j] >> 4) - 1);
     } else {
       for (int i = tid; i < n; i += kHbThreads) {
         const uint32_t key = k[i];
