@@ -175,7 +175,7 @@ def main():
     conv = np.asarray(res["converged"]) != 0
     n_src = np.asarray(res["n_source"]).astype(np.int64)
     n_tgt = np.asarray(res["n_target"]).astype(np.int64)
-    evals = np.asarray(res["n_inliers"]).astype(np.int64)  # NDT: evaluations (passes over the source) of the pair
+    evals = np.asarray(res["evaluations"]).astype(np.int64)  # passes over the source the pair asked for
     ok_truth = (errs[:, 0] < 0.30) & (errs[:, 1] < 2e-2)
     oracle = None
     if not args.no_oracle:
@@ -303,7 +303,7 @@ def main():
         line["config3"] = {"target_points": int(len(sub)), "source_points": int(len(scan)), "cells_m": 1.0,
                            "set_target_from_host_ms(median,min)": t_host, "set_target_device_cloud_ms(median,min)": t_dev,
                            "align_ms(median,min)": t_align, "iterations": int(ndt.result["iterations"]),
-                           "evaluations": int(ndt.result["n_inliers"]),
+                           "evaluations": int(ndt.result["evaluations"]),
                            "pose_err_vs_truth": synth.pose_error(ndt.getFinalTransformation(), c3_true)}
     print(json.dumps(line, default=lambda o: list(o) if isinstance(o, tuple) else float(o)))
 

@@ -23,9 +23,11 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning: 2 = mi355_pointcloud2 gained
  * `data_size` (mandatory) and a non-FLOAT32 intensity field is ignored as pcl::fromROSMsg ignores it; 3 = mi355_batch_diagnostics,
- * mi355_multi_lane_allocations, mi355_multi_batch_register_clouds, mi355_batch_set_*_views; 4 = mi355_reg_gicp_trial_cost (additions only).
+ * mi355_multi_lane_allocations, mi355_multi_batch_register_clouds, mi355_batch_set_*_views; 4 = mi355_reg_gicp_trial_cost (additions only);
+ * 5 = mi355_result gained `evaluations` (+ a reserved word: 392 -> 400 bytes; n_inliers is an inlier count again for every engine) and
+ * mi355_batch_get_cloud was added.
  * mi355_abi_version() returns the library's: a caller compares it with the MI355_ABI_VERSION it was compiled against. */
-#define MI355_ABI_VERSION 4
+#define MI355_ABI_VERSION 5
 int mi355_abi_version(void);
 
 #define MI355_OK 0
@@ -130,9 +132,12 @@ typedef struct mi355_result {
   double trans_probability; /* NDT */
   int n_source;             /* source points actually registered (after any prefilter) */
   int n_target;
-  int n_inliers;            /* GICP: correspondences within max_correspondence_distance at the last linearisation;
-                               NDT: evaluations (computeDerivatives / computeHessian passes over the source) the pair asked for */
+  int n_inliers;            /* FAST_GICP / GICP: correspondences within max_correspondence_distance at the last linearisation /
+                               evaluation; 0 for NDT and ICP */
   int status;               /* batch mode: MI355_PAIR_OK, or why the pair was not registered (T = the guess, converged = 0) */
+  int evaluations;          /* NDT: computeDerivatives / computeHessian passes over the source the pair asked for; GICP: cost
+                               evaluations of the BFGS line searches; 0 for the other engines (ABI 5) */
+  int reserved;
 } mi355_result;
 #define MI355_PAIR_OK 0
 #define MI355_PAIR_TOO_FEW_POINTS 1 /* source or target holds fewer than k_correspondences points after the prefilter
@@ -357,7 +362,7 @@ int mi355_batch_set_stream(mi355_batch* batch, void* hip_stream, int use_context
  * once: targets by descending pair count (ties: lower target id), each to the least-loaded lane (ties: lower lane) — the rule
  * of lidar_graph_slam_amd/sharding.py, whose torchrun form (one process per GPU, results all-gathered over RCCL) produces the
  * same partition.  Here the process is one, so the only exchange step between lanes — the fixed-size mi355_result
- * records, 392 bytes per pair — is a D2H copy per lane; every lane is driven by its own host thread.  (This host-view entry point
+ * records, 400 bytes per pair — is a D2H copy per lane; every lane is driven by its own host thread.  (This host-view entry point
  * also uploads every source and target cloud of the call to its lane; callers whose clouds are device-resident use
  * mi355_multi_context + mi355_cloud_* + mi355_multi_batch_register_clouds and pay that once.)  No pair crosses lanes: results are those of a single batch, pair for pair. */
 typedef struct mi355_multi mi355_multi;

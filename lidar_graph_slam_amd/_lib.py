@@ -102,6 +102,8 @@ class Result(C.Structure):
         ("n_target", C.c_int),
         ("n_inliers", C.c_int),
         ("status", C.c_int),
+        ("evaluations", C.c_int),
+        ("reserved", C.c_int),
     ]
 
     def to_dict(self):
@@ -116,6 +118,7 @@ class Result(C.Structure):
             "n_target": int(self.n_target),
             "n_inliers": int(self.n_inliers),
             "status": int(self.status),
+            "evaluations": int(self.evaluations),
         }
 
 
@@ -151,7 +154,7 @@ EXPORTS_LOOP_CLOSURE = [
 # mi355_result as a NumPy record (same layout as `Result`): BatchRegistration.results(raw=True) hands the C array over without
 # building a dict per pair
 RESULT_DTYPE = np.dtype([("T", np.float32, (4, 4)), ("converged", np.int32), ("iterations", np.int32), ("error", np.float64), ("H", np.float64, (6, 6)),
-                         ("trans_probability", np.float64), ("n_source", np.int32), ("n_target", np.int32), ("n_inliers", np.int32), ("status", np.int32)],
+                         ("trans_probability", np.float64), ("n_source", np.int32), ("n_target", np.int32), ("n_inliers", np.int32), ("status", np.int32), ("evaluations", np.int32), ("reserved", np.int32)],
                         align=True)
 
 

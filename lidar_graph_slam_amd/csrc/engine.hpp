@@ -273,7 +273,7 @@ void ndt_solver_destroy(NdtSolver*);
 // src: [P][src_pitch] points (any order), counts on the device, none above max_count.  Blocks until every pair is done.
 void ndt_solve(hipStream_t s, NdtTargets& t, NdtSolver& sv, int P, const float4* d_src, size_t src_pitch, const int* d_src_counts, int max_count,
                const int* tgt_of_src_host, const float* guesses_host, const mi355_ndt_params& p);
-// out[i].n_inliers = the evaluations (passes over the source) pair i asked for
+// out[i].evaluations = the passes over the source pair i asked for
 void ndt_solver_results(NdtSolver& sv, mi355_result* out, float* T16_all);
 int ndt_solver_rounds(const NdtSolver& sv);
 // parity probe: computeDerivatives of one source against target 0 at the pose p6

@@ -367,6 +367,7 @@ void bfgs_batch_results(BfgsBatch& b, mi355_result* out, float* T16_all) {
       o.n_source = st.n;
       o.n_target = st.n_target;
       o.n_inliers = st.n_inliers;
+      o.evaluations = st.evaluations;
     }
     if (T16_all) memcpy(T16_all + (size_t)i * 16, T, sizeof(T));
   }

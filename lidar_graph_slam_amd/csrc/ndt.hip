@@ -1011,7 +1011,7 @@ void ndt_solver_results(NdtSolver& sv, mi355_result* out, float* T16_all) {
       o.trans_probability = r.trans_probability;
       o.n_source = r.n;
       o.n_target = r.n_target;
-      o.n_inliers = r.evaluations;
+      o.evaluations = r.evaluations;
     }
     if (T16_all) memcpy(T16_all + (size_t)i * 16, r.T, 16 * sizeof(float));
   }

@@ -387,7 +387,7 @@ class BatchRegistration:
 
     def results(self, with_fitness=False, raw=False):
         """Synchronises and returns the n_sources results: a list of dicts, or (raw=True) ONE NumPy record array over the C structs
-        (fields T [4,4], converged, iterations, error, H [6,6], trans_probability, n_source, n_target, n_inliers, status) - what a
+        (fields T [4,4], converged, iterations, error, H [6,6], trans_probability, n_source, n_target, n_inliers, status, evaluations) - what a
         caller in a loop wants: building 1 024 dicts costs milliseconds of host time with the GPU idle."""
         res = (L.Result * self.n_sources)()
         fit = np.empty(self.n_sources) if with_fitness else None
