@@ -55,6 +55,9 @@ bash benchmarks/ndt_evidence.sh $R > "$O/ndt_evidence.log" 2>&1
 rm -f gpurun_out/parity_deltas.jsonl
 timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > "$O/pytest_gpu.txt" 2>&1
 # distil on the box (the raw rocprofv3 output is hundreds of MB; gpurun copies back at most 64 MiB) and drop the raw traces
-EVIDENCE_DST="$O/profiles" python benchmarks/summarize_evidence.py $R > "$O/summarize.log" 2>&1
-rm -rf "$O/trace" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq1" "$O/pmc_sq2"
+if EVIDENCE_DST="$O/profiles" python benchmarks/summarize_evidence.py $R > "$O/summarize.log" 2>&1; then
+  rm -rf "$O/trace" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq1" "$O/pmc_sq2"
+else
+  echo "summarize_evidence.py FAILED: the raw traces stay under $O (too large to travel back: fix and re-run on a box)"
+fi
 du -sh "$O"; ls "$O" "$O/profiles"; tail -n 3 "$O"/*.err | tail -60; tail -5 "$O/pytest_gpu.txt"; cat "$O/summarize.log" | tail -5

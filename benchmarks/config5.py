@@ -221,13 +221,13 @@ def main():
                     r_ = O.icp_align(src_c, tgt_c, O.icp_params(max_iterations=100, max_correspondence_distance=30.0, transformation_epsilon=1e-8, euclidean_fitness_epsilon=1e-6, num_threads=threads))
                 else:
                     r_ = O.gicp_bfgs_align(src_c, tgt_c, O.gicp_bfgs_params(max_iterations=100, max_correspondence_distance=2.0, max_optimizer_iterations=20,
-                                                                             transformation_epsilon=0.01, euclidean_fitness_epsilon=1e-8, num_threads=threads))
+                                                                             transformation_epsilon=0.01, num_threads=threads))
                 O.fitness(src_c, tgt_c, r_["T"])
                 tc += time.perf_counter() - tc0
                 worst = max(worst, float(S_.pose_error(out["T"][p_], r_["T"])[0]))
             cpu = {"value": round(len(sample) / tc, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
                    "sample": f"candidates {sample} of this list through oracle/liboracle.so ({args.method}: target set-up + align + fitness per candidate, {threads} OpenMP threads - the reference's "
-                             f"configuration) in {tc:.1f} s", "gpu_vs_cpu_pose_dt_m_max": round(worst, 6)}
+                             f"configuration) in {tc:.1f} s", "gpu_vs_cpu_pose_dt_m_max": round(worst, 9)}
         line = {
             "config": "BASELINE configs[4]: loop-closure batch, candidates sharded by sub-map over the ranks, results all-gathered",
             "n_gpus": world, "backend": backend if world > 1 else "single process", "collective_ranks": dist.get_world_size() if world > 1 else 1,

@@ -220,13 +220,19 @@ def main():
 
     by = []
     name, ms, nl, mt = fam("k_ndt_derivatives")
-    # COMPULSORY bytes of the derivative pass: the 16-byte source point per evaluation + every leaf of a launch's targets ONCE per launch (a
-    # leaf holds >= 6 target points - min_points_per_voxel - so at most 48 B per 6 target points; neighbouring points share their leaves
-    # and find them in L2).  SURVEY 8d's 268 B per point and evaluation (16 + 7 cells x 36) prices every leaf as if it came from HBM for
+    # COMPULSORY bytes of the derivative pass: the 16-byte source point per evaluation + every leaf of a launch's targets ONCE per launch
+    # (neighbouring points share their leaves and find them in L2).  SURVEY 8d's 268 B per point and evaluation (16 + 7 cells x 36) prices every leaf as if it came from HBM for
     # every point: by that figure the kernel "achieves" more than the HBM peak - kept below as `survey_pricing`, never as the fraction.
-    bytes_deriv = 16.0 * float((evals * n_src).sum()) + nl * 48.0 / 6.0 * float(n_tgt.sum())
-    by.append(row(name, nl, ms, mt, bytes_deriv, "16 B per source point and evaluation + <= 48 B per 6 target points and launch (the leaves, once per launch); "
-                                                   "evaluations per pair: mean %.2f" % float(evals.mean())))
+    # leaves per target: the voxels holding >= 6 points (min_points_per_voxel), counted on the host for a few targets of the batch
+    leaves = []
+    for p in sorted({0, P // 3, (2 * P) // 3, P - 1}):
+        tg = tgt_d[p, : counts_t[p], :3].cpu().numpy()
+        _, cnts = np.unique(np.floor(tg / np.float32(args.resolution)).astype(np.int64), axis=0, return_counts=True)
+        leaves.append(int((cnts >= 6).sum()))
+    leaves_per_target = float(np.mean(leaves))
+    bytes_deriv = 16.0 * float((evals * n_src).sum()) + nl * 48.0 * leaves_per_target * P
+    by.append(row(name, nl, ms, mt, bytes_deriv, "16 B per source point and evaluation + the 48-byte leaves of the launch's targets once per launch (%.0f leaves per target: "
+                                                   "the voxels with >= 6 points, counted on %d of the targets); evaluations per pair: mean %.2f" % (leaves_per_target, len(leaves), float(evals.mean()))))
     survey_bytes = 268.0 * float((evals * n_src).sum())
     by[0]["survey_pricing"] = {"bytes_per_unit": "268 B per source point and evaluation (16 + 7 cells x 36: SURVEY 8d)", "algorithmic_bytes_per_step": int(survey_bytes),
                                "achieved_GBs_if_all_of_it_came_from_hbm": round(survey_bytes / (ms * 1e-3) / 1e9, 1) if ms else None,

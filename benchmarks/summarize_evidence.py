@@ -115,8 +115,13 @@ def main():
                  "config5_ICP", "config5_GICP", "bench_sor", "bench_1024pairs", "bench_2048pairs"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p):
+            try:
+                line = last_json(p)
+            except (IndexError, ValueError):
+                print("no JSON line in", p, "- that leg failed (see its .err)")
+                continue
             with open(os.path.join(DST, f"{R}_{name}.json"), "w") as f:
-                f.write(json.dumps(last_json(p)) + "\n")
+                f.write(json.dumps(line) + "\n")
     shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(DST, f"{R}_kernel_stats_bench_default.csv"))
     for src_name, dst_name in (("c5trace_ICP_kernel_stats.csv", "kernel_stats_icp.csv"), ("c5trace_GICP_kernel_stats.csv", "kernel_stats_bfgs.csv"),
                                ("c5trace_ICP_launches.txt", "icp_launches.txt"), ("c5trace_GICP_launches.txt", "bfgs_launches.txt"),

@@ -125,8 +125,8 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
 HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel with nothing beside it (the rocprofv3-agreeing duration);
 "timed region" = brackets on the two concurrent preparation streams (they overlap: their sum exceeds the step).
 
-| kernel family | launches/step | own: ms per launch | × launches = ms/step | frac of HBM peak, own (algorithmic bytes) | timed-region bracket ms/step | note |
-|---|---|---|---|---|---|---|
+| kernel family | launches/step | own: ms per launch | × launches = ms/step | frac of HBM peak, own (algorithmic bytes) | valu_issue_frac (`{R}_issue.json`) | timed-region bracket ms/step | note |
+|---|---|---|---|---|---|---|---|
 """
     order = sorted(rf["by_kernel"].items(), key=lambda kv: -kv[1].get("isolated_avg_launch_ms", kv[1]["avg_launch_ms"]) * kv[1]["launches_per_step"])
     total_own = 0.0
@@ -134,8 +134,11 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
         frac = v.get("isolated_frac_of_hbm_peak")
         iso = v.get("isolated_avg_launch_ms", v["avg_launch_ms"])
         total_own += iso * v["launches_per_step"]
+        kname = {"sort_pairs": "k_sort_tile", "hash_build": "k_hash_build"}.get(name.split("(")[0], name.split("(")[0])
+        vi = issue["kernels"].get(kname, {}).get("valu_issue_frac")
         out += (f"| `{name}` | {v['launches_per_step']:.0f} | {iso:.3f} | {iso * v['launches_per_step']:.2f} | "
-                + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + f" | {v['total_ms_per_step']:.2f} | {NOTES.get(name, '')} |\n")
+                + (f"{frac:.4f} ({v['bytes_per_unit']})" if frac is not None else "–") + " | " + (f"{vi:.2f}" + (" (`k_sort_tile`)" if kname == "k_sort_tile" else "") if vi is not None else "–")
+                + f" | {v['total_ms_per_step']:.2f} | {NOTES.get(name, '')} |\n")
     out += (f"\nSum of the own durations: {total_own:.1f} ms against {b['ms_per_step']:.1f} ms per step.  The families above leave out the small kernels (keys, scans, bounds, copies: "
             f"see the kernel-stats CSV); what makes the step SHORTER than the sum is the pipeline inside the batch - its parts' preparation chains and LM loops run on "
             f"internal streams and fill each other's tails (DESIGN §2; with the chains serialised the step is the last line of this paragraph).\n")
@@ -221,6 +224,9 @@ HIP-event totals per kernel family (`roofline.by_kernel`).  "own" = the kernel w
     if ndt:
         k = {x["kernel"].split("(")[0]: x for x in ndt["by_kernel"]}
         d = k["k_ndt_derivatives"]
+        if not ndt["roofline"].get("valu_issue_frac"):
+            ni = maybe("ndt_issue") or {"kernels": {}}
+            ndt["roofline"]["valu_issue_frac"] = ni["kernels"].get("k_ndt_derivatives", {}).get("valu_issue_frac")
         c3n = ndt.get("config3") or {}
         out += f"""
 ## NDT_OMP — the front end's configured default engine (`lidar_scan_matcher.param.yaml:4`)

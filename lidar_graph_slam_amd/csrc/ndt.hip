@@ -560,14 +560,16 @@ struct NdtPassParams {
 
 // computeDerivatives (N3) of the points block `block` of `nblocks` strides over; its 28 sums go to partials_row[0..27].
 //
-// LDS-STAGED VOXEL CELLS.  The first version had every lane probe the hash seven times and fetch its (up to seven) leaves from
-// global memory: 7 + 21 scattered vector loads per point, and the counters showed the kernel waiting on the CU's texture-address
-// path (VALU issue 19 %, waiting 63 %, HBM traffic = the source points alone: the leaves came from L2 all along).  The 64 points
-// of a wave are neighbours in space (the sources of a batch are in the voxel hash's Morton order), so their DIRECT7 neighbourhoods
-// overlap almost entirely: the wave takes the box of its points' voxels grown by one voxel, lane c probes the hash for box cell c
-// and copies that leaf into slot c of the wave's LDS image (<= kNdtSlots cells, two passes), and every lane then reads its seven
-// cells from LDS — two dependent global loads per WAVE instead of per lane.  A wave whose points are spread too far for the image
-// (a caller-order scan, the far field) takes the per-lane path.  Same arithmetic either way: the leaf bytes are the same.
+// WHERE THE LEAVES COME FROM.  The kernel that runs (NDT_STAGED = 0, the default) has every lane probe the hash for its seven DIRECT7
+// voxels - all seven probes in flight - and fetch its (up to seven) 48-byte leaves itself.  The 64 points of a wave are neighbours in
+// space (the sources of a batch are in the voxel hash's Morton order), so their neighbourhoods overlap almost entirely and the leaves
+// come from L2: the counters have the HBM traffic of a launch at the source points alone, and the kernel bound by VALU issue
+// (valu_issue_frac 0.70: profiles/r06_ndt_issue.json).
+// The alternative behind NDT_STAGED = 1 - kept as an A/B build only - stages a wave's cells in LDS: the wave takes the box of its
+// points' voxels grown by one voxel, lane c probes the hash for box cell c and copies that leaf into slot c of the wave's LDS image
+// (<= kNdtSlots cells, two passes), and every lane reads its seven cells from there - two dependent global loads per WAVE instead of
+// per lane.  Built in round 5 and measured 24 % SLOWER than the per-lane loads (profiles/r05_ndt_variants.txt): the image costs more
+// instructions than the L2 hits it replaces.  Same arithmetic either way: the leaf bytes are the same.
 constexpr int kNdtSlots = 128;  // cells of a wave's LDS image (48 B each; the image shares the wave's reduction scratch)
 static_assert(kNdtSlots * 48 <= kWave * kBlockSumRow * 8, "the LDS image of a wave fits the scratch of its reduction");
 

@@ -76,3 +76,53 @@ def test_batch_icp_matches_single_and_oracle(R, small_pair, max_iterations):
     for i in (0, 1, 4):
         np.testing.assert_array_equal(np.asarray(res2[i]["T"]), np.asarray(res[i]["T"]))
     b.close()
+
+
+def test_batch_icp_and_fitness_on_sparse_targets_with_fewer_hash_levels(R):
+    """a sparse target (points ~9 m apart: every point alone in its cell at the fine levels) makes the device-sized voxel hash
+    keep fewer coarse levels, so ICP's 30 m correspondence search and the fitness query walk fine cells shell by shell - and since round
+    6 the first iterations go through the wave-cooperative tiles, whose boxes then hold hundreds of cells.  Twelve pairs (>= 8: the tile
+    path), fixed iteration count: iteration by iteration the oracle's poses, the oracle's fitness - and the batch must not take seconds."""
+    import time
+
+    rng = np.random.default_rng(91)
+    nT, nS, n = 3, 12, 3000
+    cap = n + 5
+    tgts = np.zeros((nT, cap, 4), np.float32)
+    for j in range(nT):
+        tgts[j, :n, :3] = rng.uniform([-125, -125, -20], [125, 125, 20], (n, 3))
+    srcs = np.zeros((nS, cap, 4), np.float32)
+    ns, tgt_of_src, truth = [], [], []
+    for i in range(nS):
+        j = i % nT
+        m = n - 37 * i
+        pick = rng.choice(n, m, replace=False)
+        Tt = synth.se3(0.4 + 0.05 * i, -0.3, 0.1, 0.0, 0.0, 0.004 * (i + 1))
+        src = O.transform(tgts[j, pick], np.linalg.inv(Tt).astype(np.float32))
+        src[:, :3] += rng.normal(0, 0.01, (m, 3)).astype(np.float32)
+        srcs[i, :m] = src
+        ns.append(m)
+        tgt_of_src.append(j)
+        truth.append(Tt)
+    kw = dict(max_iterations=8)
+    b = R.BatchRegistration(nS, nT, cap, method="ICP", **kw)
+    b.set_targets(tgts, [n] * nT)
+    b.set_sources(srcs, ns)
+    b.align(tgt_of_src, with_fitness=True)
+    b.results(with_fitness=True)  # (warm: allocations)
+    t0 = time.perf_counter()
+    b.set_targets(tgts, [n] * nT)
+    b.set_sources(srcs, ns)
+    b.align(tgt_of_src, with_fitness=True)
+    res, fit = b.results(with_fitness=True)
+    seconds = time.perf_counter() - t0
+    for i in range(nS):
+        si, ti = srcs[i, : ns[i]], tgts[tgt_of_src[i], :n]
+        ref = O.icp_align(si, ti, O.icp_params(**kw))
+        dt, dr = synth.pose_error(res[i]["T"], ref["T"])
+        assert res[i]["iterations"] == ref["iterations"] and dt <= 2e-5 and dr <= 2e-6, (i, dt, dr)
+        assert synth.pose_error(res[i]["T"], truth[i])[0] < 0.05
+        np.testing.assert_allclose(fit[i], O.fitness(si, ti, res[i]["T"]), rtol=1e-6)
+    assert seconds < 1.0, seconds  # (a performance cliff here would be seconds: 12 pairs x 8 iterations x 3 000 points)
+    print(f"sparse-target ICP batch: {seconds * 1e3:.1f} ms")
+    b.close()
