@@ -463,7 +463,7 @@ def main():
         if ij.get("pairs") != P:
             continue
         for fam_name, e in by_kernel.items():
-            hit = ij["kernels"].get(fam_name.split("(")[0])
+            hit = ij["kernels"].get({"sort_pairs": "k_sort_tile", "hash_build": "k_hash_build"}.get(fam_name.split("(")[0], fam_name.split("(")[0]))
             if hit:
                 e["valu_issue_frac"] = hit["valu_issue_frac"]
         hit = ij["kernels"].get(dom.split("(")[0])
