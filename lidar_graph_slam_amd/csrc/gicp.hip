@@ -773,7 +773,10 @@ __global__ __launch_bounds__(kGicpBlock, 5) void k_gicp_correspond(const float4*
   constexpr int kMaskTiles = 64;  // tiles of a block whose "safe" words are fetched in one go
   __shared__ int queue[kLinTile + kGicpBlock];  // what is left of the earlier tiles (< one block's worth) + this tile's
   __shared__ int qcount;
-  constexpr int kUnsafeCap = 2048;  // points of a block that are not marked safe: listed when they are at most this many
+#ifndef CORR_UNSAFE_CAP
+#define CORR_UNSAFE_CAP 2048  // (A/B: 1 024 brings the kernel's LDS to 6 KB - what is free on a CU beside eight k-NN waves)
+#endif
+  constexpr int kUnsafeCap = CORR_UNSAFE_CAP;  // points of a block that are not marked safe: listed when they are at most this many
   __shared__ int ulist[kUnsafeCap];
   __shared__ int ucount;
   int pair, bx;
