@@ -287,7 +287,10 @@ int mi355_cloud_save_pcd(mi355_cloud* cloud, const char* path, int binary);
 mi355_batch* mi355_batch_create(mi355_ctx* ctx, int method, const void* params, int n_sources, int n_targets, size_t capacity);
 void mi355_batch_destroy(mi355_batch* b);
 /* Device-resident inputs: packed float4 [n_clouds][capacity] + host counts.  prefilter (optional) is applied on device
- * (distance + voxel; SOR when mean_k > 0).  Enqueues work on the context stream; does not synchronise. */
+ * (distance + voxel; SOR when mean_k > 0).  Enqueues work; does not synchronise.  LIFETIME of d_points: the preparation chains that read
+ * it run on internal side streams forked from the batch's stream at the call and joined by the next mi355_batch_align - the buffer must
+ * stay valid and unchanged until the stream has passed THAT align (with mi355_batch_set_side_streams(b, 0): until it has passed this
+ * call).  After that the batch holds its own copies of everything it needs, later aligns included. */
 int mi355_batch_set_targets_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter);
 int mi355_batch_set_sources_dev(mi355_batch* b, const void* d_points, const int* counts, const mi355_prefilter_params* prefilter);
 /* Host-pointer variants (PCIe copy included). */

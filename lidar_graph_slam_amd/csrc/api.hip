@@ -1361,9 +1361,10 @@ static void batch_set(mi355_batch* b, bool targets, const float4* d_points, cons
       // points in the voxel hash's Morton order (neighbouring lanes of the derivative pass read the same leaves).
       if (targets) {
         if (pts == in && d_points != b->host_stage_tgt.p && d_points != b->cloud_stage_tgt.p) {
-          // no prefilter ran (and the points are not in the batch's own staging already): `pts` is the CALLER's buffer, and the targets' point hash (getFitnessScore) is built from it only at align
-          // time - a later enqueue than this call, by when the caller may have reused the memory (the *_dev contract is "read by work
-          // enqueued during the call").  The batch keeps its own copy.
+          // no prefilter ran (and the points are not in the batch's own staging already): `pts` is the CALLER's buffer, and the targets'
+          // point hash (getFitnessScore) is built from it at align time only - possibly at a LATER align than the one that follows this
+          // call, by when the caller may have reused the memory (mi355_lidar.h: inputs stay valid until the stream has passed the next
+          // align).  The batch keeps its own copy.
           ws.stage_a.ensure((size_t)n * b->cap);
           MI_HIP(hipMemcpyAsync(ws.stage_a.p, in, (size_t)n * b->cap * sizeof(float4), hipMemcpyDeviceToDevice, s));
           pts = ws.stage_a.p;

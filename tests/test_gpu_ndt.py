@@ -149,3 +149,41 @@ def test_batch_rejects_other_methods(R):
 
     with pytest.raises(L.Mi355Error):
         R.BatchRegistration(2, 2, 128, method="VGICP")  # the four engines of graph_based_slam.cpp:80-152 and nothing else
+
+
+def test_batch_keeps_its_own_targets_for_a_later_fitness(R, small_pair):
+    """an NDT batch builds the targets' point hash - what getFitnessScore searches - only when mi355_batch_align is
+    asked for a fitness.  Device inputs must stay valid until the stream has passed the align that follows them (include/mi355_lidar.h);
+    a LATER align with a fitness, after the caller has reused its buffers, must still score against the targets that were set - the batch
+    keeps its own copy of targets that came without a prefilter."""
+    import torch
+
+    from lidar_graph_slam_amd.context import Context
+
+    s, t, _ = small_pair
+    cap = max(len(s), len(t)) + 5
+    dev = torch.device("cuda", 0)
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    kw = dict(resolution=2.0, step_size=0.1, transformation_epsilon=0.01, max_iterations=64)
+    tgt_h = np.zeros((2, cap, 4), np.float32)
+    src_h = np.zeros((2, cap, 4), np.float32)
+    t2 = O.transform(t, synth.se3(0.2, -0.1, 0, 0, 0, 0.01).astype(np.float32))
+    tgt_h[0, : len(t)], tgt_h[1, : len(t2)] = t, t2
+    src_h[0, : len(s)], src_h[1, : len(s) - 17] = s, s[: len(s) - 17]
+    b = R.BatchRegistration(2, 2, cap, ctx=ctx, method="NDT_OMP", **kw)
+    tgt_d, src_d = torch.from_numpy(tgt_h).to(dev), torch.from_numpy(src_h).to(dev)
+    b.set_targets_dev(tgt_d.data_ptr(), [len(t), len(t2)])
+    b.set_sources_dev(src_d.data_ptr(), [len(s), len(s) - 17])
+    b.align([0, 1], with_fitness=False)
+    first = np.stack([np.asarray(r["T"]) for r in b.results()])
+    tgt_d.fill_(1.0e4)  # the caller reuses its buffers (behind the align on the same stream)
+    src_d.fill_(-1.0e4)
+    torch.cuda.synchronize()
+    b.align([0, 1], with_fitness=True)
+    res, fit = b.results(with_fitness=True)
+    np.testing.assert_array_equal(np.stack([np.asarray(r["T"]) for r in res]), first)
+    np.testing.assert_allclose(fit[0], O.fitness(s, t, first[0]), rtol=1e-9)
+    np.testing.assert_allclose(fit[1], O.fitness(s[: len(s) - 17], t2, first[1]), rtol=1e-9)
+    b.close()
+    ctx.set_stream(None)
