@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", R, "knn_stats.err")
 lines = [l.strip() for l in open(src) if l.startswith("[mi355]")]
 blk = lines[-6:]  # the last covariance launch of the run: six lines per launch
@@ -58,7 +58,10 @@ out += ["What was tried against candidates x instructions (round 5: analysis and
         "    instructions per tile): 145.8 -> 145.0 ms per step over four alternations in one box - made AFTER the evidence of this directory was",
         "    collected (0.6 %, inside its box-to-box spread).  Splitting the rank loop into steps all lanes have entries for (no end-of-list",
         "    test: 2 of 31 instructions) and the rest: +0.9 ms; folding k into the covariance epilogue: +29 VGPRs, +-0 - neither kept.",
-        "The product candidates x instructions did not fall this round (DESIGN 8)."]
+        "  * (round 6, kept, +-0) the eigenvalue iteration of the covariance epilogue warm-started in fp32 (fewer fp64 divisions): 12.43 -> 12.48 ms per",
+        "    2 048-cloud launch - the epilogue's clocks are not in those iterations.  valu_issue_frac of the kernel (the round's SQ counters on one",
+        "    scale, profiles/<round>_issue.json): 0.84 of the chip's VALU issue slots at 1.9 resident waves per SIMD.",
+        "The product candidates x instructions did not fall in rounds 5 and 6 (DESIGN 8)."]
 dst = os.path.join(DST, f"{R}_knn_tile_counters.txt")
 open(dst, "w").write("\n".join(out) + "\n")
 print("wrote", dst)
