@@ -209,7 +209,6 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* keys_i
       il[r] = (uint32_t)(p0 + r * kWave) << 16;
     }
   }
-  const unsigned long long lt_mask = (1ull << l) - 1ull;
   // (fully unrolled: carried through a rolled loop the two register arrays become 32-wide vector values that the compiler
   // copies and spills wholesale — 4 KB of scratch per lane)
 #pragma unroll
@@ -223,16 +222,21 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* keys_i
     for (int r = 0; r < kTsE; r++) {
       if (r < rounds) {  // (block-uniform; no `break`: the loop must unroll for key[] / il[] to stay in registers)
         const uint32_t d = (key[r] >> shift) & 255u;
-        unsigned long long peers = ~0ull;
+        // the lanes holding the same digit: per bit of the digit one ballot, and peers &= ~(own bit ^ the ballot) - ONE v_bitop3_b32 per
+        // half of the mask (gfx950: any three-input boolean; table 0x90 = a & ~(b ^ c)) where and / xor / not were three; the rank is
+        // the peers below the lane (v_mbcnt).  The tile sort is bound by the VALU work of this loop (valu_issue_frac 0.81).
+        uint32_t plo = ~0u, phi = ~0u;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-          const unsigned long long m = __ballot((d >> b) & 1u);
-          peers &= ((d >> b) & 1u) ? m : ~m;
+          const uint32_t t = (uint32_t)((int32_t)(d << (31 - b)) >> 31);  // all ones iff bit b of the digit is set
+          const unsigned long long m = __ballot(t != 0u);
+          plo = __builtin_amdgcn_bitop3_b32(plo, t, (uint32_t)m, 0x90);
+          phi = __builtin_amdgcn_bitop3_b32(phi, t, (uint32_t)(m >> 32), 0x90);
         }
-        const int rank = __popcll(peers & lt_mask);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
         const int before = cnt[w][d];
         __builtin_amdgcn_wave_barrier();
-        if (rank == 0) cnt[w][d] = (uint16_t)(before + __popcll(peers));
+        if (rank == 0) cnt[w][d] = (uint16_t)(before + __popc(plo) + __popc(phi));
         __builtin_amdgcn_wave_barrier();
         il[r] = (il[r] & 0xFFFF0000u) | (uint32_t)(before + rank);
         asm volatile("" : "+v"(il[r]));  // materialise the rank HERE: deferred, the 64-bit peer masks of all 24 elements stay live (and spill)
