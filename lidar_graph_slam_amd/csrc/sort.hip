@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kTsThreads) void k_sort_tile(const uint32_t* keys_i
         uint32_t plo = ~0u, phi = ~0u;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-          const uint32_t t = (uint32_t)((int32_t)(d << (31 - b)) >> 31);  // all ones iff bit b of the digit is set
+          uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)key[r], (unsigned)(shift + b), 1u);  // all ones iff bit b of the digit is set (one v_bfe_i32)
+          asm volatile("" : "+v"(t));  // (the ballot tests THIS register: left alone the compiler shifts the key a second time for a sign test)
           const unsigned long long m = __ballot(t != 0u);
           plo = __builtin_amdgcn_bitop3_b32(plo, t, (uint32_t)m, 0x90);
           phi = __builtin_amdgcn_bitop3_b32(phi, t, (uint32_t)(m >> 32), 0x90);
