@@ -434,3 +434,111 @@ def icp_align(src, tgt, guess=None, max_correspondence_distance=30.0, max_iterat
         if abs(mse - prev_mse) < 1e-12 or abs(mse - prev_mse) / prev_mse < euclidean_fitness_epsilon:
             return T, True, it
         prev_mse = mse
+
+
+# ---------------------------------------------------------------- pclomp / PCL 1.8 BFGS GICP, for the far-from-origin question
+def _euler_zyx(x, dt):
+    """R = Rz(x5) Ry(x4) Rx(x3) with every entry computed in `dt` (PCL's applyState builds it from AngleAxisf)."""
+    cx, sx, cy, sy, cz, sz = (dt(np.cos(dt(x[3]))), dt(np.sin(dt(x[3]))), dt(np.cos(dt(x[4]))), dt(np.sin(dt(x[4]))), dt(np.cos(dt(x[5]))),
+                              dt(np.sin(dt(x[5]))))
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dt)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dt)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dt)
+    return Rz @ Ry @ Rx
+
+
+def memoryless_bfgs(fdf, x, max_iter, gtol):
+    """The solver CLASS of pcl/registration/bfgs.h (GSL's vector_bfgs2): no Hessian estimate is kept - the next direction is
+    p = g - A dx - B dg from the last step alone, normalised and pointed downhill, the first one the normalised steepest descent - here
+    with SciPy's strong-Wolfe line search (c1 = 0.01, c2 just above it) where upstream has Fletcher's bracketing / sectioning.  Shares
+    the two direction formulas with oracle_gicp_bfgs.cpp and nothing else."""
+    import warnings
+
+    from scipy.optimize import line_search
+
+    f, g = fdf(x)
+    p = -g / np.linalg.norm(g)
+    alpha1, delta_f = 1.0, 0.0
+    for _ in range(max_iter):
+        fp0 = float(p @ g)
+        if fp0 == 0 or not np.isfinite(fp0):
+            break
+        if delta_f < 0:
+            alpha1 = min(1.0, 2.0 * max(-delta_f, 1e-15 * abs(f)) / (-fp0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = line_search(lambda y: fdf(y)[0], lambda y: fdf(y)[1], x, p, gfk=g, old_fval=f, old_old_fval=f + 0.5 * alpha1 * (-fp0), c1=0.01,
+                            c2=0.011, maxiter=100)[0]
+        if a is None:
+            break  # (upstream: "no progress")
+        xn = x + a * p
+        fn, gn = fdf(xn)
+        dx, dg = xn - x, gn - g
+        delta_f = fn - f
+        dxg, dgg, dxdg = dx @ gn, dg @ gn, dx @ dg
+        B = dxg / dxdg if dxdg != 0 else 0.0
+        A = -(1.0 + (dg @ dg) / dxdg) * B + dgg / dxdg if dxdg != 0 else 0.0
+        p = gn - A * dx - B * dg
+        x, f, g = xn, fn, gn
+        p = p / np.linalg.norm(p) * (-1.0 if p @ g > 0 else 1.0)
+        if np.linalg.norm(g) < gtol:
+            break
+    return x
+
+
+def gicp_bfgs_align(src, tgt, *, placement=np.float32, solver="full", k=20, max_corr=2.0, max_iterations=64, max_optimizer_iterations=20,
+                    transformation_epsilon=0.01, rotation_epsilon=2e-3):
+    """PCL 1.8's GICP outer loop (correspondences at the current pose, Mahalanobis matrices, minimise f(x) = 1/m sum r^T M r over
+    x = (translation, Euler angles ABOUT THE ORIGIN), stop when no entry of the pose matrix moved by its epsilon) from the identity guess,
+    written to ask ONE question of oracle_gicp_bfgs.cpp: when it stops converging far from the map origin, is that the fp32 in which
+    upstream transforms the points (`placement`: the dtype of R(x), of the transformed point and of the residual's subtraction) or the
+    inner solver?  solver = "full": SciPy's BFGS (keeps an inverse-Hessian estimate); "memoryless": memoryless_bfgs above.  Both run at
+    most max_optimizer_iterations steps to a gradient norm of 1e-2, as upstream.  Returns (T float64, converged, outer iterations)."""
+    from scipy.optimize import minimize
+
+    dt = placement
+    src_cov, tgt_cov = covariances(src, k, "PLANE"), covariances(tgt, k, "PLANE")
+    s, t = src[:, :3].astype(dt), tgt[:, :3].astype(dt)
+    tree = cKDTree(tgt[:, :3].astype(np.float64))
+    trans = np.eye(4, dtype=dt)
+    it, conv = 0, False
+    while not conv:
+        q = (s @ trans[:3, :3].T + trans[:3, 3]).astype(dt)
+        d, j = tree.query(q.astype(np.float64))
+        ok = d * d < max_corr * max_corr
+        if ok.sum() < 4:
+            break
+        R = trans[:3, :3].astype(np.float64)
+        M = np.linalg.inv(tgt_cov[j[ok]] + R @ src_cov[ok] @ R.T)
+        p, qq = s[ok], t[j[ok]]
+        m = len(p)
+
+        def fdf(x):
+            pp = (p @ _euler_zyx(x, dt).T + x[:3].astype(dt)).astype(dt)
+            r = (pp - qq).astype(np.float64)
+            Mr = np.einsum("nij,nj->ni", M, r)
+            g = np.zeros(6)
+            g[:3] = 2.0 / m * Mr.sum(0)
+            A = 2.0 / m * np.einsum("ni,nj->ij", p.astype(np.float64), Mr)
+            for a in range(3):  # d/d angle of sum (R p) . (M r): the derivative of R by central differences in fp64
+                xp, xm = np.array(x, np.float64), np.array(x, np.float64)
+                xp[3 + a] += 1e-6
+                xm[3 + a] -= 1e-6
+                g[3 + a] = float((((_euler_zyx(xp, np.float64) - _euler_zyx(xm, np.float64)) / 2e-6) * A.T).sum())
+            return float(np.einsum("ni,ni->", r, Mr)) / m, g
+
+        x0 = np.array([trans[0, 3], trans[1, 3], trans[2, 3], np.arctan2(trans[2, 1], trans[2, 2]), np.arcsin(-trans[2, 0]),
+                       np.arctan2(trans[1, 0], trans[0, 0])], np.float64)
+        if solver == "full":
+            x = minimize(fdf, x0, jac=True, method="BFGS", options={"maxiter": max_optimizer_iterations, "gtol": 1e-2, "norm": 2}).x
+        else:
+            x = memoryless_bfgs(fdf, x0, max_optimizer_iterations, 1e-2)
+        prev = trans.copy()
+        trans = np.eye(4, dtype=dt)
+        trans[:3, :3] = _euler_zyx(x, dt)
+        trans[:3, 3] = x[:3].astype(dt)
+        delta = max(np.abs(prev[:3, :3].astype(np.float64) - trans[:3, :3]).max() / rotation_epsilon,
+                    np.abs(prev[:3, 3].astype(np.float64) - trans[:3, 3]).max() / transformation_epsilon)
+        it += 1
+        conv = it >= max_iterations or delta < 1
+    return trans.astype(np.float64), conv, it
