@@ -33,6 +33,7 @@ const Tuning& tuning() {
     getf("MI355_CORR_R1", v.corr_r1);
     getf("MI355_ICP_R1_CELLS", v.icp_r1_cells);
     getf("MI355_ICP_MIN_MOVE", v.icp_min_move);
+    getf("MI355_ICP_RMID_CELLS", v.icp_rmid_cells);
     getf("MI355_MARGIN_STEP", v.margin_step);
     geti("MI355_BLOCKS_LIN", v.blocks_lin);
     geti("MI355_LIN_PPT", v.lin_ppt);

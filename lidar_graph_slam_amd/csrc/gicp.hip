@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void corr_scan(const float4* __restrict__ cand, int n
 
 // Gather the points of `cells` inside `nb` (and outside `ob`) through the LDS ring, scanning whenever it is full.
 __device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCells& cells_in, const TileBox& nb, const TileBox& ob, bool has_old,
-                                                 float4* cand, float qx, float qy, float qz, CorrBest& best, int* scratch) {
+                                                 float4* cand, float qx, float qy, float qz, CorrBest& best, int* scratch, const TileBox& ob2, bool has_old2) {
   const int lane = lane_id();
   const unsigned long long below = (1ull << lane) - 1ull;
   // the cells' points as one flat sequence (tile.hpp FlatCells): full 64-lane loads instead of one load per ~6-point cell
@@ -1065,7 +1065,8 @@ __device__ __forceinline__ void corr_gather_scan(const GridView& g, const TileCe
 #pragma unroll
     for (int u = 0; u < kGatherDepth; u++) {
       if (f0 + u * kWave >= fc.total) break;
-      const bool in = in_box(nb, p[u].x, p[u].y, p[u].z) && !(has_old && in_box(ob, p[u].x, p[u].y, p[u].z));
+      const bool in = in_box(nb, p[u].x, p[u].y, p[u].z) && !(has_old && in_box(ob, p[u].x, p[u].y, p[u].z)) &&
+                      !(has_old2 && in_box(ob2, p[u].x, p[u].y, p[u].z));
       const unsigned long long mask = __ballot(in);
       const int cnt = __popcll(mask);
       if (n + cnt > kCorrCand) {  // ring full: every lane scans what is there, then it is reused
@@ -1087,7 +1088,8 @@ __device__ __forceinline__ float corr_key_ub(uint32_t k) { return __uint_as_floa
 // A round cannot run only when its box needs more than 64 cells at the top level of the hash (it never does for radii of metres).
 constexpr int kCorrSplitPoints = 2048;  // a 64-lane patch whose round-1 cells hold more points than this is split into quarters
 __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float qx, float qy, float qz, float R1, float R1_2, float reach, float reach2,
-                                            bool one_round, float4* cand, CorrBest& best, float& explored2, unsigned long long* stats, int* scratch) {
+                                            bool one_round, float4* cand, CorrBest& best, float& explored2, unsigned long long* stats, int* scratch,
+                                            float r_mid = 0.f) {
   const TileBox box = tile_bounds(act, qx, qy, qz);
   const TileBox nb = grow(box, R1 + tile_eps(box, reach));
   const TileCells cells = tile_cells(g, nb, 0x7fffffff);
@@ -1095,12 +1097,12 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
   if (cells.ok) {
     // everything in the box counts (round 2 skips this box), but only what lies within R1 is known to be complete
     CorrBest b = best;
-    corr_gather_scan(g, cells, nb, nb, false, cand, qx, qy, qz, b, scratch);
+    corr_gather_scan(g, cells, nb, nb, false, cand, qx, qy, qz, b, scratch, nb, false);
     if (act) { best = b; explored2 = R1_2; }
     seen = true;
   }
   const bool found1 = best.k1 != kCorrEmpty && corr_key_ub(best.k1) <= R1_2;
-  const bool act2 = act && !(seen && (one_round || found1));
+  bool act2 = act && !(seen && (one_round || found1));
   const unsigned long long m2 = __ballot(act2);
   if (stats && lane_id() == 0) {  // tuning aid (MI355_CORR_STATS)
     atomicAdd(&stats[0], 1ull);
@@ -1109,6 +1111,23 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
     if (m2) { atomicAdd(&stats[3], 1ull); atomicAdd(&stats[4], (unsigned long long)__popcll(m2)); }
   }
   if (!m2) return;
+  // A middle round (ICP: a reach of tens of metres never fits the last round's 64 top-level cells, and whoever fails round 1 would go
+  // straight to the per-lane search): the lanes round 1 left, radius r_mid, skipping round 1's box.
+  TileBox nbm = nb;
+  bool seen_mid = false;
+  if (r_mid > R1 && r_mid < reach) {
+    const TileBox boxm = tile_bounds(act2, qx, qy, qz);
+    nbm = grow(boxm, r_mid + tile_eps(boxm, reach));
+    const TileCells cellsm = tile_cells(g, nbm, 0x7fffffff);
+    if (cellsm.ok) {
+      CorrBest b = best;
+      corr_gather_scan(g, cellsm, nbm, nb, seen, cand, qx, qy, qz, b, scratch, nb, false);
+      if (act2) { best = b; explored2 = r_mid * r_mid; }
+      seen_mid = true;
+      act2 = act2 && !(best.k1 != kCorrEmpty && corr_key_ub(best.k1) <= r_mid * r_mid);
+      if (!__ballot(act2)) return;
+    }
+  }
   const TileBox box2 = tile_bounds(act2, qx, qy, qz);
   const TileBox nb2 = grow(box2, reach + tile_eps(box2, reach));
   const TileCells cells2 = tile_cells(g, nb2, 0x7fffffff);
@@ -1117,11 +1136,11 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
     if (!cells2.ok) atomicAdd(&stats[6], 1ull);
   }
   if (!cells2.ok) {
-    if (act2) explored2 = 0.f;  // what round 1 found beyond R1 proves nothing
+    if (act2) explored2 = 0.f;  // what the earlier rounds found beyond their radius proves nothing
     return;
   }
   CorrBest b = best;
-  corr_gather_scan(g, cells2, nb2, nb, seen, cand, qx, qy, qz, b, scratch);
+  corr_gather_scan(g, cells2, nb2, nb, seen, cand, qx, qy, qz, b, scratch, nbm, seen_mid);
   if (act2) { best = b; explored2 = reach2; }
 }
 
@@ -1130,7 +1149,8 @@ __device__ __forceinline__ void corr_rounds(const GridView& g, bool act, float q
 // correspondence estimation (k_icp_correspond_tile below).
 __device__ __forceinline__ void correspond_tiles_of_pair(const GridView& g, const float4* __restrict__ sp, int n, const float* Tf, int* __restrict__ corr_p,
                                                          float4* __restrict__ qs_p, float max_corr_d2, float r1, int G, int bx,
-                                                         unsigned long long* __restrict__ stats, const int* __restrict__ order_p, float4* cand, int* scratch) {
+                                                         unsigned long long* __restrict__ stats, const int* __restrict__ order_p, float4* cand, int* scratch,
+                                                         float r_mid = 0.f) {
   const int lane = lane_id();
   const float reach2 = search_reach2(g, max_corr_d2, true);
   const float reach = sqrtf(reach2);
@@ -1162,7 +1182,7 @@ __device__ __forceinline__ void correspond_tiles_of_pair(const GridView& g, cons
       for (int part = 0; part < parts; part++) {
         const bool pact = act && (parts == 1 || (lane >> 4) == part);
         if (!__ballot(pact)) continue;
-        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats, scratch);
+        corr_rounds(g, pact, qx, qy, qz, R1, R1_2, reach, reach2, one_round, cand, best, explored2, stats, scratch, r_mid);
       }
     }
     // what the keys could not decide (a tie or near-tie of the two smallest, a box that could not be scanned) is left to the
@@ -1235,7 +1255,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_icp_correspond_tile(const flo
                                                                     const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                                     size_t tslots, const int* __restrict__ tgt_of_src, int* __restrict__ corr,
                                                                     float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S, float min_move,
-                                                                    const int* __restrict__ tile_order, size_t opitch) {
+                                                                    const int* __restrict__ tile_order, size_t opitch, float r_mid) {
   __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand + 8];
   __shared__ int gscratch[kGicpBlock / kWave][2 * kWave];
   int pair, bx;
@@ -1252,14 +1272,14 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_icp_correspond_tile(const flo
   const float I[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
   const size_t so = (size_t)pair * cpitch;
   correspond_tiles_of_pair(g, cur + so, st.n, I, corr + so, qsearch + so, max_corr_d2, r1, G, bx, nullptr,
-                           tile_order ? tile_order + (size_t)pair * opitch : nullptr, cand_all[wave_id()], gscratch[wave_id()]);
+                           tile_order ? tile_order + (size_t)pair * opitch : nullptr, cand_all[wave_id()], gscratch[wave_id()], r_mid);
 }
 void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
-                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch) {
+                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid) {
   const int G = std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cpitch, kGicpBlock)));
   TimedLaunch tl(KF_CORRESPOND_TILE, s);
   hipLaunchKernelGGL(k_icp_correspond_tile, dim3(xcd_grid(G, S)), dim3(kGicpBlock), 0, s, cur, cpitch, state, (const float4*)tgt.pts.p, (const int*)tgt.orig.p,
-                     (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, tgt_of_src, corr, qsearch, max_corr_d2, r1, G, S, min_move, tile_order, opitch);
+                     (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, tgt_of_src, corr, qsearch, max_corr_d2, r1, G, S, min_move, tile_order, opitch, r_mid);
   MI_LAUNCH_CHECK();
 }
 

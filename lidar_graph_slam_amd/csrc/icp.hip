@@ -298,7 +298,8 @@ void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, siz
       // The tiles keep d2 < max^2 where PCL keeps d2 <= max^2: the next float up makes the two the same test.
       if (ICP_TILES && S >= 8 && it < kIcpTileIterations)
         icp_correspond_tiles(s, b.cur.p, b.pitch, (const IcpPairState*)b.state.p, tgt, (const int*)b.tgt_of_src.p, b.corr.p, b.qsearch.p,
-                             nextafterf(max_d2, INFINITY), tuning().icp_r1_cells * tuning().grid_cell, S, tuning().icp_min_move, src_tile_order, spitch);
+                             nextafterf(max_d2, INFINITY), tuning().icp_r1_cells * tuning().grid_cell, S, tuning().icp_min_move, src_tile_order, spitch,
+                             tuning().icp_rmid_cells * tuning().grid_cell);
       TimedLaunch tl(KF_CORRESPOND, s);
       hipLaunchKernelGGL(k_icp_step, grid, dim3(kIcpBlock), 0, s, (const float4*)b.cur.p, b.pitch, b.corr.p, b.qsearch.p, (const IcpPairState*)b.state.p, (const float4*)tgt.pts.p,
                          (const int*)tgt.orig.p, (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap,
