@@ -12,11 +12,8 @@ run() {
 }
 EXTRA="$*"
 run A=default
-run MI355_ICP_R1_CELLS=4.0
-run MI355_ICP_RMID_CELLS=6.0
-run MI355_ICP_RMID_CELLS=8.0
-run MI355_ICP_RMID_CELLS=16.0
-run MI355_ICP_R1_CELLS=3.0 MI355_ICP_RMID_CELLS=10.0
-run MI355_ICP_R1_CELLS=4.0 MI355_ICP_RMID_CELLS=12.0
-run MI355_ICP_R1_CELLS=1.5 MI355_ICP_RMID_CELLS=6.0
+run MI355_ICP_RMID_CELLS=0.01
+run MI355_ICP_RMID_CELLS=4.0
+run MI355_ICP_MIN_MOVE=0.01
+run MI355_ICP_MIN_MOVE=0.02
 run A=default_again

@@ -34,6 +34,9 @@ const Tuning& tuning() {
     getf("MI355_ICP_R1_CELLS", v.icp_r1_cells);
     getf("MI355_ICP_MIN_MOVE", v.icp_min_move);
     getf("MI355_ICP_RMID_CELLS", v.icp_rmid_cells);
+    getf("MI355_ICP_R1_SIGMA", v.icp_r1_sigma);
+    getf("MI355_ICP_BALL_SCALE", v.icp_ball_scale);
+    getf("MI355_ICP_BALL_PAD", v.icp_ball_pad);
     getf("MI355_MARGIN_STEP", v.margin_step);
     geti("MI355_BLOCKS_LIN", v.blocks_lin);
     geti("MI355_LIN_PPT", v.lin_ppt);

@@ -212,7 +212,7 @@ void gicp_trial_cost_probe(hipStream_t s, GicpBatch& gb, const CloudSet& src, co
 struct IcpPairState;
 // tile_order (optional): [S][opitch] the sources' points in the order of their compact 64-point patches (cloud.hip build_tile_order)
 void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
-                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid);
+                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid, float r1_sigma);
 
 // ---- icp.hip -------------------------------------------------------------------------------------------------
 // pcl::IterativeClosestPoint for S pairs at once (every pair's state in HBM, advanced on the device); a registration object is a

@@ -315,7 +315,8 @@ __device__ __forceinline__ NnState lane_search(const GridView& g, float qx, floa
     const float rel = sqrtf(seed_d2) * g.m.inv_cell;
     level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
   }
-  st.explored2 = grid_search(g, qx, qy, qz, reach2, nn, level0, 1, kLaneLevelCap);
+  // (cells farther than the reach are pruned: what the walk has covered beyond it says nothing about them)
+  st.explored2 = fminf(grid_search(g, qx, qy, qz, reach2, nn, level0, 1, kLaneLevelCap), reach2);
   st.d1 = nn.d1;
   st.j1 = nn.j1;
   st.d2nd = nn.d2nd;
@@ -1255,7 +1256,7 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_icp_correspond_tile(const flo
                                                                     const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                                     size_t tslots, const int* __restrict__ tgt_of_src, int* __restrict__ corr,
                                                                     float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S, float min_move,
-                                                                    const int* __restrict__ tile_order, size_t opitch, float r_mid) {
+                                                                    const int* __restrict__ tile_order, size_t opitch, float r_mid, float r1_sigma) {
   __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand + 8];
   __shared__ int gscratch[kGicpBlock / kWave][2 * kWave];
   int pair, bx;
@@ -1269,17 +1270,20 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_icp_correspond_tile(const flo
     if (!(tr + 50.f * ang >= min_move)) return;
   }
   const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
+  // the first round's radius follows the pair: r1_sigma times the RMS correspondence distance of its last iteration, between half a base
+  // cell and r1 - as the pair closes in, the box a patch scans shrinks with it (who lies farther goes through the middle round)
+  if (r1_sigma > 0.f && st.iterations > 0 && st.mse > 0.0) r1 = fminf(r1, fmaxf(r1_sigma * sqrtf((float)st.mse), 0.5f * g.m.cell));
   const float I[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
   const size_t so = (size_t)pair * cpitch;
   correspond_tiles_of_pair(g, cur + so, st.n, I, corr + so, qsearch + so, max_corr_d2, r1, G, bx, nullptr,
                            tile_order ? tile_order + (size_t)pair * opitch : nullptr, cand_all[wave_id()], gscratch[wave_id()], r_mid);
 }
 void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
-                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid) {
+                          float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid, float r1_sigma) {
   const int G = std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cpitch, kGicpBlock)));
   TimedLaunch tl(KF_CORRESPOND_TILE, s);
   hipLaunchKernelGGL(k_icp_correspond_tile, dim3(xcd_grid(G, S)), dim3(kGicpBlock), 0, s, cur, cpitch, state, (const float4*)tgt.pts.p, (const int*)tgt.orig.p,
-                     (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, tgt_of_src, corr, qsearch, max_corr_d2, r1, G, S, min_move, tile_order, opitch, r_mid);
+                     (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, tgt_of_src, corr, qsearch, max_corr_d2, r1, G, S, min_move, tile_order, opitch, r_mid, r1_sigma);
   MI_LAUNCH_CHECK();
 }
 

@@ -16,6 +16,9 @@
 #ifndef ICP_SEEDED
 #define ICP_SEEDED 1  // 0: every iteration searches from scratch (A/B: benchmarks/build_variant.sh)
 #endif
+#ifndef ICP_FAR_MARGINS
+#define ICP_FAR_MARGINS 1  // 0 (A/B): a point whose seed is farther than two base cells is searched at every iteration, without a margin
+#endif
 #ifndef ICP_TILES
 #define ICP_TILES 1  // 0: per-lane searches only (A/B)
 #endif
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
                                                         const int* __restrict__ torig, const HashSlot* __restrict__ ttable,
                                                         const GridMeta* __restrict__ tmeta, size_t tcap, size_t tslots,
                                                         const int* __restrict__ tgt_of_src, float max_d2, int G, int S,
-                                                        double* __restrict__ partials) {
+                                                        double* __restrict__ partials, float ball_scale, float ball_pad) {
   __shared__ double smem[4 * kIcpAcc];
   __shared__ int queue[kIcpTile + kIcpBlock];  // what is left of the earlier tiles (< one block's worth) + this tile's
   __shared__ int wq[kIcpPpt][kIcpBlock / kWave];
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
         if (ICP_MARGINS && nn.best_j >= 0 && limit < 4.f * g.m.cell * g.m.cell) {
           // a seed within two base cells: everything inside a ball a little larger than the seed distance - the nearest, and the runner-up
           // if it is in there (else it is at least the ball's radius away) - from a handful of cells of the level that fits the ball
-          const float r = sqrtf(limit) * 1.25f + 0.02f;
+          const float r = sqrtf(limit) * ball_scale + ball_pad;
           Nearest2 n2{g.orig, limit, nn.best_j, INFINITY, r * r};
           grid_ball_search(g, p.x, p.y, p.z, n2, 2.1f);
           nn.best_d2 = n2.d1;
@@ -205,6 +208,25 @@ __global__ __launch_bounds__(kIcpBlock) void k_icp_step(const float4* __restrict
           if (n2.d1 <= max_d2) {
             const float d1 = sqrtf(n2.d1);
             margin = fminf(0.5f * (sqrtf(fminf(n2.d2nd, r * r)) - d1), max_d - d1) * (1.f - 1e-4f) - 1e-5f;  // (fp32 slack, as finish_search in gicp.hip)
+          }
+        } else if (ICP_MARGINS && ICP_FAR_MARGINS) {
+          // a far seed, or none: the walk covers a little more than the seed distance (half a base cell), from the level whose cells are
+          // about that long, and keeps the runner-up - a point metres from anything earns a margin too instead of being searched again
+          // at every iteration
+          const float lim_r = sqrtf(limit) + 0.5f * g.m.cell;
+          const float lim2 = lim_r * lim_r;
+          int level0 = 0;
+          if (nn.best_j >= 0) {
+            const float rel = sqrtf(limit) * g.m.inv_cell;
+            level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
+          }
+          Nearest2 n2{g.orig, nn.best_d2, nn.best_j, INFINITY, lim2};
+          const float ex2 = fminf(grid_search(g, p.x, p.y, p.z, lim2, n2, level0, 1), lim2);  // (cells beyond lim2 are pruned)
+          nn.best_d2 = n2.d1;
+          nn.best_j = n2.j1;
+          if (n2.j1 >= 0 && n2.d1 <= max_d2) {
+            const float d1 = sqrtf(n2.d1);
+            margin = fminf(0.5f * (sqrtf(fminf(n2.d2nd, ex2)) - d1), max_d - d1) * (1.f - 1e-4f) - 1e-5f;
           }
         } else {
           grid_search(g, p.x, p.y, p.z, nextafterf(limit, INFINITY), nn, 0, 2);
@@ -299,11 +321,11 @@ void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, siz
       if (ICP_TILES && S >= 8 && it < kIcpTileIterations)
         icp_correspond_tiles(s, b.cur.p, b.pitch, (const IcpPairState*)b.state.p, tgt, (const int*)b.tgt_of_src.p, b.corr.p, b.qsearch.p,
                              nextafterf(max_d2, INFINITY), tuning().icp_r1_cells * tuning().grid_cell, S, tuning().icp_min_move, src_tile_order, spitch,
-                             tuning().icp_rmid_cells * tuning().grid_cell);
+                             tuning().icp_rmid_cells * tuning().grid_cell, tuning().icp_r1_sigma);
       TimedLaunch tl(KF_CORRESPOND, s);
       hipLaunchKernelGGL(k_icp_step, grid, dim3(kIcpBlock), 0, s, (const float4*)b.cur.p, b.pitch, b.corr.p, b.qsearch.p, (const IcpPairState*)b.state.p, (const float4*)tgt.pts.p,
                          (const int*)tgt.orig.p, (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap,
-                         (const int*)b.tgt_of_src.p, max_d2, b.G, S, b.partials.p);
+                         (const int*)b.tgt_of_src.p, max_d2, b.G, S, b.partials.p, tuning().icp_ball_scale, tuning().icp_ball_pad);
       const bool last = k == chunk - 1 || it + 1 >= std::max(p.max_iterations, 1);
       hipLaunchKernelGGL(k_icp_advance, dim3(div_up(S, 64)), dim3(64), 0, s, b.state.p, (const double*)b.partials.p, c, b.G, S, last ? b.n_active.p : nullptr);
     }
