@@ -12,8 +12,4 @@ run() {
 }
 EXTRA="$*"
 run A=default
-run MI355_ICP_RMID_CELLS=0.01
-run MI355_ICP_RMID_CELLS=4.0
-run MI355_ICP_MIN_MOVE=0.01
-run MI355_ICP_MIN_MOVE=0.02
 run A=default_again

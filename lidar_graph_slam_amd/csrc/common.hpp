@@ -120,7 +120,7 @@ struct Tuning {
   float icp_r1_cells = 2.f;   // MI355_ICP_R1_CELLS      first-round radius of ICP's correspondence tiles, in base cells of the target's voxel hash
   float icp_rmid_cells = 6.f; // MI355_ICP_RMID_CELLS    radius of a middle round for the lanes the first round left, in base cells (a value below the first radius turns it off; a reach of tens of metres never fits the
                               //                         last round: without it they go to the per-lane search; config 5 at 2 048 candidates: 14.3 -> 17.4 k pairs/s)
-  float icp_r1_sigma = 0.f;   // MI355_ICP_R1_SIGMA      first-round radius of a pair's tiles = this many RMS correspondence distances of its last iteration, within [half a base cell, MI355_ICP_R1_CELLS]; 0 = fixed
+  float icp_r1_sigma = 3.f;   // MI355_ICP_R1_SIGMA      first-round radius of a pair's tiles = this many RMS correspondence distances of its last iteration, within [half a base cell, MI355_ICP_R1_CELLS] (config 5: +3 %; a huge value = fixed)
   float icp_ball_scale = 1.25f, icp_ball_pad = 0.02f;  // MI355_ICP_BALL_SCALE / _PAD  a settled ICP point is searched in the ball of radius scale x (distance to its last correspondent) + pad (m): its margin can be at most half of what the ball adds
   float icp_min_move = 0.005f; // MI355_ICP_MIN_MOVE     an ICP pair is searched by tiles while its last fit moved it by more than this (m at a 50 m lever arm)
   int corr_stats = 0;         // MI355_CORR_STATS        1 = count what the correspondence tiles scan, print after every align
