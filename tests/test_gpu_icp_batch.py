@@ -2,6 +2,7 @@
 default engine (graph_based_slam.param.yaml:9, graph_based_slam.cpp:142-151) with every pair's fit and PCL's convergence criteria
 advanced on the device — against the registration object (a batch of one, the source in the caller's order) and the oracle."""
 import numpy as np
+import parity
 import pytest
 
 from lidar_graph_slam_amd import synth
@@ -63,8 +64,8 @@ def test_batch_icp_matches_single_and_oracle(R, small_pair, max_iterations):
         dt, dr = synth.pose_error(r["T"], ref["T"])
         if max_iterations == 6:  # fixed iteration count: iteration by iteration the oracle's pose
             assert r["iterations"] == ref["iterations"] and dt <= 2e-5 and dr <= 2e-6, (i, dt, dr)
-        else:  # PCL's stopping rules: the stopping iteration hinges on the last bits of the mean squared distance
-            assert dt <= 0.02 and dr <= 1e-3, (i, dt, dr)
+        else:  # PCL's stopping rules: the stopping iteration hinges on the last bits of the mean squared distance - SURVEY 8(c)'s band,
+            parity.assert_in_band(r["T"], ref["T"], f"icp_batch/pair{i}")  # the measured worst case in profiles/rNN_parity_deltas.txt
         assert r["n_source"] == ns[i] and r["n_target"] == nt[tgt_of_src[i]]
         np.testing.assert_allclose(fit[i], O.fitness(si, ti, r["T"]), rtol=1e-6)
     assert res[5]["iterations"] == 0 and res[5]["n_source"] == 0 and not res[5]["converged"]
