@@ -211,6 +211,9 @@ void gicp_trial_cost_probe(hipStream_t s, GicpBatch& gb, const CloudSet& src, co
 // sources as moved so far, corr / qsearch the rows k_icp_step reads; pairs whose last fit moved them less than min_move are skipped
 struct IcpPairState;
 // tile_order (optional): [S][opitch] the sources' points in the order of their compact 64-point patches (cloud.hip build_tile_order)
+// (moved_correspond_tiles: the same for any engine that keeps its moved sources in `cur` - jobs[pair] = the pair's point count, 0 = not now)
+void moved_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const int* jobs, const CloudSet& tgt, const int* tgt_of_src, int* corr,
+                            float4* qsearch, float max_corr_d2, float r1, float r_mid, int S, const int* tile_order, size_t opitch);
 void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
                           float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid, float r1_sigma);
 

@@ -1278,6 +1278,36 @@ __global__ __launch_bounds__(kGicpBlock, 4) void k_icp_correspond_tile(const flo
   correspond_tiles_of_pair(g, cur + so, st.n, I, corr + so, qsearch + so, max_corr_d2, r1, G, bx, nullptr,
                            tile_order ? tile_order + (size_t)pair * opitch : nullptr, cand_all[wave_id()], gscratch[wave_id()], r_mid);
 }
+// The same tiles for an engine that keeps its sources where the search should find them (`cur`, identity pose) and says per pair whether it
+// wants a search now (`jobs[pair]` = the pair's point count, 0 = not in this launch): pclomp's BFGS GICP at the start of an outer iteration
+// (gicp_bfgs.hip).  A point inside the margin of its last search keeps its correspondent here too.
+__global__ __launch_bounds__(kGicpBlock, 4) void k_moved_correspond_tile(const float4* __restrict__ cur, size_t cpitch, const int* __restrict__ jobs,
+                                                                      const float4* __restrict__ tpts, const int* __restrict__ torig,
+                                                                      const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
+                                                                      size_t tslots, const int* __restrict__ tgt_of_src, int* __restrict__ corr,
+                                                                      float4* __restrict__ qsearch, float max_corr_d2, float r1, int G, int S,
+                                                                      const int* __restrict__ tile_order, size_t opitch, float r_mid) {
+  __shared__ float4 cand_all[kGicpBlock / kWave][kCorrCand + 8];
+  __shared__ int gscratch[kGicpBlock / kWave][2 * kWave];
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
+  const int n = jobs[pair];
+  if (n <= 0) return;
+  const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
+  const float I[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  const size_t so = (size_t)pair * cpitch;
+  correspond_tiles_of_pair(g, cur + so, n, I, corr + so, qsearch + so, max_corr_d2, r1, G, bx, nullptr,
+                           tile_order ? tile_order + (size_t)pair * opitch : nullptr, cand_all[wave_id()], gscratch[wave_id()], r_mid);
+}
+void moved_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const int* jobs, const CloudSet& tgt, const int* tgt_of_src, int* corr,
+                            float4* qsearch, float max_corr_d2, float r1, float r_mid, int S, const int* tile_order, size_t opitch) {
+  const int G = std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cpitch, kGicpBlock)));
+  TimedLaunch tl(KF_CORRESPOND_TILE, s);
+  hipLaunchKernelGGL(k_moved_correspond_tile, dim3(xcd_grid(G, S)), dim3(kGicpBlock), 0, s, cur, cpitch, jobs, (const float4*)tgt.pts.p, (const int*)tgt.orig.p,
+                     (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, tgt_of_src, corr, qsearch, max_corr_d2, r1, G, S, tile_order,
+                     opitch, r_mid);
+  MI_LAUNCH_CHECK();
+}
 void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const IcpPairState* state, const CloudSet& tgt, const int* tgt_of_src, int* corr,
                           float4* qsearch, float max_corr_d2, float r1, int S, float min_move, const int* tile_order, size_t opitch, float r_mid, float r1_sigma) {
   const int G = std::max(1, std::min(std::max(4, std::min(64, 16384 / std::max(S, 1))), div_up((long)cpitch, kGicpBlock)));

@@ -25,6 +25,9 @@
 #include "grid.hpp"
 #include "primitives.hpp"
 
+#ifndef BFGS_TILES
+#define BFGS_TILES 1  // 0 (A/B): per-lane searches only
+#endif
 #ifndef BFGS_SEEDED
 #define BFGS_SEEDED 1  // 0: every outer iteration searches from scratch (A/B: benchmarks/build_variant.sh)
 #endif
@@ -56,6 +59,9 @@ struct BfgsBatch {
   DevBuf<BfgsPairState> state;
   DevBuf<int> corr;          // [S][pitch] correspondent (sorted target index) of every sorted source point, -1: none in range
   DevBuf<double> mahal;      // [S][pitch][6] fp64 Mahalanobis matrices of the current outer iteration
+  DevBuf<float4> cur;        // [S][pitch] batches: transformation_ * (guess * p) of the pairs that start an outer iteration - what the tiles search at
+  DevBuf<float4> qsearch;    // [S][pitch] batches: where a point's query stood at its last search (xyz), how far it may move before the answer can change (w)
+  DevBuf<int> jobs;          // [S] batches: the point count of a pair that starts an outer iteration in this round, else 0
   DevBuf<double> partials;   // [S][G][kBfgsPartStride]
   DevBuf<int> tgt_of_src, n_active;
   DevBuf<float> guesses;
@@ -107,6 +113,28 @@ __global__ void k_bfgs_begin(BfgsPairState* __restrict__ state, const float* __r
   bfgs_schedule_outer(st);
 }
 
+// Batches (round 6): the pairs that start an outer iteration put their moved sources where the wave-cooperative tiles of gicp.hip search
+// them - q = transformation_ * (guess * p), the two fp32 products upstream makes - and say so in jobs[].
+__global__ __launch_bounds__(kBfgsBlock) void k_bfgs_move(const float4* __restrict__ spts, size_t scap, const BfgsPairState* __restrict__ state,
+                                                          float4* __restrict__ cur, size_t pitch, int* __restrict__ jobs, int G, int S) {
+  int pair, bx;
+  if (!xcd_item_chunk(G, S, pair, bx)) return;
+  const BfgsPairState& st = state[pair];
+  const bool now = st.active && st.need_corr;
+  if (bx == 0 && threadIdx.x == 0) jobs[pair] = now ? st.n : 0;
+  if (!now) return;
+  float guess[12], trans[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) { guess[k] = st.guess[k]; trans[k] = st.trans[k]; }
+  const float4* sp = spts + (size_t)pair * scap;
+  float4* out = cur + (size_t)pair * pitch;
+  for (int i = bx * kBfgsBlock + threadIdx.x; i < st.n; i += G * kBfgsBlock) {
+    const float4 p = sp[i];
+    const float gx = row_apply(guess, p.x, p.y, p.z), gy = row_apply(guess + 4, p.x, p.y, p.z), gz = row_apply(guess + 8, p.x, p.y, p.z);
+    out[i] = make_float4(row_apply(trans, gx, gy, gz), row_apply(trans + 4, gx, gy, gz), row_apply(trans + 8, gx, gy, gz), p.w);
+  }
+}
+
 // The correspondences and Mahalanobis matrices of the pairs that start an outer iteration.  grid = xcd_grid(G, S): the blocks of a pair
 // share an XCD (its target's points and hash table in ONE L2).  From the second outer iteration on the search is seeded with the
 // previous correspondent: its distance bounds the walk through the voxel hash from the start (the same exact nearest neighbour under
@@ -116,7 +144,8 @@ __global__ __launch_bounds__(kBfgsBlock) void k_bfgs_correspond(const float4* __
                                                                 const int* __restrict__ torig, const Cov6* __restrict__ tcov,
                                                                 const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta,
                                                                 size_t tcap, size_t tslots, const int* __restrict__ tgt_of_src, float max_d2, int G,
-                                                                int S, int* __restrict__ corr, double* __restrict__ mahal, size_t pitch) {
+                                                                int S, int* __restrict__ corr, double* __restrict__ mahal, size_t pitch,
+                                                                const float4* __restrict__ qsearch) {
   int pair, bx;
   if (!xcd_item_chunk(G, S, pair, bx)) return;
   const BfgsPairState& st = state[pair];
@@ -142,7 +171,13 @@ __global__ __launch_bounds__(kBfgsBlock) void k_bfgs_correspond(const float4* __
     const float qx = row_apply(trans, gx, gy, gz), qy = row_apply(trans + 4, gx, gy, gz), qz = row_apply(trans + 8, gx, gy, gz);
     Nearest1 nn{g.orig, INFINITY, -1};
     float limit = max_d2;
-    if (seeded) {
+    // (batches: the tiles have been here - a margin that is not NaN says the correspondent in cr[i], or its absence, is this pose's exact answer;
+    // what they left undecided - near-ties of their keys, boxes they could not scan - is searched here, from scratch)
+    const bool decided = qsearch != nullptr && qsearch[(size_t)pair * pitch + i].w == qsearch[(size_t)pair * pitch + i].w;
+    if (decided) {
+      nn.best_j = cr[i];
+      nn.best_d2 = nn.best_j >= 0 ? 0.f : INFINITY;  // (within range by the tiles' own test, the same d2 < max_dist^2)
+    } else if (seeded && qsearch == nullptr) {
       const int j0 = cr[i];
       if (j0 >= 0) {
         const float4 q0 = g.pts[j0];
@@ -150,7 +185,7 @@ __global__ __launch_bounds__(kBfgsBlock) void k_bfgs_correspond(const float4* __
         if (d0 < max_d2) { nn.best_d2 = d0; nn.best_j = j0; limit = nextafterf(d0, INFINITY); }
       }
     }
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, limit, nn, 0, 2);
+    if (!decided && isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, limit, nn, 0, 2);
     int j = -1;
     if (nn.best_j >= 0 && nn.best_d2 < max_d2) {
       j = nn.best_j;
@@ -299,6 +334,16 @@ void bfgs_batch_align(hipStream_t s, BfgsBatch& b, int S, const CloudSet& src, c
   b.h_state.ensure((size_t)S);
   b.corr.ensure((size_t)S * b.pitch);
   b.mahal.ensure((size_t)S * b.pitch * 6);
+  // A batch searches by tiles first (a handful of pairs cannot fill the chip with them: icp.hip); its sources follow their tile order.
+  const bool tiles = BFGS_TILES && S >= 8;
+  if (tiles) {
+    b.cur.ensure((size_t)S * b.pitch);
+    b.qsearch.ensure((size_t)S * b.pitch);
+    b.jobs.ensure((size_t)S);
+    // "never searched": correspondent -1, NaN margin (all-ones bytes are both)
+    MI_HIP(hipMemsetAsync(b.corr.p, 0xFF, (size_t)S * b.pitch * sizeof(int), s));
+    MI_HIP(hipMemsetAsync(b.qsearch.p, 0xFF, (size_t)S * b.pitch * sizeof(float4), s));
+  }
   b.tgt_of_src.ensure((size_t)S);
   b.guesses.ensure((size_t)S * 16);
   b.partials.ensure((size_t)S * b.G * kBfgsPartStride);
@@ -323,12 +368,20 @@ void bfgs_batch_align(hipStream_t s, BfgsBatch& b, int S, const CloudSet& src, c
   for (long round = 0; round < max_rounds;) {
     MI_HIP(hipMemsetAsync(b.n_active.p, 0, sizeof(int), s));
     for (int k = 0; k < chunk && round < max_rounds; k++, round++) {
+      if (tiles) {
+        hipLaunchKernelGGL(k_bfgs_move, grid, dim3(kBfgsBlock), 0, s, (const float4*)src.pts.p, src.cap, (const BfgsPairState*)b.state.p, b.cur.p, b.pitch,
+                           b.jobs.p, b.G, S);
+        // first radius two base cells of the targets' voxel hash, a middle round at six when the range reaches that far (gicp.hip)
+        moved_correspond_tiles(s, b.cur.p, b.pitch, (const int*)b.jobs.p, tgt, (const int*)b.tgt_of_src.p, b.corr.p, b.qsearch.p, max_d2,
+                               2.f * tuning().grid_cell, 6.f * tuning().grid_cell, S,
+                               (src.has_order && src.cap >= b.pitch) ? (const int*)src.tile_order.p : (const int*)nullptr, src.cap);
+      }
       {
         TimedLaunch tl(KF_CORRESPOND, s);
         hipLaunchKernelGGL(k_bfgs_correspond, grid, dim3(kBfgsBlock), 0, s, (const float4*)src.pts.p, (const Cov6*)src.cov.p, src.cap,
                            (const BfgsPairState*)b.state.p, (const float4*)tgt.pts.p, (const int*)tgt.orig.p, (const Cov6*)tgt.cov.p,
                            (const HashSlot*)tgt.table.p, (const GridMeta*)tgt.meta.p, tgt.cap, tgt.slots_cap, (const int*)b.tgt_of_src.p, max_d2, b.G, S,
-                           b.corr.p, b.mahal.p, b.pitch);
+                           b.corr.p, b.mahal.p, b.pitch, tiles ? (const float4*)b.qsearch.p : (const float4*)nullptr);
       }
       hipLaunchKernelGGL(k_bfgs_cost, grid, dim3(kBfgsBlock), 0, s, (const float4*)src.pts.p, src.cap, (const BfgsPairState*)b.state.p,
                          (const float4*)tgt.pts.p, tgt.cap, (const int*)b.tgt_of_src.p, (const int*)b.corr.p, (const double*)b.mahal.p, b.pitch, b.G, S,

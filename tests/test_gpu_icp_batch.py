@@ -22,7 +22,7 @@ def R():
 def test_batch_icp_matches_single_and_oracle(R, small_pair, max_iterations):
     s, t, T = small_pair
     cap = max(len(s), len(t)) + 7
-    nS, nT = 7, 2
+    nS, nT = 9, 2  # (>= 8 pairs: the batch searches by wave-cooperative tiles while a pair moves, the registration object - a batch of one - per lane)
     srcs = np.zeros((nS, cap, 4), np.float32)
     tgts = np.zeros((nT, cap, 4), np.float32)
     shifts = [np.eye(4, dtype=np.float32), synth.se3(0.2, -0.1, 0, 0, 0, 0.01).astype(np.float32)]
@@ -37,7 +37,7 @@ def test_batch_icp_matches_single_and_oracle(R, small_pair, max_iterations):
         ns.append(len(si))
     ns[5] = 0  # an empty source
     srcs[6, : ns[6], :3] += 1000.0  # nothing within 30 m: "Not enough correspondences found"
-    tgt_of_src = [0, 1, 0, 1, 1, 0, 0]
+    tgt_of_src = [0, 1, 0, 1, 1, 0, 0, 1, 0]
     guesses = np.tile(np.eye(4, dtype=np.float32), (nS, 1, 1))
     guesses[2] = (T @ synth.se3(0.05, -0.03, 0.0, 0, 0, 0.004)).astype(np.float32)
     guesses[3] = synth.se3(0.5, -0.1, 0, 0, 0, -0.01)
@@ -48,7 +48,7 @@ def test_batch_icp_matches_single_and_oracle(R, small_pair, max_iterations):
     b.align(tgt_of_src, guesses=guesses, with_fitness=True)
     res, fit = b.results(with_fitness=True)
     single = R.IterativeClosestPoint(**kw)
-    for i in range(5):
+    for i in (0, 1, 2, 3, 4, 7, 8):
         si, ti = srcs[i, : ns[i]], tgts[tgt_of_src[i], : nt[tgt_of_src[i]]]
         single.setInputTarget(ti)
         single.setInputSource(si)
