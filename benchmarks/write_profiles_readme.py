@@ -82,7 +82,7 @@ batch, one batch at a time, 20 timed steps, 5 warm-ups; 64 k-point pairs, distan
         ((f"{R}_config5_1gpu.json",), "BASELINE config 5 at its stated size — 4 096 candidates × 64 sub-maps — through `mi355_multi_batch_register` on ONE GPU with 2 lanes, host views in (pinned staging), results out: `benchmarks/config5.py --candidates 4096 --submaps 64 --multi-lanes 2`"),
         ((f"{R}_config5_FAST_GICP.json", f"{R}_config5_ICP.json", f"{R}_config5_NDT_OMP.json", f"{R}_config5_GICP.json"), "the same candidate list through one `BatchRegistration` per rank (`benchmarks/config5.py --method …`: uploads + registration + fitness + read-back, the shorter of two runs on one batch object), every engine `GraphBasedSLAM::get_registration` builds — ICP is that node's yaml default; each line carries a `cpu_baseline` (the oracle on four of the same candidates, 4 OpenMP threads).  NDT_OMP on 8 and BFGS GICP on 4 sub-maps near the map origin (DESIGN §3; `tests/test_oracle_ndt.py::test_far_from_the_map_origin_*` pins the NDT half of that claim against an all-fp64 NumPy NDT)"),
         ((f"{R}_kernel_stats_icp.csv", f"{R}_icp_launches.txt", f"{R}_config5_ICP_under_trace.json"), "**kernel-level rows of batched ICP** (the back end's default engine): `rocprofv3 --kernel-trace --stats` of `benchmarks/config5.py --method ICP --candidates 4096 --submaps 64` (`benchmarks/config5_trace.sh`), and the durations of `k_icp_correspond_tile` / `k_icp_step` in launch order"),
-        ((f"{R}_kernel_stats_bfgs.csv", f"{R}_bfgs_launches.txt", f"{R}_config5_GICP_under_trace.json"), "the same for pclomp's BFGS GICP (`--method GICP --submaps 4`): `k_bfgs_correspond`, `k_bfgs_cost`, `k_bfgs_advance`"),
+        ((f"{R}_kernel_stats_bfgs.csv", f"{R}_bfgs_launches.txt", f"{R}_config5_GICP_under_trace.json"), "the same for pclomp's BFGS GICP (`--method GICP --submaps 4`): `k_bfgs_move` + `k_moved_correspond_tile` (the tiles, for the pairs that start an outer iteration), `k_bfgs_correspond`, `k_bfgs_cost`, `k_bfgs_advance`"),
         ((f"{R}_knn_tile_counters.txt",), "`k_knn_cov_tile`'s own counters (`MI355_KNN_STATS=1`: candidates gathered / ranked per lane, rounds, phase clocks, hand-over) beside the PMC instruction counts"),
         ((f"{R}_parity_deltas.txt",), "worst GPU-vs-oracle pose difference per test family of one `pytest -m gpu` run (BASELINE.md §4)"),
         ((f"{R}_bench_sor.json",), "`python bench.py --sor --pairs 2048`: the reference's launch-file prefilter (leaf 0.1 m + StatisticalOutlierRemoval 30 / 1.2) — a different workload, never the headline; carries the SOR row"),
