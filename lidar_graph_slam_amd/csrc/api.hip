@@ -1624,7 +1624,9 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
       if (b->with_fitness) {
         std::vector<float> T((size_t)b->n_sources * 16);
         icp_batch_results(*b->icp, nullptr, T.data());
-        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
+        size_t seed_pitch = 0;
+        const int* seed = icp_batch_corr(*b->icp, &seed_pitch);
+        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data(), seed, seed_pitch);
       }
     } else if (b->method == MI355_METHOD_GICP) {
       Part& pt = *b->parts[0];
@@ -1636,7 +1638,9 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
       if (b->with_fitness) {
         std::vector<float> T((size_t)b->n_sources * 16);
         bfgs_batch_results(*b->bfgs, nullptr, T.data());
-        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data());
+        size_t seed_pitch = 0;
+        const int* seed = bfgs_batch_corr(*b->bfgs, &seed_pitch);
+        gicp_fitness(main, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, false, T.data(), seed, seed_pitch);
       }
     } else {
       // every part's LM loop on its stream, behind the chains it needs: its own sources' and those of the targets its pairs name
@@ -1701,7 +1705,7 @@ extern "C" int mi355_batch_align(mi355_batch* b, const int* tgt_of_src, const fl
         if (pt.ns <= 0) continue;
         hipStream_t s = b->lm_stream(i);
         if (tuning().corr_stats) gicp_corr_stats_print(s, pt.gb);
-        if (b->with_fitness) gicp_fitness(s, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, true, nullptr);
+        if (b->with_fitness) gicp_fitness(s, pt.gb, pt.src, b->tgt, 1.7976931348623157e308, true, nullptr, (const int*)pt.gb.corr.p, pt.src.cap);
         if (s != main) {  // join: what the caller enqueues on the batch's stream next comes after this alignment
           MI_HIP(hipEventRecord(pt.lm_done, s));
           MI_HIP(hipStreamWaitEvent(main, pt.lm_done, 0));

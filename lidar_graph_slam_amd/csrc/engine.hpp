@@ -195,8 +195,10 @@ void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb);  // Tuning::corr_stats
 // parity probe: incremental correspondences at the final pose vs a from-scratch search (batches of >= 8 pairs: k_gicp_correspond)
 void gicp_verify_correspondences(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, const mi355_gicp_params& p, long long* n_checked,
                                  long long* n_mismatch);
+// seed_corr (optional): [S][seed_pitch] a correspondent per sorted source point from the engine's last iteration (-1: none) - its distance at the
+// final pose bounds the search from the start; the score is the same sum of exact nearest distances
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
-                  const float* T16_host_all);
+                  const float* T16_host_all, const int* seed_corr = nullptr, size_t seed_pitch = 0);
 void gicp_results(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, mi355_result* out, double* fitness_out);
 // per pair: the iteration count at which is_converged first held (-1: never); synchronises
 void gicp_first_converged(hipStream_t s, GicpBatch& gb, int* out);
@@ -223,6 +225,7 @@ void icp_correspond_tiles(hipStream_t s, const float4* cur, size_t cpitch, const
 struct IcpBatch;
 IcpBatch* icp_batch_create();
 void icp_batch_destroy(IcpBatch*);
+const int* icp_batch_corr(const IcpBatch& b, size_t* pitch);  // the correspondents of the last iteration (seeds of the fitness search)
 // src: [S][spitch] points in any order, counts on the device, none above max_count; tgt: built sets (the NN voxel hash is all
 // point-to-point ICP needs); pair p registers against target tgt_of_src_host[p] (nullptr: p).  Blocks until every pair is done.
 void icp_batch_align(hipStream_t s, IcpBatch& b, int S, const float4* d_src, size_t spitch, const int* d_src_counts, size_t max_count, const CloudSet& tgt,
@@ -242,6 +245,7 @@ void icp_align(hipStream_t s, IcpScratch& sc, const CloudSet& tgt, const float4*
 struct BfgsBatch;
 BfgsBatch* bfgs_batch_create();
 void bfgs_batch_destroy(BfgsBatch*);
+const int* bfgs_batch_corr(const BfgsBatch& b, size_t* pitch);  // the correspondents of the last outer iteration (seeds of the fitness search)
 // src / tgt: built sets with PLANE covariances; pair p registers source p against target tgt_of_src_host[p] (nullptr: p); no source
 // holds more than max_count points.  Blocks until every pair is done.
 void bfgs_batch_align(hipStream_t s, BfgsBatch& b, int S, const CloudSet& src, const CloudSet& tgt, size_t max_count, const int* tgt_of_src_host,

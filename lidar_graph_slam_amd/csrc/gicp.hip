@@ -2077,7 +2077,7 @@ __global__ __launch_bounds__(kGicpBlock) void k_fitness(const float4* __restrict
                                                         const HashSlot* __restrict__ ttable, const GridMeta* __restrict__ tmeta, size_t tcap,
                                                         size_t tslots, const int* __restrict__ tgt_of_src, const GicpPairState* __restrict__ state,
                                                         const float* __restrict__ T_all, double* __restrict__ fit_partials, float search_d2,
-                                                        double max_range) {
+                                                        double max_range, const int* __restrict__ seed, size_t seed_pitch) {
   __shared__ double smem[4 * 2];
   const int pair = blockIdx.y;
   const GridView g = grid_view(tpts, torig, ttable, tmeta, tgt_of_src[pair], tcap, tslots);
@@ -2098,7 +2098,26 @@ __global__ __launch_bounds__(kGicpBlock) void k_fitness(const float4* __restrict
     const float4 p = spts[so + i];
     const float qx = transform_row(Tf, p.x, p.y, p.z), qy = transform_row(Tf + 4, p.x, p.y, p.z), qz = transform_row(Tf + 8, p.x, p.y, p.z);
     Nearest1 nn{g.orig, INFINITY, -1};
-    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, search_d2, nn, 0, 2);
+    float lim = search_d2;
+    int level0 = 0, level_step = 2;
+    if (seed) {
+      // the engine's last correspondent of this point: the final pose is a last small step away from where it was found, so its distance
+      // bounds the walk from the start (the same exact nearest distance: the walk covers everything closer)
+      const int j0 = seed[(size_t)pair * seed_pitch + i];
+      if (j0 >= 0 && j0 < g.m.n) {
+        const float4 q0 = g.pts[j0];
+        const float d0 = dist2f(qx, qy, qz, q0.x, q0.y, q0.z);
+        if (d0 <= search_d2) {
+          nn.best_d2 = d0;
+          nn.best_j = j0;
+          lim = nextafterf(d0, INFINITY);
+          const float rel = sqrtf(d0) * g.m.inv_cell;
+          level0 = (rel <= 1.f) ? 0 : min(g.m.top_level, (int)ceilf(log2f(rel)));
+          level_step = 1;
+        }
+      }
+    }
+    if (isfinite(qx) && isfinite(qy) && isfinite(qz)) grid_search(g, qx, qy, qz, lim, nn, level0, level_step);
     if (nn.best_j >= 0 && (double)nn.best_d2 <= max_range) { acc[0] += (double)nn.best_d2; acc[1] += 1.0; }
   }
   block_sum<2, 4>(acc, smem);
@@ -2134,7 +2153,7 @@ void gicp_corr_stats_print(hipStream_t s, GicpBatch& gb) {
 }
 
 void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const CloudSet& tgt, double max_range, bool use_final_pose,
-                  const float* T16_host_all) {
+                  const float* T16_host_all, const int* seed_corr, size_t seed_pitch) {
   const float* dTp = nullptr;
   if (!use_final_pose) {
     gb.h_fit_T.assign(T16_host_all, T16_host_all + (size_t)gb.S * 16);
@@ -2145,7 +2164,7 @@ void gicp_fitness(hipStream_t s, GicpBatch& gb, const CloudSet& src, const Cloud
   const float search_d2 = (max_range >= 3.0e38) ? INFINITY : (float)(max_range * (1.0 + 1e-6)) + 1e-30f;
   TimedLaunch tl(KF_FITNESS, s);
   hipLaunchKernelGGL(k_fitness, dim3(gb.blocks_lin, gb.S), dim3(kGicpBlock), 0, s, src.pts.p, src.count.p, src.cap, tgt.pts.p, tgt.orig.p,
-                     tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, dTp, gb.fit_partials.p, search_d2, max_range);
+                     tgt.table.p, tgt.meta.p, tgt.cap, tgt.slots_cap, gb.tgt_of_src.p, gb.state.p, dTp, gb.fit_partials.p, search_d2, max_range, seed_corr, seed_pitch);
   hipLaunchKernelGGL(k_fitness_final, dim3(div_up(gb.S, 64)), dim3(64), 0, s, gb.fit_partials.p, gb.fitness.p, gb.S, gb.blocks_lin);
   MI_LAUNCH_CHECK();
 }

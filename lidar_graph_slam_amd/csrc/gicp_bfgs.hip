@@ -74,6 +74,7 @@ struct BfgsBatch {
 
 BfgsBatch* bfgs_batch_create() { return new BfgsBatch(); }
 void bfgs_batch_destroy(BfgsBatch* b) { delete b; }
+const int* bfgs_batch_corr(const BfgsBatch& b, size_t* pitch) { *pitch = b.pitch; return b.corr.p; }
 
 // Eigen's Matrix4f * Vector4f with w = 1, evaluated left to right (no fma: the oracle spells the same expression)
 __device__ __forceinline__ float row_apply(const float* r, float x, float y, float z) { return r[0] * x + r[1] * y + r[2] * z + r[3]; }

@@ -50,6 +50,7 @@ struct IcpBatch {
 };
 IcpBatch* icp_batch_create() { return new IcpBatch(); }
 void icp_batch_destroy(IcpBatch* b) { delete b; }
+const int* icp_batch_corr(const IcpBatch& b, size_t* pitch) { *pitch = b.pitch; return b.corr.p; }
 
 __global__ void k_icp_begin(IcpPairState* __restrict__ st, const float* __restrict__ guesses, const int* __restrict__ scount,
                             const GridMeta* __restrict__ tmeta, const int* __restrict__ tgt_of_src, int S) {
