@@ -244,10 +244,12 @@ def test_config4_at_its_stated_size_1000_scans(ground_max_range):
     assert o["n_key_frames"] == n_kf + 1 and o["target_points"] > 150_000
 
 
-@pytest.mark.parametrize("method,n", [("FAST_GICP", 512), ("NDT_OMP", 128)])
+@pytest.mark.parametrize("method,n", [("FAST_GICP", 512), ("NDT_OMP", 128), ("ICP", 128)])
 def test_config5_per_gpu_share_of_the_loop_closure_batch(method, n):
     """FAST_GICP: the 512-candidate per-GPU share of BASELINE configs[4].  NDT_OMP (graph_based_slam.cpp:101-119, 1.0 m cells as
-    graph_based_slam.param.yaml:18): the same candidates through the batched NDT, every pair's More-Thuente state on the device."""
+    graph_based_slam.param.yaml:18): the same candidates through the batched NDT, every pair's More-Thuente state on the device.  ICP - the back
+    end's yaml default (graph_based_slam.param.yaml:9, graph_based_slam.cpp:142-151: 30 m, 100 iterations, 1e-8, 1e-6): the candidates through the
+    batched ICP, its first iterations on the wave-cooperative tiles (128 pairs >= 8), the settled ones on search margins."""
     from lidar_graph_slam_amd import loop_batch
     from lidar_graph_slam_amd.filters import PointsPreFiltering
 
@@ -287,13 +289,16 @@ def test_config5_per_gpu_share_of_the_loop_closure_batch(method, n):
             submaps[s] = np.concatenate(parts, axis=0)
         return submaps[s]
 
-    kw = dict(max_iterations=64) if method == "FAST_GICP" else dict(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01)
+    kw = {"FAST_GICP": dict(max_iterations=64), "NDT_OMP": dict(max_iterations=100, resolution=1.0, step_size=0.1, transformation_epsilon=0.01),
+          "ICP": dict(max_iterations=100, max_correspondence_distance=30.0, transformation_epsilon=1e-8, euclidean_fitness_epsilon=1e-6)}[method]
     out = loop_batch.register_sharded(tgt_of_src, load_source, load_target, 100_000, target_prefilter=loop_batch.voxel_prefilter(0.5), method=method, **kw)
     assert out["reported"].all() and (out["status"] == 0).all()
     errs = np.array([synth.pose_error(out["T"][p], true_pose(p) @ np.linalg.inv(graph_pose(p))) for p in range(n)])
     accepted = out["converged"] & (out["fitness"] < 0.3)  # graph_based_slam.cpp:321-328
     if method == "FAST_GICP":
         assert accepted.sum() >= 0.98 * n and (errs[accepted, 0] < 0.05).mean() > 0.98, (accepted.sum(), np.median(errs[:, 0]))
+    elif method == "ICP":  # point-to-point with a 30 m range on voxel-filtered surfaces: decimetres, like the oracle (benchmarks/config5.py: median 5 - 9 cm)
+        assert accepted.sum() >= 0.9 * n and np.median(errs[accepted, 0]) < 0.15, (accepted.sum(), np.median(errs[:, 0]))
     else:  # NDT with 1 m cells from up to 1.5 m / 4 deg off: coarser, and some candidates stay in a neighbouring basin — like the oracle
         assert accepted.sum() >= 0.9 * n and np.median(errs[accepted, 0]) < 0.10, (accepted.sum(), np.median(errs[:, 0]))
     # a sample against the oracle: same voxel-filtered sub-map, same candidate, identity guess (graph_based_slam.cpp:311-322)
@@ -302,6 +307,9 @@ def test_config5_per_gpu_share_of_the_loop_closure_batch(method, n):
         assert out["n_target"][p] == len(t)
         if method == "FAST_GICP":
             ref = O.gicp_align(load_source(p), t, O.gicp_params(max_iterations=64))
+        elif method == "ICP":
+            ref = O.icp_align(load_source(p), t, O.icp_params(**kw))
+            assert abs(int(out["iterations"][p]) - ref["iterations"]) <= 2, (p, out["iterations"][p], ref["iterations"])
         else:
             ref = O.ndt_align(load_source(p), t, O.ndt_params(**kw))
             assert abs(int(out["iterations"][p]) - ref["iterations"]) <= 2, (p, out["iterations"][p], ref["iterations"])
